@@ -1,0 +1,156 @@
+/* ssx_fmath.h -- the float transcendentals that are part of the parity contract.
+ *
+ * Why this exists: the reference calls the platform libm (std::sin / std::cos / std::acos on
+ * float: reference src/util/random.cpp:33-34,108-115,135, src/util/spherical-tri.cpp:25-27,
+ * 39-41,67-69) and does not pin it.  The spherical-triangle solid angle is ill-conditioned in
+ * f32, so a 1-ulp libm difference flips discrete path decisions (SURVEY.md 8(c) "libm
+ * sensitivity").  A GPU cannot call glibc, so the build defines these three functions once, with
+ * IEEE-754 basic operations only (+ - * sqrt fma in binary64, round-to-nearest-even, no
+ * contraction, no table lookups), so that x86-64 and gfx950 produce the same bits.  The CPU
+ * oracle (oracle/) and the HIP kernels both include this header; tests/test_fmath.py pins it
+ * against correctly rounded values computed with mpmath.
+ *
+ * Definition: ssx_sinf(x) = RN_f32(s) where s is a binary64 evaluation of sin(x) with relative
+ * error < 2^-50 for |x| <= 2^20 (so the result is the correctly rounded float except when sin(x)
+ * lies within 2^-50 relative of a float rounding boundary).  Same for ssx_cosf and ssx_acosf.
+ * Outside the domain (|x| > 2^20, NaN, inf; |x| > 1 for acos) the result is NaN.
+ *
+ * Plain C99 / C++17 / HIP.  Compile every user of this header with -ffp-contract=off.
+ */
+#ifndef SSX_FMATH_H
+#define SSX_FMATH_H
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define SSX_FM_FN static __host__ __device__ __forceinline__
+#else
+#define SSX_FM_FN static inline
+#endif
+
+/* fma is an exactly specified IEEE operation: hardware v_fma_f64 on gfx950, vfmadd or the
+ * correctly rounded software fma() of libm on the host. */
+#define SSX_FMA(a, b, c) __builtin_fma((a), (b), (c))
+
+/* Cody-Waite reduction by pi/2: n = rint(x*2/pi), r = (x - n*P1) - n*P1T.
+ * P1 holds the leading 33 bits of pi/2, so n*P1 is exact for |n| <= 2^20. */
+SSX_FM_FN int ssx_fm_reduce(double x, double* r_out) {
+	const double inv_pio2 = 0x1.45f306dc9c883p-1;  /* 2/pi */
+	const double pio2_1   = 0x1.921fb54400000p+0;  /* leading 33 bits of pi/2 */
+	const double pio2_1t  = 0x1.0b4611a626331p-34; /* pi/2 - pio2_1 */
+	const double shifter  = 0x1.8p52;               /* 1.5*2^52: adds then removes -> rint */
+	double fn = (x * inv_pio2 + shifter) - shifter;
+	*r_out = (x - fn * pio2_1) - fn * pio2_1t;
+	return (int)fn;
+}
+
+/* sin(r), |r| <= pi/4 (+rounding slack): r + r^3*(S1 + z*(S2 + ... + z*S8)), S_k = (-1)^k/(2k+1)!;
+ * first dropped term r^19/19! < 1e-19. */
+SSX_FM_FN double ssx_fm_ksin(double r) {
+	double z = r * r;
+	double p =      0x1.952c77030ad4ap-49;   /*  1/17! */
+	p = SSX_FMA(p, z, -0x1.ae7f3e733b81fp-41); /* -1/15! */
+	p = SSX_FMA(p, z,  0x1.6124613a86d09p-33); /*  1/13! */
+	p = SSX_FMA(p, z, -0x1.ae64567f544e4p-26); /* -1/11! */
+	p = SSX_FMA(p, z,  0x1.71de3a556c734p-19); /*  1/9!  */
+	p = SSX_FMA(p, z, -0x1.a01a01a01a01ap-13); /* -1/7!  */
+	p = SSX_FMA(p, z,  0x1.1111111111111p-7);  /*  1/5!  */
+	p = SSX_FMA(p, z, -0x1.5555555555555p-3);  /* -1/3!  */
+	return SSX_FMA(r * z, p, r);
+}
+
+/* cos(r), |r| <= pi/4: 1 - z/2 + z^2*(C2 + z*(C3 + ... + z*C9)), C_k = (-1)^k/(2k)!;
+ * first dropped term r^20/20! < 1e-20. */
+SSX_FM_FN double ssx_fm_kcos(double r) {
+	double z = r * r;
+	double p =     -0x1.6827863b97d97p-53;   /* -1/18! */
+	p = SSX_FMA(p, z,  0x1.ae7f3e733b81fp-45); /*  1/16! */
+	p = SSX_FMA(p, z, -0x1.93974a8c07c9dp-37); /* -1/14! */
+	p = SSX_FMA(p, z,  0x1.1eed8eff8d898p-29); /*  1/12! */
+	p = SSX_FMA(p, z, -0x1.27e4fb7789f5cp-22); /* -1/10! */
+	p = SSX_FMA(p, z,  0x1.a01a01a01a01ap-16); /*  1/8!  */
+	p = SSX_FMA(p, z, -0x1.6c16c16c16c17p-10); /* -1/6!  */
+	p = SSX_FMA(p, z,  0x1.5555555555555p-5);  /*  1/4!  */
+	double hz = 0.5 * z;
+	/* (1 - hz) + z*z*p, with 1-hz exact-ish (hz <= 0.31) */
+	return SSX_FMA(z * z, p, 1.0 - hz);
+}
+
+SSX_FM_FN void ssx_sincosf(float xf, float* s_out, float* c_out) {
+	double x = (double)xf;
+	double ax = x < 0.0 ? -x : x;
+	if (!(ax <= 1048576.0)) { /* NaN, inf, out of domain */
+		float q = xf - xf; q = q / q;
+		*s_out = q; *c_out = q;
+		return;
+	}
+	double r;
+	int n = ssx_fm_reduce(x, &r);
+	double s = ssx_fm_ksin(r);
+	double c = ssx_fm_kcos(r);
+	double so = (n & 1) ? c : s;
+	double co = (n & 1) ? s : c;
+	if (n & 2) so = -so;
+	if ((n + 1) & 2) co = -co;
+	*s_out = (float)so;
+	*c_out = (float)co;
+}
+
+SSX_FM_FN float ssx_sinf(float xf) {
+	double x = (double)xf;
+	double ax = x < 0.0 ? -x : x;
+	if (!(ax <= 1048576.0)) { float q = xf - xf; return q / q; }
+	double r;
+	int n = ssx_fm_reduce(x, &r);
+	double v = (n & 1) ? ssx_fm_kcos(r) : ssx_fm_ksin(r);
+	if (n & 2) v = -v;
+	return (float)v;
+}
+
+SSX_FM_FN float ssx_cosf(float xf) {
+	double x = (double)xf;
+	double ax = x < 0.0 ? -x : x;
+	if (!(ax <= 1048576.0)) { float q = xf - xf; return q / q; }
+	double r;
+	int n = ssx_fm_reduce(x, &r);
+	double v = (n & 1) ? ssx_fm_ksin(r) : ssx_fm_kcos(r);
+	if ((n + 1) & 2) v = -v;
+	return (float)v;
+}
+
+/* asin(s) = s + s*z*P(z), z = s*s in [0, 0.25]; P from tools/gen_fmath_coeffs.py (degree 11
+ * Chebyshev fit, max abs error of P 2.3e-16 -> relative error of asin < 6e-17). */
+SSX_FM_FN double ssx_fm_asin_poly(double z) {
+	double p =      0x1.cd864394d2ff2p-6;
+	p = SSX_FMA(p, z, -0x1.603991d6060e0p-7);
+	p = SSX_FMA(p, z,  0x1.06b9d26d10838p-6);
+	p = SSX_FMA(p, z,  0x1.ff5fc4d14c735p-8);
+	p = SSX_FMA(p, z,  0x1.8522ddffa6208p-7);
+	p = SSX_FMA(p, z,  0x1.c87265d47ef49p-7);
+	p = SSX_FMA(p, z,  0x1.1c593c7b1d958p-6);
+	p = SSX_FMA(p, z,  0x1.6e8b2b3b10be4p-6);
+	p = SSX_FMA(p, z,  0x1.f1c71f95269afp-6);
+	p = SSX_FMA(p, z,  0x1.6db6db684b6a1p-5);
+	p = SSX_FMA(p, z,  0x1.3333333336da5p-4);
+	p = SSX_FMA(p, z,  0x1.555555555554fp-3);
+	return p;
+}
+
+SSX_FM_FN float ssx_acosf(float xf) {
+	const double pio2_hi = 0x1.921fb54442d18p+0, pio2_lo = 0x1.1a62633145c07p-54;
+	const double pi_hi   = 0x1.921fb54442d18p+1, pi_lo   = 0x1.1a62633145c07p-53;
+	double x = (double)xf;
+	double ax = x < 0.0 ? -x : x;
+	if (!(ax <= 1.0)) { float q = xf - xf; return q / q; }
+	if (ax <= 0.5) {
+		double z = x * x;
+		double t = SSX_FMA(x * z, ssx_fm_asin_poly(z), x); /* asin(x) */
+		return (float)(pio2_hi - (t - pio2_lo));
+	}
+	double z = (1.0 - ax) * 0.5;            /* exact */
+	double s = __builtin_sqrt(z);           /* correctly rounded */
+	double t = SSX_FMA(s * z, ssx_fm_asin_poly(z), s); /* asin(s) = acos(ax)/2 */
+	double r = t + t;
+	if (x < 0.0) r = pi_hi - (r - pi_lo);
+	return (float)r;
+}
+
+#endif /* SSX_FMATH_H */
