@@ -1,0 +1,158 @@
+/* ssx.h -- C ABI of the MI355X spectral path-tracing core (libssx_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of geometrian/simple-spectral: the body of
+ * Renderer::_render_threadwork (reference src/renderer.cpp:309-395) -- the tile loop, the
+ * per-pixel sample loop (_render_pixel, :278-308) and the radiance recursion (_render_sample,
+ * :104-277) -- between "Options + Scene + Color tables exist" and "framebuffer(i,j) is filled".
+ * The reference has no FFI layer (single executable); the entry points below are what a
+ * maintainer would bind in its place (INTEGRATION.md shows the C++ stub).
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Every function returns 0 (SSX_OK) or a
+ * negative code mirroring the reference's `throw int` values (-1 data/I-O, -2 argument, -3 unknown
+ * scene/variant; reference src/main.cpp:78,100, src/renderer.cpp:37, src/spectrum.cpp:19,181,197,
+ * 208, src/material.cpp:17) plus device failures.  The host owns every pointer it passes; the
+ * library copies what it needs during the call and owns all device allocations.
+ * There is NO CPU fallback: without a gfx950 device ssx_create fails with SSX_ERR_DEVICE.
+ */
+#ifndef SSX_H
+#define SSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSX_ABI_VERSION 1
+
+enum {
+	SSX_OK = 0,
+	SSX_ERR_DATA = -1,    /* bad table / texture data */
+	SSX_ERR_ARG = -2,     /* bad argument */
+	SSX_ERR_SCENE = -3,   /* unknown scene / unsupported variant */
+	SSX_ERR_DEVICE = -10, /* HIP failure or no device */
+	SSX_ERR_STATE = -11   /* call not valid in the current state */
+};
+
+/* Compile-time constants of the reference this core is built for (src/stdafx.hpp:44-93). */
+#define SSX_MAX_DEPTH 10u          /* MAX_DEPTH */
+#define SSX_TILE_SIZE 8u           /* TILE_SIZE */
+#define SSX_SAMPLE_WAVELENGTHS 4u  /* SAMPLE_WAVELENGTHS */
+#define SSX_MAX_TEXTURES 4u
+#define SSX_MAX_QUADS 32u          /* one candidate bit pair per quad in a 64-bit lane mask */
+
+/* _Spectrum (reference src/spectrum.hpp:12-31): n uniform samples over [low,high]. */
+typedef struct ssx_spectrum {
+	uint32_t offset;   /* first sample in ssx_scene_desc.samples */
+	uint32_t n;        /* >= 2 */
+	float low, high;
+	float delta_recip; /* float(n-1)/(high-low), src/spectrum.cpp:22-25 */
+} ssx_spectrum;
+
+/* Vertex (src/geometry.hpp:13-22) */
+typedef struct ssx_vertex { float pos[3]; float st[2]; } ssx_vertex;
+
+/* PrimQuad = tri0(v00,v10,v11) + tri1(v00,v11,v01) (src/geometry.hpp:76-103); normals are the
+ * host-computed PrimTri normals (src/geometry.hpp:68). */
+typedef struct ssx_quad {
+	ssx_vertex v00, v10, v11, v01;
+	float normal0[3], normal1[3];
+	uint32_t material;
+	uint32_t is_light; /* material->is_emissive() at construction, src/geometry.cpp:7-9 */
+} ssx_quad;
+
+enum { SSX_MTL_LAMBERTIAN = 0, SSX_MTL_MIRROR = 1 };   /* src/material.hpp:144-176 */
+enum { SSX_ALBEDO_CONSTANT = 0, SSX_ALBEDO_TEXTURE = 1 }; /* MaterialSimpleAlbedoBase::MODE */
+
+typedef struct ssx_material {
+	uint32_t kind;
+	uint32_t albedo_mode;
+	uint32_t albedo_spectrum;   /* index into spectra (CONSTANT) */
+	uint32_t albedo_texture;    /* index into textures (TEXTURE) */
+	uint32_t emission_spectrum; /* index into spectra */
+} ssx_material;
+
+/* sRGB_ReflectanceTexture (src/material.hpp:14-45): RGB8, rows top to bottom. */
+typedef struct ssx_texture { uint32_t width, height; const uint8_t* rgb; } ssx_texture;
+
+/* Everything the kernel reads: the flattened Scene (src/scene.hpp:16-66) + Color::data tables
+ * (src/util/color.hpp:22-68).  Uplift = "ours" basis (RENDER_MODE_SPECTRAL_ALGNUM 1). */
+typedef struct ssx_scene_desc {
+	uint32_t struct_size; /* sizeof(ssx_scene_desc) */
+	uint32_t reserved;
+	double pv_inv[16];    /* camera.matr_PV_inv, column-major (src/scene.cpp:24) */
+	float cam_pos[3];     /* camera.pos */
+	float lambda_min;     /* LAMBDA_MIN */
+	float lambda_step;    /* LAMBDA_STEP = (LAMBDA_MAX-LAMBDA_MIN)/4 (src/stdafx.hpp:289) */
+	uint32_t spec_xbar, spec_ybar, spec_zbar;          /* std_obs_{x,y,z}bar */
+	uint32_t spec_basis_r, spec_basis_g, spec_basis_b; /* basis_bt709.{r,g,b} */
+	const ssx_spectrum* spectra;  uint32_t n_spectra;
+	const float* samples;         uint32_t n_samples;
+	const ssx_material* materials; uint32_t n_materials;
+	const ssx_quad* quads;        uint32_t n_quads;   /* Scene::primitives, in order */
+	const uint32_t* lights;       uint32_t n_lights;  /* Scene::lights (indices into quads) */
+	const ssx_texture* textures;  uint32_t n_textures;
+	/* srgb_to_lrgb(u8*(1/255)) for u8=0..255 (src/material.cpp:52-56, src/util/color.hpp:91-97):
+	 * built by the host with the platform powf, exactly as the reference evaluates it per texel. */
+	float srgb_to_linear[256];
+} ssx_scene_desc;
+
+/* One render = Renderer::render_start..render_wait (src/renderer.cpp:396-430) for this device's
+ * share of the 8x8 tile list (src/renderer.cpp:396-409; row-major tile index t = ty*ceil(W/8)+tx). */
+typedef struct ssx_render_params {
+	uint32_t struct_size;
+	uint32_t width, height;   /* Options::res */
+	uint32_t spp;             /* Options::spp: the pixel mean divides by this */
+	uint32_t indirect_only;   /* Options::indirect_only */
+	uint32_t tile_first;      /* this device renders tiles t with t % tile_stride == tile_first ... */
+	uint32_t tile_stride;     /* ... (1 = whole image); other pixels are written as 0 */
+	uint32_t spp_per_launch;  /* progress/cancel granularity; 0 = library default */
+	uint64_t seed;            /* seeding contract below */
+} ssx_render_params;
+
+/* Seeding contract (build-defined; the shipped reference is racy):
+ * sample k of pixel p=j*W+i uses its own PCG32 stream
+ *     a = mix64(seed + G*(p+1)); b = mix64(a + G*(k+1)); state = b; inc = mix64(b ^ C) | 1
+ * with G=0x9E3779B97F4A7C15, C=0xDA3E39CB94B95BDB and mix64 the splitmix64 finaliser; samples of
+ * a pixel are accumulated in ascending k as double += float(sample*0.001f) (src/renderer.cpp:
+ * 292-296).  The image is therefore independent of tile partition, launch size and device. */
+
+typedef struct ssx_ctx ssx_ctx;
+
+/* Renderer::Renderer / ~Renderer (src/renderer.cpp:12-51).  device = HIP ordinal. */
+int ssx_create(int device, ssx_ctx** out);
+void ssx_destroy(ssx_ctx* ctx);
+
+/* Replaces handing `Scene*` + `Color::data` to the worker threads (src/renderer.cpp:33,163,189). */
+int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* scene);
+
+/* Renderer::render_start (src/renderer.cpp:396-422): returns at once, work proceeds on the device. */
+int ssx_render_start(ssx_ctx* ctx, const ssx_render_params* params);
+/* Renderer::render_stop (src/renderer.hpp:77): cooperative, takes effect between launches. */
+int ssx_render_stop(ssx_ctx* ctx);
+/* Renderer::is_rendering (src/renderer.hpp:81) */
+int ssx_is_rendering(ssx_ctx* ctx);
+/* the `part` of Renderer::_print_progress (src/renderer.cpp:75): fraction in [0,1] */
+float ssx_progress(ssx_ctx* ctx);
+/* Renderer::render_wait (src/renderer.cpp:423-430) + read-back of what `framebuffer(i,j)=...`
+ * (src/renderer.cpp:298) would receive BEFORE ciexyz_to_srgb: float4 {X,Y,Z,alpha} per pixel,
+ * index j*W+i, row 0 = bottom (src/framebuffer.hpp:26-34).  xyza_out may be NULL. */
+int ssx_render_wait(ssx_ctx* ctx, float* xyza_out);
+
+/* Same render, enqueued on the caller's HIP stream into a caller-owned DEVICE buffer of
+ * width*height float4 (no host synchronisation; used when the framebuffer stays on the GPU, e.g.
+ * for the RCCL reduce).  hip_stream is a hipStream_t (NULL = default stream). */
+int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* params, void* d_xyza_out, void* hip_stream);
+
+/* Last error text for ctx (or for ssx_create when ctx is NULL). */
+const char* ssx_last_error(const ssx_ctx* ctx);
+
+/* Introspection: ABI version, and per-kernel resource usage for reports. */
+int ssx_abi_version(void);
+int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* scratch_bytes, int* max_blocks_per_cu);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSX_H */

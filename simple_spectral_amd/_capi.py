@@ -1,0 +1,117 @@
+"""ctypes view of the C ABI (include/ssx.h) and of the host library (include/ssx_host.h)."""
+import ctypes as C
+import os
+
+from . import build as _build
+
+
+class SsxSpectrum(C.Structure):
+    _fields_ = [("offset", C.c_uint32), ("n", C.c_uint32), ("low", C.c_float), ("high", C.c_float),
+                ("delta_recip", C.c_float)]
+
+
+class SsxVertex(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("st", C.c_float * 2)]
+
+
+class SsxQuad(C.Structure):
+    _fields_ = [("v00", SsxVertex), ("v10", SsxVertex), ("v11", SsxVertex), ("v01", SsxVertex),
+                ("normal0", C.c_float * 3), ("normal1", C.c_float * 3),
+                ("material", C.c_uint32), ("is_light", C.c_uint32)]
+
+
+class SsxMaterial(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("albedo_mode", C.c_uint32), ("albedo_spectrum", C.c_uint32),
+                ("albedo_texture", C.c_uint32), ("emission_spectrum", C.c_uint32)]
+
+
+class SsxTexture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb", C.POINTER(C.c_uint8))]
+
+
+class SsxSceneDesc(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("reserved", C.c_uint32),
+        ("pv_inv", C.c_double * 16), ("cam_pos", C.c_float * 3),
+        ("lambda_min", C.c_float), ("lambda_step", C.c_float),
+        ("spec_xbar", C.c_uint32), ("spec_ybar", C.c_uint32), ("spec_zbar", C.c_uint32),
+        ("spec_basis_r", C.c_uint32), ("spec_basis_g", C.c_uint32), ("spec_basis_b", C.c_uint32),
+        ("spectra", C.POINTER(SsxSpectrum)), ("n_spectra", C.c_uint32),
+        ("samples", C.POINTER(C.c_float)), ("n_samples", C.c_uint32),
+        ("materials", C.POINTER(SsxMaterial)), ("n_materials", C.c_uint32),
+        ("quads", C.POINTER(SsxQuad)), ("n_quads", C.c_uint32),
+        ("lights", C.POINTER(C.c_uint32)), ("n_lights", C.c_uint32),
+        ("textures", C.POINTER(SsxTexture)), ("n_textures", C.c_uint32),
+        ("srgb_to_linear", C.c_float * 256),
+    ]
+
+
+class SsxRenderParams(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32),
+                ("indirect_only", C.c_uint32), ("tile_first", C.c_uint32), ("tile_stride", C.c_uint32),
+                ("spp_per_launch", C.c_uint32), ("seed", C.c_uint64)]
+
+
+SSX_OK, SSX_ERR_DATA, SSX_ERR_ARG, SSX_ERR_SCENE, SSX_ERR_DEVICE, SSX_ERR_STATE = 0, -1, -2, -3, -10, -11
+
+# every symbol include/ssx.h and include/ssx_host.h declare (tests check the libraries export them)
+HIP_SYMBOLS = ["ssx_create", "ssx_destroy", "ssx_upload_scene", "ssx_render_start", "ssx_render_stop",
+               "ssx_is_rendering", "ssx_progress", "ssx_render_wait", "ssx_render_device", "ssx_last_error",
+               "ssx_abi_version", "ssx_kernel_info"]
+HOST_SYMBOLS = ["ssh_scene_create", "ssh_scene_destroy", "ssh_scene_desc", "ssh_xyza_to_srgba", "ssh_save_image",
+                "ssh_load_png_rgb8", "ssh_free", "ssh_color_values", "ssh_last_error"]
+
+_hip = None
+_host = None
+
+
+def host_lib():
+    global _host
+    if _host is None:
+        path = _build.HOST_LIB
+        if not os.path.exists(path):
+            _build.build_host()
+        lib = C.CDLL(path)
+        vp = C.c_void_p
+        lib.ssh_last_error.restype = C.c_char_p
+        lib.ssh_scene_create.argtypes = [C.c_char_p, C.c_char_p, C.c_int, vp, C.c_uint32, C.c_uint32, C.c_char_p,
+                                         C.c_float, C.POINTER(vp)]
+        lib.ssh_scene_destroy.argtypes = [vp]
+        lib.ssh_scene_desc.restype = C.POINTER(SsxSceneDesc)
+        lib.ssh_scene_desc.argtypes = [vp]
+        lib.ssh_xyza_to_srgba.argtypes = [vp, vp, vp, C.c_size_t]
+        lib.ssh_save_image.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32]
+        lib.ssh_load_png_rgb8.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_uint32),
+                                          C.POINTER(C.c_uint32)]
+        lib.ssh_free.argtypes = [vp]
+        lib.ssh_color_values.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_int]
+        _host = lib
+    return _host
+
+
+def hip_lib():
+    """The HIP library.  There is no fallback: a missing library is an error."""
+    global _hip
+    if _hip is None:
+        path = _build.HIP_LIB
+        if not os.path.exists(path):
+            raise RuntimeError("%s is missing: run `python -m simple_spectral_amd.build` (needs hipcc). "
+                               "simple_spectral_amd has no CPU or PyTorch fallback path." % path)
+        lib = C.CDLL(path)
+        vp = C.c_void_p
+        lib.ssx_last_error.restype = C.c_char_p
+        lib.ssx_last_error.argtypes = [vp]
+        lib.ssx_create.argtypes = [C.c_int, C.POINTER(vp)]
+        lib.ssx_destroy.argtypes = [vp]
+        lib.ssx_destroy.restype = None
+        lib.ssx_upload_scene.argtypes = [vp, C.POINTER(SsxSceneDesc)]
+        lib.ssx_render_start.argtypes = [vp, C.POINTER(SsxRenderParams)]
+        lib.ssx_render_stop.argtypes = [vp]
+        lib.ssx_is_rendering.argtypes = [vp]
+        lib.ssx_progress.argtypes = [vp]
+        lib.ssx_progress.restype = C.c_float
+        lib.ssx_render_wait.argtypes = [vp, vp]
+        lib.ssx_render_device.argtypes = [vp, C.POINTER(SsxRenderParams), vp, vp]
+        lib.ssx_kernel_info.argtypes = [vp] + [C.POINTER(C.c_int)] * 5
+        _hip = lib
+    return _hip

@@ -1,0 +1,73 @@
+"""Build the two in-tree shared libraries (no JIT cache: the .so files travel with the repo).
+
+    libssx_hip.so   HIP kernels + C ABI (include/ssx.h), hipcc --offload-arch=gfx950
+    libssx_host.so  host-side table / scene / image code (include/ssx_host.h), g++
+"""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+HIP_LIB = os.path.join(PKG, "libssx_hip.so")
+HOST_LIB = os.path.join(PKG, "libssx_host.so")
+
+HIP_SRC = [os.path.join(PKG, "csrc", f) for f in ("ssx_api.hip",)]
+HIP_DEPS = [os.path.join(PKG, "csrc", f) for f in ("ssx_api.hip", "ssx_kernels.hip", "ssx_blob.h")] + [
+    os.path.join(ROOT, "include", f) for f in ("ssx.h", "ssx_fmath.h")]
+HOST_SRC = [os.path.join(PKG, "host", f) for f in
+            ("spectrum.cpp", "color.cpp", "scene.cpp", "image_io.cpp", "renderer.cpp", "host_api.cpp")]
+HOST_DEPS = HOST_SRC + [os.path.join(PKG, "host", f) for f in
+                        ("spectrum.hpp", "color.hpp", "scene.hpp", "image_io.hpp", "renderer.hpp")] + [
+    os.path.join(ROOT, "include", f) for f in ("ssx.h", "ssx_host.h")]
+CLI_SRC = os.path.join(PKG, "host", "main.cpp")
+CLI_BIN = os.path.join(ROOT, "simple-spectral")
+
+# -ffp-contract=off is part of the numerics contract (bit parity with the oracle).
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build_hip(force=False, verbose=False):
+    if force or _stale(HIP_LIB, HIP_DEPS):
+        cmd = [hipcc()] + HIP_FLAGS + HIP_SRC + ["-o", HIP_LIB, "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HIP_LIB
+
+
+def build_host(force=False, verbose=False):
+    srcs = [s for s in HOST_SRC if os.path.exists(s)]
+    if force or _stale(HOST_LIB, HOST_DEPS):
+        cmd = ["g++"] + HOST_FLAGS + ["-shared"] + srcs + ["-o", HOST_LIB, "-lz", "-ldl", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    if os.path.exists(CLI_SRC) and (force or _stale(CLI_BIN, HOST_DEPS + [CLI_SRC])):
+        cmd = ["g++"] + HOST_FLAGS + [CLI_SRC, "-o", CLI_BIN, "-L" + PKG, "-lssx_host",
+                                      "-Wl,-rpath,$ORIGIN/simple_spectral_amd", "-ldl", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return HOST_LIB
+
+
+def build_all(force=False, verbose=False):
+    return build_hip(force, verbose), build_host(force, verbose)
+
+
+if __name__ == "__main__":
+    import sys
+    build_all(force="--force" in sys.argv, verbose=True)

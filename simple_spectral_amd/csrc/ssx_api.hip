@@ -1,0 +1,404 @@
+// ssx_api.hip -- C ABI (include/ssx.h) over the gfx950 megakernel.  One translation unit with the
+// kernels so the host launches them directly.  No CPU fallback of any kind lives here: every
+// entry point either drives the HIP kernels or returns an error.
+#include "ssx_kernels.hip"
+
+#include "../../include/ssx.h"
+
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HostError { int code; std::string msg; };
+
+std::string fmt(const char* f, ...) {
+	char buf[512];
+	va_list ap; va_start(ap, f); vsnprintf(buf, sizeof buf, f, ap); va_end(ap);
+	return buf;
+}
+
+} // namespace
+
+struct ssx_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;       // used by the asynchronous start/stop/wait path
+	uint32_t* d_blob = nullptr;
+	uint32_t blob_words = 0;
+	std::vector<uint8_t*> d_textures;
+	double* d_accum = nullptr;  size_t accum_pixels = 0;
+	float* d_out = nullptr;     size_t out_pixels = 0;
+	bool have_scene = false;
+
+	std::thread worker;
+	std::atomic<int> rendering{0};
+	std::atomic<int> stop_flag{0};
+	std::atomic<uint32_t> done_spp{0};
+	uint32_t total_spp = 0;
+	int worker_rc = 0;
+	ssx_render_params cur{};
+
+	std::string error;
+};
+
+namespace {
+
+#define SSX_HIP(ctx, call)                                                                          \
+	do {                                                                                            \
+		hipError_t e_ = (call);                                                                     \
+		if (e_ != hipSuccess) {                                                                     \
+			(ctx)->error = fmt("%s failed: %s", #call, hipGetErrorString(e_));                      \
+			return SSX_ERR_DEVICE;                                                                  \
+		}                                                                                           \
+	} while (0)
+
+int fail(ssx_ctx* ctx, int code, const std::string& msg) { ctx->error = msg; return code; }
+
+uint32_t align4(uint32_t words) { return (words + 3u) & ~3u; }
+
+// Packs ssx_scene_desc into the blob layout of ssx_blob.h.
+int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>& d_tex, std::vector<uint32_t>& blob) {
+	if (s->n_quads == 0 || s->n_quads > SSX_MAX_QUADS) return fail(ctx, SSX_ERR_SCENE, fmt("n_quads=%u outside 1..%u", s->n_quads, SSX_MAX_QUADS));
+	if (s->n_lights == 0) return fail(ctx, SSX_ERR_SCENE, "scene has no lights (reference asserts !lights.empty(), scene.cpp:30)");
+	if (s->n_textures > SSX_MAX_TEXTURES) return fail(ctx, SSX_ERR_SCENE, "too many textures");
+	const uint32_t spec_ids[6] = { s->spec_xbar, s->spec_ybar, s->spec_zbar, s->spec_basis_r, s->spec_basis_g, s->spec_basis_b };
+	for (uint32_t id : spec_ids) if (id >= s->n_spectra) return fail(ctx, SSX_ERR_ARG, "observer/basis spectrum index out of range");
+	for (uint32_t i = 0; i < s->n_spectra; ++i) {
+		const ssx_spectrum& sp = s->spectra[i];
+		if (sp.n < 2) return fail(ctx, SSX_ERR_DATA, "Must have at-least two elements in sampled spectrum!"); // spectrum.cpp:17-20
+		if ((uint64_t)sp.offset + sp.n > s->n_samples) return fail(ctx, SSX_ERR_ARG, "spectrum samples out of range");
+	}
+	for (uint32_t i = 0; i < s->n_materials; ++i) {
+		const ssx_material& m = s->materials[i];
+		if (m.kind > SSX_MTL_MIRROR || m.albedo_mode > SSX_ALBEDO_TEXTURE) return fail(ctx, SSX_ERR_ARG, "bad material kind/mode");
+		if (m.emission_spectrum >= s->n_spectra) return fail(ctx, SSX_ERR_ARG, "material emission spectrum out of range");
+		if (m.albedo_mode == SSX_ALBEDO_CONSTANT && m.albedo_spectrum >= s->n_spectra) return fail(ctx, SSX_ERR_ARG, "material albedo spectrum out of range");
+		if (m.albedo_mode == SSX_ALBEDO_TEXTURE && m.albedo_texture >= s->n_textures) return fail(ctx, SSX_ERR_ARG, "material texture out of range");
+	}
+	for (uint32_t i = 0; i < s->n_quads; ++i) if (s->quads[i].material >= s->n_materials) return fail(ctx, SSX_ERR_ARG, "quad material out of range");
+	for (uint32_t i = 0; i < s->n_lights; ++i) if (s->lights[i] >= s->n_quads) return fail(ctx, SSX_ERR_ARG, "light index out of range");
+
+	SsxBlobHeader h{};
+	memcpy(h.pv_inv, s->pv_inv, sizeof h.pv_inv);
+	memcpy(h.cam_pos, s->cam_pos, sizeof h.cam_pos);
+	h.lambda_min = s->lambda_min; h.lambda_step = s->lambda_step;
+	h.n_quads = s->n_quads; h.n_lights = s->n_lights; h.n_materials = s->n_materials; h.n_spectra = s->n_spectra;
+	h.spec_xbar = s->spec_xbar; h.spec_ybar = s->spec_ybar; h.spec_zbar = s->spec_zbar;
+	h.spec_basis_r = s->spec_basis_r; h.spec_basis_g = s->spec_basis_g; h.spec_basis_b = s->spec_basis_b;
+	h.n_textures = s->n_textures;
+
+	uint32_t off = (uint32_t)(sizeof(SsxBlobHeader) / 4);
+	h.off_perm = off;      off = align4(off + s->n_quads * SSX_PERM_WORDS_PER_QUAD);
+	h.off_quads = off;     off = align4(off + s->n_quads * (uint32_t)(sizeof(SsxBlobQuad) / 4));
+	h.off_lights = off;    off = align4(off + s->n_lights);
+	h.off_materials = off; off = align4(off + s->n_materials * (uint32_t)(sizeof(SsxBlobMaterial) / 4));
+	h.off_spectra = off;   off = align4(off + s->n_spectra * (uint32_t)(sizeof(SsxBlobSpectrum) / 4));
+	const uint32_t off_samples = off; off = align4(off + s->n_samples);
+	h.off_lut = off;       off = align4(off + 256u);
+	h.off_tex = off;       off = align4(off + s->n_textures * (uint32_t)(sizeof(SsxBlobTexture) / 4));
+	h.total_words = off;
+	if ((size_t)off * 4 > SSX_BLOB_MAX_BYTES) return fail(ctx, SSX_ERR_SCENE, fmt("scene tables need %u bytes of LDS (max %u)", off * 4, SSX_BLOB_MAX_BYTES));
+
+	blob.assign(off, 0u);
+	memcpy(blob.data(), &h, sizeof h);
+	float* perm = reinterpret_cast<float*>(blob.data() + h.off_perm);
+	SsxBlobQuad* bq = reinterpret_cast<SsxBlobQuad*>(blob.data() + h.off_quads);
+	for (uint32_t q = 0; q < s->n_quads; ++q) {
+		const ssx_quad& Q = s->quads[q];
+		const ssx_vertex* vs[4] = { &Q.v00, &Q.v10, &Q.v11, &Q.v01 };
+		for (uint32_t p = 0; p < 6; ++p) {
+			// (kx,ky,kz) of geometry.cpp:19-32: kz=0 -> (1,2,0); kz=1 -> (2,0,1); kz=2 -> (0,1,2); odd p swaps kx,ky
+			uint32_t kz = p >> 1, kx = (kz + 1) % 3, ky = (kz + 2) % 3;
+			if (p & 1u) { uint32_t t = kx; kx = ky; ky = t; }
+			float* dst = perm + q * SSX_PERM_WORDS_PER_QUAD + p * 12u;
+			for (int v = 0; v < 4; ++v) { dst[3 * v + 0] = vs[v]->pos[kx]; dst[3 * v + 1] = vs[v]->pos[ky]; dst[3 * v + 2] = vs[v]->pos[kz]; }
+		}
+		for (int v = 0; v < 4; ++v) {
+			memcpy(bq[q].pos[v], vs[v]->pos, 12);
+			memcpy(bq[q].st[v], vs[v]->st, 8);
+		}
+		memcpy(bq[q].normal[0], Q.normal0, 12);
+		memcpy(bq[q].normal[1], Q.normal1, 12);
+		bq[q].material = Q.material;
+		bq[q].is_light = Q.is_light;
+	}
+	memcpy(blob.data() + h.off_lights, s->lights, 4 * s->n_lights);
+	SsxBlobMaterial* bm = reinterpret_cast<SsxBlobMaterial*>(blob.data() + h.off_materials);
+	for (uint32_t i = 0; i < s->n_materials; ++i) {
+		const ssx_material& m = s->materials[i];
+		bm[i].kind = m.kind; bm[i].albedo_mode = m.albedo_mode; bm[i].albedo_spec = m.albedo_spectrum;
+		bm[i].albedo_tex = m.albedo_texture; bm[i].emission_spec = m.emission_spectrum;
+	}
+	SsxBlobSpectrum* bs = reinterpret_cast<SsxBlobSpectrum*>(blob.data() + h.off_spectra);
+	for (uint32_t i = 0; i < s->n_spectra; ++i) {
+		bs[i].offset = off_samples + s->spectra[i].offset;
+		bs[i].n = s->spectra[i].n;
+		bs[i].low = s->spectra[i].low;
+		bs[i].delta_recip = s->spectra[i].delta_recip;
+	}
+	memcpy(blob.data() + off_samples, s->samples, 4 * (size_t)s->n_samples);
+	memcpy(blob.data() + h.off_lut, s->srgb_to_linear, 4 * 256);
+	SsxBlobTexture* bt = reinterpret_cast<SsxBlobTexture*>(blob.data() + h.off_tex);
+	for (uint32_t i = 0; i < s->n_textures; ++i) {
+		uint64_t p = (uint64_t)(uintptr_t)d_tex[i];
+		bt[i].ptr_lo = (uint32_t)p; bt[i].ptr_hi = (uint32_t)(p >> 32);
+		bt[i].w = s->textures[i].width; bt[i].h = s->textures[i].height;
+	}
+	return SSX_OK;
+}
+
+int check_params(ssx_ctx* ctx, const ssx_render_params* p) {
+	if (!p || p->struct_size != sizeof(ssx_render_params)) return fail(ctx, SSX_ERR_ARG, "ssx_render_params.struct_size mismatch");
+	if (!ctx->have_scene) return fail(ctx, SSX_ERR_STATE, "no scene uploaded");
+	if (p->width == 0 || p->height == 0 || p->spp == 0) return fail(ctx, SSX_ERR_ARG, "width, height and spp must be positive");
+	if ((uint64_t)p->width * p->height > (1ull << 28)) return fail(ctx, SSX_ERR_ARG, "image too large");
+	if (p->tile_stride == 0 || p->tile_first >= p->tile_stride) return fail(ctx, SSX_ERR_ARG, "need tile_first < tile_stride");
+	return SSX_OK;
+}
+
+int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
+	if (ctx->accum_pixels < pixels) {
+		if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+		ctx->d_accum = nullptr; ctx->accum_pixels = 0;
+		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_accum, pixels * 4 * sizeof(double)));
+		ctx->accum_pixels = pixels;
+	}
+	if (need_out && ctx->out_pixels < pixels) {
+		if (ctx->d_out) (void)hipFree(ctx->d_out);
+		ctx->d_out = nullptr; ctx->out_pixels = 0;
+		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_out, pixels * 4 * sizeof(float)));
+		ctx->out_pixels = pixels;
+	}
+	return SSX_OK;
+}
+
+struct LaunchPlan { SsxKernelArgs args; uint32_t blocks; size_t lds_bytes; };
+
+LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
+	LaunchPlan pl{};
+	SsxKernelArgs& a = pl.args;
+	a.blob = ctx->d_blob; a.blob_words = ctx->blob_words;
+	a.width = p->width; a.height = p->height;
+	a.tiles_x = (p->width + 7u) / 8u;
+	a.n_tiles = a.tiles_x * ((p->height + 7u) / 8u);
+	a.tile_first = p->tile_first; a.tile_stride = p->tile_stride;
+	a.indirect_only = p->indirect_only ? 1u : 0u;
+	a.seed = p->seed;
+	a.accum = ctx->d_accum;
+	uint32_t my_tiles = a.n_tiles > p->tile_first ? (a.n_tiles - p->tile_first + p->tile_stride - 1u) / p->tile_stride : 0u;
+	pl.blocks = (my_tiles + 3u) / 4u;
+	pl.lds_bytes = (size_t)ctx->blob_words * 4;
+	return pl;
+}
+
+int launch_range(ssx_ctx* ctx, LaunchPlan& pl, uint32_t k0, uint32_t k1, hipStream_t stream) {
+	if (pl.blocks == 0) return SSX_OK;
+	pl.args.k0 = k0; pl.args.k1 = k1;
+	hipLaunchKernelGGL(ssx_render_kernel, dim3(pl.blocks), dim3(256), pl.lds_bytes, stream, pl.args);
+	SSX_HIP(ctx, hipGetLastError());
+	return SSX_OK;
+}
+
+int launch_finalize(ssx_ctx* ctx, const ssx_render_params* p, float* d_out, hipStream_t stream) {
+	uint32_t pixels = p->width * p->height;
+	hipLaunchKernelGGL(ssx_finalize_kernel, dim3((pixels + 255u) / 256u), dim3(256), 0, stream,
+	                   (const double*)ctx->d_accum, (float4*)d_out, p->width, p->height, (p->width + 7u) / 8u,
+	                   p->tile_first, p->tile_stride, p->spp);
+	SSX_HIP(ctx, hipGetLastError());
+	return SSX_OK;
+}
+
+void worker_main(ssx_ctx* ctx) {
+	const ssx_render_params p = ctx->cur;
+	int rc = SSX_OK;
+	auto run = [&]() -> int {
+		SSX_HIP(ctx, hipSetDevice(ctx->device));
+		size_t pixels = (size_t)p.width * p.height;
+		SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, pixels * 4 * sizeof(double), ctx->stream));
+		LaunchPlan pl = make_plan(ctx, &p);
+		uint32_t chunk = p.spp_per_launch ? p.spp_per_launch : (p.spp + 31u) / 32u;
+		if (chunk == 0) chunk = 1;
+		for (uint32_t k0 = 0; k0 < p.spp && !ctx->stop_flag.load(); k0 += chunk) {
+			uint32_t k1 = (p.spp - k0 < chunk) ? p.spp : k0 + chunk;
+			int r = launch_range(ctx, pl, k0, k1, ctx->stream);
+			if (r) return r;
+			SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			ctx->done_spp.store(k1);
+		}
+		// like the reference's last worker (renderer.cpp:388-394) the image is produced even after
+		// a stop; pixels hold the mean over Options::spp of the samples accumulated so far.
+		int r = launch_finalize(ctx, &p, ctx->d_out, ctx->stream);
+		if (r) return r;
+		SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		return SSX_OK;
+	};
+	rc = run();
+	ctx->worker_rc = rc;
+	ctx->rendering.store(0);
+}
+
+} // namespace
+
+extern "C" {
+
+int ssx_abi_version(void) { return SSX_ABI_VERSION; }
+
+const char* ssx_last_error(const ssx_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int ssx_create(int device, ssx_ctx** out) {
+	if (!out) { g_create_error = "out is NULL"; return SSX_ERR_ARG; }
+	*out = nullptr;
+	int n = 0;
+	hipError_t e = hipGetDeviceCount(&n);
+	if (e != hipSuccess || n == 0) {
+		g_create_error = fmt("no HIP device available (%s); this library has no CPU path", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+		return SSX_ERR_DEVICE;
+	}
+	if (device < 0 || device >= n) { g_create_error = fmt("device %d out of range (0..%d)", device, n - 1); return SSX_ERR_ARG; }
+	hipDeviceProp_t prop;
+	if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) { g_create_error = hipGetErrorString(e); return SSX_ERR_DEVICE; }
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+		g_create_error = fmt("device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+		return SSX_ERR_DEVICE;
+	}
+	ssx_ctx* ctx = new ssx_ctx;
+	ctx->device = device;
+	if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+		g_create_error = hipGetErrorString(e);
+		delete ctx;
+		return SSX_ERR_DEVICE;
+	}
+	*out = ctx;
+	return SSX_OK;
+}
+
+void ssx_destroy(ssx_ctx* ctx) {
+	if (!ctx) return;
+	if (ctx->worker.joinable()) { ctx->stop_flag.store(1); ctx->worker.join(); }
+	(void)hipSetDevice(ctx->device);
+	if (ctx->d_blob) (void)hipFree(ctx->d_blob);
+	for (uint8_t* t : ctx->d_textures) (void)hipFree(t);
+	if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+	if (ctx->d_out) (void)hipFree(ctx->d_out);
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
+	if (!ctx) return SSX_ERR_ARG;
+	if (!s || s->struct_size != sizeof(ssx_scene_desc)) return fail(ctx, SSX_ERR_ARG, "ssx_scene_desc.struct_size mismatch");
+	if (ctx->rendering.load()) return fail(ctx, SSX_ERR_STATE, "render in progress");
+	SSX_HIP(ctx, hipSetDevice(ctx->device));
+	SSX_HIP(ctx, hipDeviceSynchronize());
+	for (uint8_t* t : ctx->d_textures) (void)hipFree(t);
+	ctx->d_textures.clear();
+	ctx->have_scene = false;
+	for (uint32_t i = 0; i < s->n_textures && i < SSX_MAX_TEXTURES; ++i) {
+		const ssx_texture& t = s->textures[i];
+		if (!t.rgb || t.width == 0 || t.height == 0) return fail(ctx, SSX_ERR_DATA, "Could not load texture"); // material.cpp:15-18
+		uint8_t* d = nullptr;
+		size_t bytes = (size_t)3 * t.width * t.height;
+		SSX_HIP(ctx, hipMalloc((void**)&d, bytes));
+		ctx->d_textures.push_back(d);
+		SSX_HIP(ctx, hipMemcpy(d, t.rgb, bytes, hipMemcpyHostToDevice));
+	}
+	std::vector<uint32_t> blob;
+	int rc = pack_blob(ctx, s, ctx->d_textures, blob);
+	if (rc) return rc;
+	if (ctx->d_blob) { (void)hipFree(ctx->d_blob); ctx->d_blob = nullptr; }
+	SSX_HIP(ctx, hipMalloc((void**)&ctx->d_blob, blob.size() * 4));
+	SSX_HIP(ctx, hipMemcpy(ctx->d_blob, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+	ctx->blob_words = (uint32_t)blob.size();
+	ctx->have_scene = true;
+	return SSX_OK;
+}
+
+int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out, void* hip_stream) {
+	if (!ctx) return SSX_ERR_ARG;
+	int rc = check_params(ctx, p);
+	if (rc) return rc;
+	if (!d_xyza_out) return fail(ctx, SSX_ERR_ARG, "d_xyza_out is NULL");
+	if (ctx->rendering.load()) return fail(ctx, SSX_ERR_STATE, "asynchronous render in progress");
+	hipStream_t stream = (hipStream_t)hip_stream;
+	SSX_HIP(ctx, hipSetDevice(ctx->device));
+	size_t pixels = (size_t)p->width * p->height;
+	if ((rc = ensure_buffers(ctx, pixels, false))) return rc;
+	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, pixels * 4 * sizeof(double), stream));
+	LaunchPlan pl = make_plan(ctx, p);
+	uint32_t chunk = p->spp_per_launch ? p->spp_per_launch : p->spp;
+	for (uint32_t k0 = 0; k0 < p->spp; k0 += chunk) {
+		uint32_t k1 = (p->spp - k0 < chunk) ? p->spp : k0 + chunk;
+		if ((rc = launch_range(ctx, pl, k0, k1, stream))) return rc;
+	}
+	return launch_finalize(ctx, p, (float*)d_xyza_out, stream);
+}
+
+int ssx_render_start(ssx_ctx* ctx, const ssx_render_params* p) {
+	if (!ctx) return SSX_ERR_ARG;
+	int rc = check_params(ctx, p);
+	if (rc) return rc;
+	if (ctx->rendering.load()) return fail(ctx, SSX_ERR_STATE, "render already in progress");
+	if (ctx->worker.joinable()) ctx->worker.join();
+	SSX_HIP(ctx, hipSetDevice(ctx->device));
+	if ((rc = ensure_buffers(ctx, (size_t)p->width * p->height, true))) return rc;
+	ctx->cur = *p;
+	ctx->total_spp = p->spp;
+	ctx->done_spp.store(0);
+	ctx->stop_flag.store(0);
+	ctx->worker_rc = 0;
+	ctx->rendering.store(1);
+	ctx->worker = std::thread(worker_main, ctx);
+	return SSX_OK;
+}
+
+int ssx_render_stop(ssx_ctx* ctx) {
+	if (!ctx) return SSX_ERR_ARG;
+	ctx->stop_flag.store(1);
+	return SSX_OK;
+}
+
+int ssx_is_rendering(ssx_ctx* ctx) { return ctx ? ctx->rendering.load() : 0; }
+
+float ssx_progress(ssx_ctx* ctx) {
+	if (!ctx || ctx->total_spp == 0) return 0.0f;
+	return (float)ctx->done_spp.load() / (float)ctx->total_spp;
+}
+
+int ssx_render_wait(ssx_ctx* ctx, float* xyza_out) {
+	if (!ctx) return SSX_ERR_ARG;
+	if (!ctx->worker.joinable()) return fail(ctx, SSX_ERR_STATE, "no render was started");
+	ctx->worker.join();
+	if (ctx->worker_rc) return ctx->worker_rc;
+	if (xyza_out) {
+		SSX_HIP(ctx, hipSetDevice(ctx->device));
+		SSX_HIP(ctx, hipMemcpy(xyza_out, ctx->d_out, (size_t)ctx->cur.width * ctx->cur.height * 4 * sizeof(float), hipMemcpyDeviceToHost));
+	}
+	return SSX_OK;
+}
+
+int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* scratch_bytes, int* max_blocks_per_cu) {
+	if (!ctx) return SSX_ERR_ARG;
+	SSX_HIP(ctx, hipSetDevice(ctx->device));
+	hipFuncAttributes at;
+	SSX_HIP(ctx, hipFuncGetAttributes(&at, (const void*)ssx_render_kernel));
+	if (vgprs) *vgprs = at.numRegs;
+	if (sgprs) *sgprs = 0;
+	if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes + (int)ctx->blob_words * 4;
+	if (scratch_bytes) *scratch_bytes = (int)at.localSizeBytes;
+	if (max_blocks_per_cu) {
+		int nb = 0;
+		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)ssx_render_kernel, 256, (size_t)ctx->blob_words * 4));
+		*max_blocks_per_cu = nb;
+	}
+	return SSX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,64 @@
+// ssx_blob.h -- layout of the scene blob the host packs (ssx_api.cpp) and every workgroup
+// stages into LDS (ssx_kernels.hip).  All offsets are in 4-byte words from the blob start.
+//
+// Sizes (reference scenes): cornell-srgb / CIE 1931 ~ 12 KB, CIE 2006 tables ~ 19 KB; the blob
+// must stay <= SSX_BLOB_MAX_BYTES so several 256-lane workgroups fit in a CU's 160 KB LDS.
+#pragma once
+#include <stdint.h>
+
+#define SSX_BLOB_MAX_BYTES (48u * 1024u)
+
+// Permuted vertex table: for quad q and axis permutation p (0..5) the 12 floats
+//   v00[kx] v00[ky] v00[kz]  v10[kx] v10[ky] v10[kz]  v11[kx] ...  v01[kz]
+// so a lane reads its ray's shear-space ordering with three 16-byte LDS loads instead of
+// selecting components per vertex.  p = 2*kz_case + swapped, with (kx,ky,kz) as chosen by the
+// reference's axis rule (src/geometry.cpp:17-32).  The six 48-byte copies of one quad sit in
+// distinct 16-byte bank slots, so lanes with different p do not conflict.
+#define SSX_PERM_WORDS_PER_QUAD (6u * 12u)
+
+struct SsxBlobQuad {   // 36 words (144 B): stride 36 mod 32 = 4 banks, 16-byte aligned
+	float pos[4][3];   // v00, v10, v11, v01 (light sampling needs the unpermuted positions)
+	float st[4][2];
+	float normal[2][3]; // tri0, tri1
+	uint32_t material;
+	uint32_t is_light;
+	uint32_t pad[8];
+};
+static_assert(sizeof(SsxBlobQuad) == 144, "layout");
+
+struct SsxBlobMaterial { // 8 words
+	uint32_t kind, albedo_mode, albedo_spec, albedo_tex, emission_spec, is_emissive, pad0, pad1;
+};
+struct SsxBlobSpectrum { // 4 words
+	uint32_t offset; // word offset of the first sample from the blob start
+	uint32_t n;
+	float low, delta_recip;
+};
+
+struct SsxBlobHeader {
+	double pv_inv[16];
+	float cam_pos[3];
+	float lambda_min, lambda_step;
+	uint32_t n_quads, n_lights, n_materials, n_spectra;
+	uint32_t spec_xbar, spec_ybar, spec_zbar, spec_basis_r, spec_basis_g, spec_basis_b;
+	uint32_t off_perm, off_quads, off_lights, off_materials, off_spectra, off_lut, off_tex;
+	uint32_t n_textures;
+	uint32_t total_words;
+};
+static_assert(sizeof(SsxBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
+
+struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top to bottom) + size
+	uint32_t ptr_lo, ptr_hi, w, h;
+};
+
+struct SsxKernelArgs {
+	const uint32_t* blob;   // device copy of the scene blob
+	uint32_t blob_words;
+	uint32_t width, height;
+	uint32_t tiles_x, n_tiles;
+	uint32_t tile_first, tile_stride;
+	uint32_t k0, k1;        // sample range of this launch
+	uint32_t indirect_only;
+	uint64_t seed;
+	double* accum;          // double4 per pixel (sum of float(sample*0.001f))
+};

@@ -1,0 +1,622 @@
+// ssx_kernels.hip -- the per-pixel spectral integrator as a gfx950 megakernel.
+//
+// Path covered (reference file:line, paths relative to the reference's src/):
+//   renderer.cpp:309-395  tile loop            -> one wave64 per 8x8 tile, one lane per pixel
+//   renderer.cpp:278-299  _render_pixel        -> per-lane f64 XYZA accumulation over samples
+//   renderer.cpp:104-277  _render_sample / L   -> iterative path loop + post-order fold (R5)
+//   scene.cpp:433-445, geometry.cpp:12-139     -> trace(): quad-batched watertight test
+//   scene.cpp:417-431, geometry.cpp:103-145, util/spherical-tri.cpp, util/random.cpp:101-154
+//                                              -> sample_light()
+//   material.cpp:45-143, util/color.cpp:167-173, spectrum.cpp:39-67 -> albedo / spectrum lookups
+//   util/color.hpp:115-139                     -> flux_to_xyz()
+//
+// Numerics contract: every float expression is evaluated in the reference's order with IEEE
+// +,-,*,/,sqrt (no contraction: build with -ffp-contract=off), so results are bit-identical to
+// the CPU restatement in oracle/ (which follows the reference expression by expression).  The
+// three transcendentals come from include/ssx_fmath.h.  Where work is re-associated for the GPU
+// (shear constants hoisted out of the triangle loop, vertices shared by a quad's two triangles,
+// candidate triangles finished in a second pass) each individual operation still sees the same
+// operands, so every intermediate is the same float.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ssx_fmath.h"
+#include "ssx_blob.h"
+
+#define SSX_EPS 0.001f          // stdafx.hpp:58
+#define SSX_MAX_DEPTH_ 10u       // stdafx.hpp:47
+#define SSX_PI_F 3.14159265358979323846f
+
+namespace {
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 scl(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+// GLM order: dot = t.x+t.y+t.z, cross, normalize = v*(1/sqrt(dot))
+__device__ __forceinline__ float dot3(V3 a, V3 b) { float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z; return tx + ty + tz; }
+__device__ __forceinline__ float inversesqrt_(float x) { return 1.0f / __builtin_sqrtf(x); }
+__device__ __forceinline__ V3 normalize3(V3 v) { float s = inversesqrt_(dot3(v, v)); return mk(v.x * s, v.y * s, v.z * s); }
+__device__ __forceinline__ float fmax_glm(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ float fmin_glm(float a, float b) { return (b < a) ? b : a; }
+__device__ __forceinline__ float clamp_glm(float x, float lo, float hi) { return fmin_glm(fmax_glm(x, lo), hi); }
+
+// ------------------------------------------------------------------ RNG (util/random.hpp) ----
+struct Rng { uint64_t state, inc; };
+__device__ __forceinline__ uint32_t rng_next(Rng& r) { // random.hpp:52-58
+	uint32_t xorshifted = (uint32_t)(((r.state >> 18u) ^ r.state) >> 27u);
+	uint32_t rot = (uint32_t)(r.state >> 59u);
+	uint32_t result = (xorshifted >> rot) | (xorshifted << ((0u - rot) & 31u));
+	r.state = r.state * 6364136223846793005ull + r.inc;
+	return result;
+}
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+	z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+	z ^= z >> 27; z *= 0x94D049BB133111EBull;
+	z ^= z >> 31;
+	return z;
+}
+// libstdc++-11 generate_canonical<float,24> (random.hpp:68-70)
+__device__ __forceinline__ float rand_1f(Rng& r) {
+	float ret = (float)rng_next(r) / 4294967296.0f;
+	return (ret >= 1.0f) ? 0x1.fffffep-1f : ret;
+}
+// generate_canonical<double,53>: first draw is the low word (random.hpp:71-73)
+__device__ __forceinline__ double rand_1d(Rng& r) {
+	double sum = (double)rng_next(r);
+	sum += (double)rng_next(r) * 4294967296.0;
+	double ret = sum / 18446744073709551616.0;
+	return (ret >= 1.0) ? 0x1.fffffffffffffp-1 : ret;
+}
+// uniform_int_distribution<size_t>(0,n-1), Lemire, 32-bit URBG (random.hpp:75-78)
+__device__ __forceinline__ uint32_t rand_choice(Rng& r, uint32_t range) {
+	uint64_t product = (uint64_t)rng_next(r) * (uint64_t)range;
+	uint32_t low = (uint32_t)product;
+	if (low < range) {
+		uint32_t threshold = (0u - range) % range;
+		while (low < threshold) {
+			product = (uint64_t)rng_next(r) * (uint64_t)range;
+			low = (uint32_t)product;
+		}
+	}
+	return (uint32_t)(product >> 32);
+}
+
+// ------------------------------------------------------------------ scene in LDS ----
+struct Lds {
+	const uint32_t* w; // blob words
+	__device__ __forceinline__ const SsxBlobHeader& hdr() const { return *reinterpret_cast<const SsxBlobHeader*>(w); }
+	__device__ __forceinline__ const float* perm(uint32_t q, uint32_t p) const {
+		return reinterpret_cast<const float*>(w + hdr().off_perm) + q * SSX_PERM_WORDS_PER_QUAD + p * 12u;
+	}
+	__device__ __forceinline__ const SsxBlobQuad& quad(uint32_t q) const {
+		return reinterpret_cast<const SsxBlobQuad*>(w + hdr().off_quads)[q];
+	}
+	__device__ __forceinline__ const SsxBlobMaterial& material(uint32_t m) const {
+		return reinterpret_cast<const SsxBlobMaterial*>(w + hdr().off_materials)[m];
+	}
+	__device__ __forceinline__ SsxBlobSpectrum spectrum(uint32_t s) const {
+		return reinterpret_cast<const SsxBlobSpectrum*>(w + hdr().off_spectra)[s];
+	}
+	__device__ __forceinline__ uint32_t light(uint32_t i) const { return w[hdr().off_lights + i]; }
+	__device__ __forceinline__ float lut(uint32_t u8) const { return reinterpret_cast<const float*>(w + hdr().off_lut)[u8]; }
+	__device__ __forceinline__ SsxBlobTexture texture(uint32_t t) const {
+		return reinterpret_cast<const SsxBlobTexture*>(w + hdr().off_tex)[t];
+	}
+};
+
+struct Hero { float v[4]; };
+
+// spectrum.cpp:39-67: linear reconstruction, zero outside the table; lambda_i = l0 + float(i)*STEP
+__device__ __forceinline__ Hero spectrum_hero(const Lds& L, uint32_t spec_id, float lambda_0, float step) {
+	SsxBlobSpectrum sp = L.spectrum(spec_id);
+	const float* data = reinterpret_cast<const float*>(L.w + sp.offset);
+	Hero out;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		float lambda = lambda_0 + (float)i * step;
+		float x = (lambda - sp.low) * sp.delta_recip;
+		float i0f = __builtin_floorf(x);
+		float frac = x - i0f;
+		int i0 = (int)i0f;
+		int i1 = i0 + 1;
+		float val0 = (i0 >= 0 && (uint32_t)i0 < sp.n) ? data[i0] : 0.0f;
+		float val1 = (i1 >= 0 && (uint32_t)i1 < sp.n) ? data[i1] : 0.0f;
+		out.v[i] = val0 * (1.0f - frac) + val1 * frac; // math-helpers.hpp:10-12
+	}
+	return out;
+}
+
+// material.cpp:45-97 + util/color.cpp:167-173 ("ours" basis uplift)
+__device__ __forceinline__ Hero texture_sample(const Lds& L, uint32_t tex_index, float st_x, float st_y, float lambda_0) {
+	const SsxBlobTexture t = L.texture(tex_index);
+	const uint8_t* rgb = reinterpret_cast<const uint8_t*>(((uint64_t)t.ptr_hi << 32) | (uint64_t)t.ptr_lo);
+	float uvx = st_x * (float)t.w, uvy = st_y * (float)t.h;
+	float index_x = uvx, index_y = (float)t.h - uvy;
+	int i = (int)__builtin_floorf(index_x), j = (int)__builtin_floorf(index_y);
+	int hi_i = (int)t.w - 1, hi_j = (int)t.h - 1;
+	i = (i < 0) ? 0 : i; i = (hi_i < i) ? hi_i : i;
+	j = (j < 0) ? 0 : j; j = (hi_j < j) ? hi_j : j;
+	const uint8_t* px = rgb + 3u * ((size_t)j * (size_t)t.w + (size_t)i);
+	float r = L.lut(px[0]), g = L.lut(px[1]), b = L.lut(px[2]);
+	const SsxBlobHeader& h = L.hdr();
+	Hero br = spectrum_hero(L, h.spec_basis_r, lambda_0, h.lambda_step);
+	Hero bg = spectrum_hero(L, h.spec_basis_g, lambda_0, h.lambda_step);
+	Hero bb = spectrum_hero(L, h.spec_basis_b, lambda_0, h.lambda_step);
+	Hero out;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) out.v[k] = (r * br.v[k] + g * bg.v[k]) + b * bb.v[k];
+	return out;
+}
+
+__device__ __forceinline__ Hero material_albedo(const Lds& L, const SsxBlobMaterial& m, float st_x, float st_y, float lambda_0) {
+	if (m.albedo_mode == 0u) return spectrum_hero(L, m.albedo_spec, lambda_0, L.hdr().lambda_step);
+	return texture_sample(L, m.albedo_tex, st_x, st_y, lambda_0);
+}
+
+// util/color.hpp:115-139
+__device__ __forceinline__ void flux_to_xyz(const Lds& L, const Hero& flux, float lambda_0, float out[3]) {
+	const SsxBlobHeader& h = L.hdr();
+	const uint32_t ids[3] = { h.spec_xbar, h.spec_ybar, h.spec_zbar };
+#pragma unroll
+	for (int ch = 0; ch < 3; ++ch) {
+		Hero bar = spectrum_hero(L, ids[ch], lambda_0, h.lambda_step);
+		float acc = 0.0f;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) acc += (bar.v[i] * flux.v[i]) * h.lambda_step;
+		out[ch] = acc;
+	}
+}
+
+// ------------------------------------------------------------------ intersection ----
+struct RaySetup { // per-ray constants of the watertight test (geometry.cpp:17-37), hoisted
+	float okx, oky, okz; // ray origin in (kx,ky,kz) order
+	float Sx, Sy, Sz;
+	uint32_t perm;       // 2*kz + swapped
+};
+__device__ __forceinline__ float comp(V3 v, uint32_t k) { return k == 0u ? v.x : (k == 1u ? v.y : v.z); }
+
+__device__ __forceinline__ RaySetup ray_setup(V3 orig, V3 dir) {
+	float ax = __builtin_fabsf(dir.x), ay = __builtin_fabsf(dir.y), az = __builtin_fabsf(dir.z);
+	uint32_t kx, ky, kz;
+	if (ax > ay) {
+		if (ax > az) { kz = 0; kx = 1; ky = 2; } else { kz = 2; kx = 0; ky = 1; }
+	} else {
+		if (ay > az) { kz = 1; kx = 2; ky = 0; } else { kz = 2; kx = 0; ky = 1; }
+	}
+	uint32_t swapped = comp(dir, kz) < 0 ? 1u : 0u;
+	if (swapped) { uint32_t t = kx; kx = ky; ky = t; }
+	RaySetup rs;
+	float dkz = comp(dir, kz);
+	rs.Sx = comp(dir, kx) / dkz;
+	rs.Sy = comp(dir, ky) / dkz;
+	rs.Sz = 1.0f / dkz;
+	rs.okx = comp(orig, kx); rs.oky = comp(orig, ky); rs.okz = comp(orig, kz);
+	rs.perm = 2u * kz + swapped;
+	return rs;
+}
+
+struct HitInfo {
+	int tri;          // 2*quad + which, -1 = none
+	float dist;
+	float U, V, W, det_recip; // of the accepted triangle (for st interpolation)
+};
+
+// One vertex in shear space: x' = (v-o)[kx] - Sx*(v-o)[kz], y' likewise, z raw = (v-o)[kz]
+struct SV { float x, y, z; };
+__device__ __forceinline__ SV shear_vertex(const float* pv, const RaySetup& rs) {
+	float rx = pv[0] - rs.okx, ry = pv[1] - rs.oky, rz = pv[2] - rs.okz;
+	SV s;
+	s.x = rx - rs.Sx * rz;
+	s.y = ry - rs.Sy * rz;
+	s.z = rz;
+	return s;
+}
+
+// scene.cpp:433-445 + geometry.cpp:128-139 + geometry.cpp:12-101.
+// Pass 1 (all quads, uniform loop): edge functions U,V,W of both triangles from the four shared
+// sheared vertices; a triangle whose nonzero edge values have mixed signs can never be accepted
+// (geometry.cpp:55-67: float and double signs agree whenever the float is nonzero), everything
+// else sets a candidate bit.  Pass 2 (per lane, ascending triangle order = the reference's
+// visiting order): finish candidates exactly -- f64 edge fallback, det, T, sign test, 1/det,
+// dist, closest-so-far with strict '<' -- and skip tri1 when tri0 of the same quad was accepted
+// (the `goto HIT` of PrimQuad::intersect).
+__device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_quad, HitInfo& hit) {
+	const RaySetup rs = ray_setup(orig, dir);
+	const uint32_t nq = L.hdr().n_quads;
+	uint64_t cand = 0;
+	for (uint32_t q = 0; q < nq; ++q) {
+		const float* pv = L.perm(q, rs.perm);
+		SV a = shear_vertex(pv + 0, rs), b = shear_vertex(pv + 3, rs), c = shear_vertex(pv + 6, rs), d = shear_vertex(pv + 9, rs);
+		// tri0 = (A=a,B=b,C=c): UVW = cross(ABCy, ABCx)
+		float U0 = b.y * c.x - b.x * c.y;
+		float V0 = c.y * a.x - c.x * a.y;
+		float W0 = a.y * b.x - a.x * b.y;
+		// tri1 = (A=a,B=c,C=d)
+		float U1 = c.y * d.x - c.x * d.y;
+		float V1 = d.y * a.x - d.x * a.y;
+		float W1 = a.y * c.x - a.x * c.y;
+		float mn0 = __builtin_fminf(__builtin_fminf(U0, V0), W0), mx0 = __builtin_fmaxf(__builtin_fmaxf(U0, V0), W0);
+		float mn1 = __builtin_fminf(__builtin_fminf(U1, V1), W1), mx1 = __builtin_fmaxf(__builtin_fmaxf(U1, V1), W1);
+		uint32_t bits = ((mn0 < 0.0f && mx0 > 0.0f) ? 0u : 1u) | ((mn1 < 0.0f && mx1 > 0.0f) ? 0u : 2u);
+		cand |= (uint64_t)bits << (2u * q);
+	}
+	if (ignore_quad >= 0) cand &= ~(3ull << (2u * (uint32_t)ignore_quad));
+
+	hit.tri = -1;
+	hit.dist = __builtin_inff();
+	hit.U = hit.V = hit.W = hit.det_recip = 0.0f;
+	while (cand) {
+		uint32_t bit = (uint32_t)__builtin_ctzll(cand);
+		cand &= cand - 1ull;
+		uint32_t q = bit >> 1, which = bit & 1u;
+		const float* pv = L.perm(q, rs.perm);
+		SV A = shear_vertex(pv + 0, rs);
+		SV B = shear_vertex(pv + (which ? 6 : 3), rs);
+		SV C = shear_vertex(pv + (which ? 9 : 6), rs);
+		float U = B.y * C.x - B.x * C.y;
+		float V = C.y * A.x - C.x * A.y;
+		float W = A.y * B.x - A.x * B.y;
+		if (!(U != 0.0f && V != 0.0f && W != 0.0f)) {
+			double Ud = (double)B.y * (double)C.x - (double)B.x * (double)C.y;
+			double Vd = (double)C.y * (double)A.x - (double)C.x * (double)A.y;
+			double Wd = (double)A.y * (double)B.x - (double)A.x * (double)B.y;
+			if ((Ud < 0.0 || Vd < 0.0 || Wd < 0.0) && (Ud > 0.0 || Vd > 0.0 || Wd > 0.0)) continue;
+			U = (float)Ud; V = (float)Vd; W = (float)Wd;
+		}
+		float det = U + V + W;
+		if (!(__builtin_fabsf(det) > SSX_EPS)) continue;
+		float Az = rs.Sz * A.z, Bz = rs.Sz * B.z, Cz = rs.Sz * C.z;
+		float T = U * Az + V * Bz + W * Cz;
+		if ((__float_as_uint(det) ^ __float_as_uint(T)) & 0x80000000u) continue;
+		float det_recip = 1.0f / det;
+		float dist = T * det_recip;
+		if (dist >= SSX_EPS && dist < hit.dist) {
+			hit.tri = (int)bit; hit.dist = dist;
+			hit.U = U; hit.V = V; hit.W = W; hit.det_recip = det_recip;
+			if (which == 0u) cand &= ~(1ull << (bit + 1u)); // PrimQuad::intersect: tri0 hit -> tri1 not tested
+		}
+	}
+}
+
+// ------------------------------------------------------------------ light sampling ----
+struct SphTri {
+	V3 A, B, C;
+	float b, cos_c;
+	float alpha, cos_alpha;
+	float area;
+};
+
+// util/spherical-tri.cpp:18-124 (only the members rand_toward_sphericaltri and the pdf read)
+__device__ __forceinline__ void sphtri_make(V3 A, V3 B, V3 C, SphTri& t) {
+	const float under_pi = __uint_as_float(0x40490FDAu);
+	const float nanv = __uint_as_float(0x7FC00000u);
+	t.A = A; t.B = B; t.C = C;
+	float cos_a = clamp_glm(dot3(B, C), -1.0f, 1.0f);
+	float cos_b = clamp_glm(dot3(A, C), -1.0f, 1.0f);
+	float cos_c = clamp_glm(dot3(A, B), -1.0f, 1.0f);
+	float a = clamp_glm(ssx_acosf(cos_a), 0.0f, under_pi);
+	float b = clamp_glm(ssx_acosf(cos_b), 0.0f, under_pi);
+	float c = clamp_glm(ssx_acosf(cos_c), 0.0f, under_pi);
+	float sin_a = ssx_sinf(a), sin_b = ssx_sinf(b), sin_c = ssx_sinf(c);
+	float numer0 = cos_a - cos_b * cos_c;
+	float numer1 = cos_b - cos_c * cos_a;
+	float numer2 = cos_c - cos_a * cos_b;
+	float denom0 = sin_b * sin_c;
+	float denom1 = sin_c * sin_a;
+	float denom2 = sin_a * sin_b;
+	t.b = b; t.cos_c = cos_c;
+	if (denom0 > 0 && denom1 > 0 && denom2 > 0) {
+		float cos_alpha = clamp_glm(numer0 / denom0, -1.0f, 1.0f);
+		float cos_beta  = clamp_glm(numer1 / denom1, -1.0f, 1.0f);
+		float cos_gamma = clamp_glm(numer2 / denom2, -1.0f, 1.0f);
+		float alpha = clamp_glm(ssx_acosf(cos_alpha), 0.0f, under_pi);
+		float beta  = clamp_glm(ssx_acosf(cos_beta ), 0.0f, under_pi);
+		float gamma = clamp_glm(ssx_acosf(cos_gamma), 0.0f, under_pi);
+		float area = alpha + beta + gamma - SSX_PI_F;
+		if (area >= 0); else area = 0;
+		t.alpha = alpha; t.cos_alpha = cos_alpha; t.area = area;
+		return;
+	}
+	t.area = 0;
+	// degenerate ladder (:76-123): alpha/cos_alpha are the only vertex-angle members read later
+	if (sin_a > 0) {
+		if (sin_b > 0) {
+			if (sin_c > 0) { t.alpha = nanv; t.cos_alpha = nanv; }
+			else { t.cos_alpha = 1; t.alpha = SSX_PI_F * 0.5f; }
+		} else {
+			if (sin_c > 0) { t.cos_alpha = 1; t.alpha = SSX_PI_F * 0.5f; }
+			else { t.alpha = nanv; t.cos_alpha = nanv; }
+		}
+	} else {
+		if (sin_b > 0) {
+			if (sin_c > 0) { t.cos_alpha = clamp_glm(numer0 / denom0, -1.0f, 1.0f); t.alpha = ssx_acosf(t.cos_alpha); }
+			else { t.alpha = nanv; t.cos_alpha = nanv; }
+		} else { t.alpha = nanv; t.cos_alpha = nanv; }
+	}
+}
+
+__device__ __forceinline__ V3 func_bar(V3 x, V3 y) { // util/random.cpp:139-144
+	V3 dir = sub(x, scl(dot3(x, y), y));
+	float lensq = dot3(dir, dir);
+	if (lensq == 0.0f) return mk(0, 0, 0);
+	float is = inversesqrt_(lensq);
+	return mk(dir.x * is, dir.y * is, dir.z * is);
+}
+
+// util/random.cpp:101-154 (Arvo)
+__device__ __forceinline__ V3 rand_toward_sphericaltri(Rng& rng, const SphTri& tri) {
+	float r0 = rand_1f(rng);
+	float r1 = rand_1f(rng);
+	float sin_alpha = ssx_sinf(tri.alpha);
+	float q;
+	if (sin_alpha > 0) {
+		float random_area = r0 * tri.area;
+		float phi = random_area - tri.alpha;
+		float s, t;
+		ssx_sincosf(phi, &s, &t);
+		float u = t - tri.cos_alpha;
+		float v = s + sin_alpha * tri.cos_c;
+		float denom = (v * s + u * t) * sin_alpha;
+		if (denom != 0.0f) q = ((v * t - u * s) * tri.cos_alpha - v) / denom;
+		else q = tri.cos_c;
+	} else {
+		q = ssx_cosf(tri.b * r0); // random.cpp:134 (double cos of a float, rounded back)
+	}
+	q = clamp_glm(q, -1.0f, 1.0f);
+	V3 C_hat = add(scl(q, tri.A), scl(__builtin_sqrtf(1 - q * q), func_bar(tri.C, tri.A)));
+	float z = 1.0f - r1 * (1.0f - dot3(C_hat, tri.B));
+	z = clamp_glm(z, -1.0f, 1.0f);
+	return add(scl(z, tri.B), scl(__builtin_sqrtf(1 - z * z), func_bar(C_hat, tri.B)));
+}
+
+// scene.cpp:417-431 -> geometry.cpp:141-145 -> geometry.cpp:103-116
+__device__ __forceinline__ void sample_light(const Lds& L, Rng& rng, V3 from, V3& dir, uint32_t& light_quad, float& pdf) {
+	const uint32_t nl = L.hdr().n_lights;
+	light_quad = L.light(rand_choice(rng, nl));
+	const SsxBlobQuad& Q = L.quad(light_quad);
+	bool first = rand_1f(rng) <= 0.5f;
+	const float* p0 = Q.pos[0];
+	const float* p1 = first ? Q.pos[1] : Q.pos[2];
+	const float* p2 = first ? Q.pos[2] : Q.pos[3];
+	SphTri st;
+	sphtri_make(normalize3(sub(mk(p0[0], p0[1], p0[2]), from)),
+	            normalize3(sub(mk(p1[0], p1[1], p1[2]), from)),
+	            normalize3(sub(mk(p2[0], p2[1], p2[2]), from)), st);
+	dir = rand_toward_sphericaltri(rng, st);
+	pdf = 1.0f / st.area;
+	pdf *= 0.5f;
+	pdf /= (float)nl;
+}
+
+// ------------------------------------------------------------------ BSDF sampling ----
+// util/random.cpp:29-49
+__device__ __forceinline__ V3 rand_coshemi(Rng& rng, float& pdf) {
+	V3 result;
+	do {
+		float angle = rand_1f(rng) * (2.0f * SSX_PI_F);
+		float s, c;
+		ssx_sincosf(angle, &s, &c);
+		float radius_sq = rand_1f(rng);
+		float radius = __builtin_sqrtf(radius_sq);
+		result = mk(radius * c, __builtin_sqrtf(1 - radius_sq), radius * s);
+		pdf = result.y;
+	} while (pdf <= SSX_EPS);
+	pdf *= 1.0f / SSX_PI_F;
+	return result;
+}
+// util/math-helpers.hpp:14-39
+__device__ __forceinline__ V3 get_rotated_to(V3 dir, V3 n) {
+	float sign = __builtin_copysignf(1.0f, n.z);
+	float a = -1.0f / (sign + n.z);
+	float b = n.x * n.y * a;
+	V3 bx = mk(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
+	V3 bz = mk(b, sign + n.y * n.y * a, -n.y);
+	return add(add(scl(dir.x, bx), scl(dir.y, n)), scl(dir.z, bz));
+}
+__device__ __forceinline__ V3 reflect3(V3 vec, V3 n) { // math-helpers.hpp:40-42
+	return add(mk(-vec.x, -vec.y, -vec.z), scl(2.0f * dot3(vec, n), n));
+}
+
+// ------------------------------------------------------------------ one sample ----
+struct Frame { float direct[4]; float f_s[4]; float n_dot_l, pdf; };
+
+// renderer.cpp:104-277.  The recursion L() is unrolled into a forward pass that records, per
+// depth, direct = emission + NEE and the (n_dot_l, f_s, pdf) of the continuation, and a backward
+// fold rad_d = direct_d + ((rad_{d+1}*n_dot_l)*f_s)/pdf -- the same float operations in the same
+// order as the reference's post-order evaluation.
+__device__ __forceinline__ void render_sample(const Lds& L, const SsxKernelArgs& a, Rng& rng, uint32_t i, uint32_t j, float out[4]) {
+	const SsxBlobHeader& h = L.hdr();
+	// :113 -- g++ evaluates dvec2(rand_1d(rng),rand_1d(rng)) right to left: y first
+	double sub_y = rand_1d(rng);
+	double sub_x = rand_1d(rng);
+	double st_x = ((double)i + sub_x) / (double)a.width;
+	double st_y = ((double)j + sub_y) / (double)a.height;
+	double ndc_x = st_x * 2.0 - 1.0, ndc_y = st_y * 2.0 - 1.0;
+	V3 cam = mk(h.cam_pos[0], h.cam_pos[1], h.cam_pos[2]);
+	V3 dir;
+	{
+		double p[4];
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+			p[r] = (h.pv_inv[0 * 4 + r] * ndc_x + h.pv_inv[1 * 4 + r] * ndc_y) + (h.pv_inv[2 * 4 + r] * 0.0 + h.pv_inv[3 * 4 + r] * 1.0);
+		double w = p[3];
+		double px = p[0] / w, py = p[1] / w, pz = p[2] / w;
+		double dx = px - (double)cam.x, dy = py - (double)cam.y, dz = pz - (double)cam.z;
+		double inv = 1.0 / __builtin_sqrt((dx * dx + dy * dy) + dz * dz);
+		dir = mk((float)(dx * inv), (float)(dy * inv), (float)(dz * inv));
+	}
+	float lambda_0 = h.lambda_min + rand_1f(rng) * h.lambda_step; // :138
+
+	Frame stack[SSX_MAX_DEPTH_ - 1u];
+	float rad[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+	bool hit_anything = false;
+	V3 orig = cam;
+	int ignore = -1;
+	uint32_t depth = 0;
+	for (;;) {
+		HitInfo hit;
+		trace(L, orig, dir, ignore, hit);
+		if (hit.tri < 0) { rad[0] = rad[1] = rad[2] = rad[3] = 0.0f; break; }
+		hit_anything = true;
+		const uint32_t hq = (uint32_t)hit.tri >> 1, which = (uint32_t)hit.tri & 1u;
+		const SsxBlobQuad& Q = L.quad(hq);
+		const SsxBlobMaterial& M = L.material(Q.material);
+		V3 N = mk(Q.normal[which][0], Q.normal[which][1], Q.normal[which][2]);
+
+		float direct[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+		// emission: only the camera ray has last_was_delta (:169-172, :247)
+		if (depth == 0u && !a.indirect_only) {
+			Hero em = spectrum_hero(L, M.emission_spec, lambda_0, h.lambda_step);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) direct[k] += em.v[k];
+		}
+		// depth+1 < MAX_DEPTH always holds here: the loop never starts depth MAX_DEPTH-1 (see below)
+		V3 hit_pos = add(orig, scl(hit.dist, dir)); // Ray::at
+		// hitrec.st (geometry.cpp:91-95) is read only by textured albedo
+		float st_x = 0.0f, st_y = 0.0f;
+		if (M.albedo_mode != 0u) {
+			float bx = hit.U * hit.det_recip, by = hit.V * hit.det_recip, bz = hit.W * hit.det_recip;
+			const float* s0 = Q.st[0];
+			const float* s1 = which ? Q.st[2] : Q.st[1];
+			const float* s2 = which ? Q.st[3] : Q.st[2];
+			st_x = (bx * s0[0] + by * s1[0]) + bz * s2[0];
+			st_y = (bx * s0[1] + by * s1[1]) + bz * s2[1];
+		}
+		// albedo(lambda) is shared by evaluate_bsdf and interact_bsdf (material.cpp:120-143)
+		Hero alb = material_albedo(L, M, st_x, st_y, lambda_0);
+		float f_lamb[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) f_lamb[k] = alb.v[k] / SSX_PI_F;
+
+		// direct lighting (:182-219)
+		if (!a.indirect_only || depth > 0u) {
+			V3 sdir; uint32_t light; float spdf;
+			sample_light(L, rng, hit_pos, sdir, light, spdf);
+			float n_dot_l = dot3(sdir, N);
+			if (n_dot_l > 0.0f) {
+				HitInfo sh;
+				trace(L, hit_pos, sdir, (int)hq, sh);
+				if (sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == light) {
+					const SsxBlobMaterial& LM = L.material(L.quad(light).material);
+					Hero emitted = spectrum_hero(L, LM.emission_spec, lambda_0, h.lambda_step);
+#pragma unroll
+					for (int k = 0; k < 4; ++k) {
+						float fs = (M.kind == 0u) ? f_lamb[k] : 0.0f; // Mirror::evaluate_bsdf -> 0
+						direct[k] += ((emitted.v[k] * n_dot_l) * fs) / spdf;
+					}
+				}
+			}
+		}
+
+		// indirect lighting (:222-250)
+		V3 w_i; float pdf_w_i; float f_s[4];
+		if (M.kind == 0u) {
+			w_i = rand_coshemi(rng, pdf_w_i);
+			w_i = get_rotated_to(w_i, N);
+#pragma unroll
+			for (int k = 0; k < 4; ++k) f_s[k] = f_lamb[k];
+		} else {
+			w_i = reflect3(mk(-dir.x, -dir.y, -dir.z), N);
+			pdf_w_i = __builtin_inff();
+#pragma unroll
+			for (int k = 0; k < 4; ++k) f_s[k] = alb.v[k];
+		}
+		bool cont = false;
+		float n_dot_l = 0.0f;
+		float dotfs = (f_s[0] * f_s[0] + f_s[1] * f_s[1]) + (f_s[2] * f_s[2] + f_s[3] * f_s[3]);
+		if (dotfs > 0.0f) {
+			if (__builtin_isfinite(pdf_w_i)) n_dot_l = dot3(w_i, N);
+			else { n_dot_l = 1.0f; pdf_w_i = 1.0f; }
+			cont = n_dot_l > 0.0f;
+		}
+		// A ray at depth MAX_DEPTH-1 can add nothing (no emission: last_was_delta is false; no
+		// further bounce: depth+1 == MAX_DEPTH) and hit_anything is already set, so it is not traced:
+		// its L() is 0 unless it hits, and (0*n)*f/p == 0 either way.
+		if (!cont || depth + 2u >= SSX_MAX_DEPTH_) {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) rad[k] = direct[k];
+			if (cont) { // deepest level reached: child radiance is exactly 0 -> direct + ((0*n)*f)/p
+#pragma unroll
+				for (int k = 0; k < 4; ++k) rad[k] = direct[k] + ((0.0f * n_dot_l) * f_s[k]) / pdf_w_i;
+			}
+			break;
+		}
+		Frame& F = stack[depth];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) { F.direct[k] = direct[k]; F.f_s[k] = f_s[k]; }
+		F.n_dot_l = n_dot_l; F.pdf = pdf_w_i;
+		orig = hit_pos; dir = w_i; ignore = (int)hq;
+		++depth;
+	}
+	// backward fold
+	while (depth > 0u) {
+		--depth;
+		const Frame& F = stack[depth];
+#pragma unroll
+		for (int k = 0; k < 4; ++k) rad[k] = F.direct[k] + ((rad[k] * F.n_dot_l) * F.f_s[k]) / F.pdf;
+	}
+	Hero flux; // FLAT_FIELD_CORRECTION: flux = radiance (:262-263)
+#pragma unroll
+	for (int k = 0; k < 4; ++k) flux.v[k] = rad[k];
+	float xyz[3];
+	flux_to_xyz(L, flux, lambda_0, xyz);
+	out[0] = xyz[0]; out[1] = xyz[1]; out[2] = xyz[2];
+	out[3] = hit_anything ? 1.0f : 0.0f;
+}
+
+} // namespace
+
+// One wave64 per 8x8 tile (Framebuffer::Tile, renderer.cpp:396-409), one lane per pixel; four
+// tiles per 256-lane workgroup share one LDS copy of the scene blob.
+extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArgs a) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds_blob[];
+	for (uint32_t w = threadIdx.x; w < a.blob_words; w += blockDim.x) lds_blob[w] = a.blob[w];
+	__syncthreads();
+	Lds L; L.w = lds_blob;
+
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wave;   // index among this device's tiles
+	const uint64_t tile64 = (uint64_t)a.tile_first + (uint64_t)slot * (uint64_t)a.tile_stride;
+	if (tile64 >= (uint64_t)a.n_tiles) return;
+	const uint32_t tile = (uint32_t)tile64;
+	const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+	const uint32_t i = tx * 8u + (lane & 7u), j = ty * 8u + (lane >> 3);
+	if (i >= a.width || j >= a.height) return;
+	const uint64_t pixel = (uint64_t)j * (uint64_t)a.width + (uint64_t)i;
+
+	double* acc_p = a.accum + 4u * pixel;
+	double acc[4] = { acc_p[0], acc_p[1], acc_p[2], acc_p[3] };
+	const uint64_t pa = mix64(a.seed + 0x9E3779B97F4A7C15ull * (pixel + 1ull));
+	for (uint32_t k = a.k0; k < a.k1; ++k) {
+		Rng rng;
+		uint64_t b = mix64(pa + 0x9E3779B97F4A7C15ull * ((uint64_t)k + 1ull));
+		rng.state = b;
+		rng.inc = mix64(b ^ 0xDA3E39CB94B95BDBull) | 1ull;
+		float s[4];
+		render_sample(L, a, rng, i, j, s);
+#pragma unroll
+		for (int c = 0; c < 4; ++c) acc[c] += (double)(s[c] * 0.001f); // renderer.cpp:294
+	}
+	acc_p[0] = acc[0]; acc_p[1] = acc[1]; acc_p[2] = acc[2]; acc_p[3] = acc[3];
+}
+
+// renderer.cpp:296,298: avg *= 1000.0/spp, then the float conversion of CIEXYZ_32F(avg) / avg.a.
+// Pixels of tiles this device does not own are written as 0 (x+0 is exact in the RCCL sum).
+extern "C" __global__ void __launch_bounds__(256) ssx_finalize_kernel(const double* accum, float4* out, uint32_t width, uint32_t height,
+                                                  uint32_t tiles_x, uint32_t tile_first, uint32_t tile_stride, uint32_t spp) {
+	uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= width * height) return;
+	uint32_t i = p % width, j = p / width;
+	uint32_t tile = (j >> 3) * tiles_x + (i >> 3);
+	float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	if (tile % tile_stride == tile_first) {
+		double sc = 1000.0 / (double)spp;
+		o.x = (float)(accum[4u * p + 0] * sc);
+		o.y = (float)(accum[4u * p + 1] * sc);
+		o.z = (float)(accum[4u * p + 2] * sc);
+		o.w = (float)(accum[4u * p + 3] * sc);
+	}
+	out[p] = o;
+}

@@ -1,0 +1,99 @@
+// host_api.cpp -- C entry points of libssx_host.so (include/ssx_host.h).
+#include "../../include/ssx_host.h"
+
+#include "color.hpp"
+#include "image_io.hpp"
+#include "scene.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+struct ssh_scene {
+	std::unique_ptr<ssx::ColorData> color;
+	std::unique_ptr<ssx::Scene> scene;
+};
+
+namespace {
+thread_local std::string g_error;
+int report(const ssx::HostError& e) { g_error = e.message; return e.code; }
+} // namespace
+
+extern "C" {
+
+const char* ssh_last_error(void) { return g_error.c_str(); }
+
+int ssh_scene_create(const char* scene_name, const char* data_dir, int observer,
+                     const uint8_t* tex_rgb, uint32_t tex_w, uint32_t tex_h, const char* texture_path,
+                     float light_scale, ssh_scene** out) {
+	if (!scene_name || !data_dir || !out) { g_error = "NULL argument"; return SSX_ERR_ARG; }
+	*out = nullptr;
+	try {
+		auto s = std::make_unique<ssh_scene>();
+		s->color = std::make_unique<ssx::ColorData>(data_dir, observer);
+		ssx::Texture tex;
+		const ssx::Texture* texp = nullptr;
+		if (tex_rgb && tex_w && tex_h) {
+			tex.width = tex_w; tex.height = tex_h;
+			tex.rgb.assign(tex_rgb, tex_rgb + (size_t)3 * tex_w * tex_h);
+			texp = &tex;
+		} else if (texture_path && *texture_path) {
+			tex = ssx::load_png_rgb8(texture_path);
+			texp = &tex;
+		}
+		s->scene = std::make_unique<ssx::Scene>(*s->color, scene_name, data_dir, texp, light_scale);
+		*out = s.release();
+		return SSX_OK;
+	} catch (const ssx::HostError& e) {
+		return report(e);
+	} catch (const std::exception& e) {
+		g_error = e.what();
+		return SSX_ERR_DATA;
+	}
+}
+
+void ssh_scene_destroy(ssh_scene* scene) { delete scene; }
+
+const ssx_scene_desc* ssh_scene_desc(const ssh_scene* scene) { return scene ? &scene->scene->desc() : nullptr; }
+
+int ssh_xyza_to_srgba(const ssh_scene* scene, const float* xyza, float* srgba, size_t n) {
+	if (!scene || !xyza || !srgba) { g_error = "NULL argument"; return SSX_ERR_ARG; }
+	for (size_t p = 0; p < n; ++p) {
+		scene->color->ciexyz_to_srgb(xyza + 4 * p, srgba + 4 * p);
+		srgba[4 * p + 3] = xyza[4 * p + 3];
+	}
+	return SSX_OK;
+}
+
+int ssh_save_image(const char* path, const float* srgba, uint32_t width, uint32_t height) {
+	if (!path || !srgba) { g_error = "NULL argument"; return SSX_ERR_ARG; }
+	try { ssx::save_image(path, srgba, width, height); return SSX_OK; }
+	catch (const ssx::HostError& e) { return report(e); }
+}
+
+int ssh_load_png_rgb8(const char* path, uint8_t** rgb_out, uint32_t* width, uint32_t* height) {
+	if (!path || !rgb_out || !width || !height) { g_error = "NULL argument"; return SSX_ERR_ARG; }
+	try {
+		ssx::Texture t = ssx::load_png_rgb8(path);
+		*rgb_out = static_cast<uint8_t*>(malloc(t.rgb.size()));
+		memcpy(*rgb_out, t.rgb.data(), t.rgb.size());
+		*width = t.width; *height = t.height;
+		return SSX_OK;
+	} catch (const ssx::HostError& e) { return report(e); }
+}
+void ssh_free(void* p) { free(p); }
+
+int ssh_color_values(const ssh_scene* scene, const char* name, float* out, int capacity) {
+	if (!scene || !name || !out) return SSX_ERR_ARG;
+	const ssx::ColorData& c = *scene->color;
+	const float* src = nullptr; int n = 0;
+	if (!strcmp(name, "D65_rad_XYZ")) { src = c.D65_rad_XYZ; n = 3; }
+	else if (!strcmp(name, "xyz_to_lrgb")) { src = &c.matr_xyz_to_lrgb.m[0][0]; n = 9; }
+	else if (!strcmp(name, "lrgb_to_xyz")) { src = &c.matr_lrgb_to_xyz.m[0][0]; n = 9; }
+	else return SSX_ERR_ARG;
+	if (capacity < n) return SSX_ERR_ARG;
+	memcpy(out, src, sizeof(float) * (size_t)n);
+	return n;
+}
+
+} // extern "C"

@@ -1,0 +1,165 @@
+#include "image_io.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iterator>
+
+namespace ssx {
+namespace {
+
+uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | (uint32_t)p[3]; }
+void put_be32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+
+int paeth(int a, int b, int c) {
+	const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+	return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+bool ends_with(const std::string& s, const char* suffix) {
+	const size_t n = std::strlen(suffix);
+	return s.size() >= n && s.compare(s.size() - n, n, suffix) == 0;
+}
+
+void write_chunk(std::vector<uint8_t>& out, const char type[4], const std::vector<uint8_t>& data) {
+	put_be32(out, (uint32_t)data.size());
+	const size_t start = out.size();
+	out.insert(out.end(), type, type + 4);
+	out.insert(out.end(), data.begin(), data.end());
+	put_be32(out, (uint32_t)crc32(0L, out.data() + start, (uInt)(out.size() - start)));
+}
+
+} // namespace
+
+// Non-interlaced PNG, bit depth 8 (grey, grey+alpha, RGB, RGBA, palette) or 16 (high byte kept).
+Texture load_png_rgb8(const std::string& path) {
+	std::ifstream f(path, std::ios::binary);
+	if (!f.good()) throw HostError{ -1, "Could not load texture \"" + path + "\"" };
+	std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+	static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n' };
+	if (file.size() < 8 || std::memcmp(file.data(), sig, 8) != 0) throw HostError{ -1, "Could not load texture \"" + path + "\"" };
+
+	uint32_t w = 0, h = 0; int depth = 0, ctype = -1, interlace = 0;
+	std::vector<uint8_t> idat, palette;
+	for (size_t pos = 8; pos + 12 <= file.size();) {
+		const uint32_t len = be32(&file[pos]);
+		const char* type = reinterpret_cast<const char*>(&file[pos + 4]);
+		const uint8_t* data = &file[pos + 8];
+		if (pos + 12 + len > file.size()) break;
+		if (!std::memcmp(type, "IHDR", 4) && len >= 13) { w = be32(data); h = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12]; }
+		else if (!std::memcmp(type, "PLTE", 4)) palette.assign(data, data + len);
+		else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
+		else if (!std::memcmp(type, "IEND", 4)) break;
+		pos += 12 + len;
+	}
+	const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+	if (!w || !h || !channels || interlace || (depth != 8 && depth != 16) || (ctype == 3 && depth != 8))
+		throw HostError{ -1, "Could not load texture \"" + path + "\" (unsupported PNG variant)" };
+	const size_t bpp = (size_t)channels * (depth / 8), stride = bpp * w;
+	std::vector<uint8_t> raw((stride + 1) * h);
+	uLongf raw_len = (uLongf)raw.size();
+	if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size())
+		throw HostError{ -1, "Could not load texture \"" + path + "\" (bad zlib stream)" };
+
+	std::vector<uint8_t> img(stride * h);
+	for (uint32_t y = 0; y < h; ++y) {
+		const uint8_t filter = raw[(stride + 1) * y];
+		const uint8_t* src = &raw[(stride + 1) * y + 1];
+		uint8_t* dst = &img[stride * y];
+		const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
+		for (size_t x = 0; x < stride; ++x) {
+			const int a = x >= bpp ? dst[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
+			int v = src[x];
+			switch (filter) {
+				case 1: v += a; break;
+				case 2: v += b; break;
+				case 3: v += (a + b) / 2; break;
+				case 4: v += paeth(a, b, c); break;
+				default: break;
+			}
+			dst[x] = (uint8_t)v;
+		}
+	}
+	Texture t;
+	t.width = w; t.height = h;
+	t.rgb.resize((size_t)3 * w * h);
+	const size_t step = depth / 8;
+	for (size_t p = 0; p < (size_t)w * h; ++p) {
+		const uint8_t* px = &img[p * bpp];
+		uint8_t r, g, b;
+		if (ctype == 3) { const size_t k = (size_t)px[0] * 3; r = k + 2 < palette.size() ? palette[k] : 0; g = k + 2 < palette.size() ? palette[k + 1] : 0; b = k + 2 < palette.size() ? palette[k + 2] : 0; }
+		else if (channels <= 2) { r = g = b = px[0]; }
+		else { r = px[0]; g = px[step]; b = px[2 * step]; }
+		t.rgb[3 * p] = r; t.rgb[3 * p + 1] = g; t.rgb[3 * p + 2] = b;
+	}
+	return t;
+}
+
+void save_image(const std::string& path, const float* srgba, size_t W, size_t H) {
+	auto to_linear = [&](size_t j, size_t i, float out[3]) {
+		const float* p = srgba + 4 * (j * W + i);
+		for (int c = 0; c < 3; ++c) out[c] = srgb_to_lrgb(p[c]);
+	};
+	FILE* file = std::fopen(path.c_str(), "wb");
+	if (!file) throw HostError{ -1, "Could not open \"" + path + "\" for writing" };
+	if (ends_with(path, ".csv")) { // linear RGB text, rows bottom to top as stored (framebuffer.cpp:40-63)
+		for (size_t j = 0; j < H; ++j) for (size_t i = 0; i < W; ++i) {
+			float l[3]; to_linear(j, i, l);
+			std::fprintf(file, "%g,%g,%g", (double)l[0], (double)l[1], (double)l[2]);
+			std::fputc(i + 1 < W ? ',' : '\n', file);
+		}
+	} else if (ends_with(path, ".hdr")) { // flat RGBE, top row first (framebuffer.cpp:64-111)
+		std::fprintf(file, "#?RADIANCE\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\nSOFTWARE=simple-spectral\n\n-Y %zu +X %zu\n", H, W);
+		for (size_t j = 0; j < H; ++j) for (size_t i = 0; i < W; ++i) {
+			float l[3]; to_linear(H - 1 - j, i, l);
+			float v = std::max(l[0], std::max(l[1], l[2]));
+			if (v < 1.0e-32f) { const uint32_t zero = 0; std::fwrite(&zero, 4, 1, file); continue; }
+			int e;
+			v = std::frexp(v, &e) * 256.0f / v;
+			e += 128;
+			uint8_t px[4];
+			for (int c = 0; c < 3; ++c) {
+				const int q = (int)std::round(std::round(l[c] * v));
+				px[c] = (uint8_t)std::min(std::max(q, 0), 255);
+			}
+			px[3] = (uint8_t)e;
+			std::fwrite(px, 1, 4, file);
+		}
+	} else if (ends_with(path, ".pfm")) { // linear float RGB, bottom row first, little endian (framebuffer.cpp:112-140)
+		std::fprintf(file, "PF\n%zu %zu\n-1.0\n", W, H);
+		for (size_t j = 0; j < H; ++j) for (size_t i = 0; i < W; ++i) {
+			float l[3]; to_linear(H - 1 - j, i, l);
+			std::fwrite(l, sizeof(float), 3, file);
+		}
+	} else { // RGBA8 PNG, rows flipped to top-to-bottom (framebuffer.cpp:141-175)
+		std::vector<uint8_t> raw((4 * W + 1) * H);
+		for (size_t j = 0; j < H; ++j) {
+			uint8_t* row = &raw[(4 * W + 1) * (H - 1 - j)];
+			row[0] = 0; // filter type None
+			for (size_t i = 0; i < W; ++i) for (int c = 0; c < 4; ++c) {
+				float v = 255.0f * srgba[4 * (j * W + i) + c];
+				v = std::min(std::max(v, 0.0f), 255.0f);
+				row[1 + 4 * i + c] = (uint8_t)std::round(v);
+			}
+		}
+		uLongf zlen = compressBound((uLong)raw.size());
+		std::vector<uint8_t> z(zlen);
+		if (compress2(z.data(), &zlen, raw.data(), (uLong)raw.size(), 6) != Z_OK) { std::fclose(file); throw HostError{ -1, "PNG compression failed" }; }
+		z.resize(zlen);
+		std::vector<uint8_t> out = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n' };
+		std::vector<uint8_t> ihdr;
+		put_be32(ihdr, (uint32_t)W); put_be32(ihdr, (uint32_t)H);
+		ihdr.insert(ihdr.end(), { 8, 6, 0, 0, 0 }); // 8-bit RGBA, deflate, adaptive filtering, no interlace
+		write_chunk(out, "IHDR", ihdr);
+		write_chunk(out, "IDAT", z);
+		write_chunk(out, "IEND", {});
+		std::fwrite(out.data(), 1, out.size(), file);
+	}
+	std::fclose(file);
+}
+
+} // namespace ssx

@@ -1,0 +1,195 @@
+"""Host-side mirror of the reference's Renderer (src/renderer.hpp:14-82) over the C ABI.
+
+    opts = Options(scene_name="cornell-srgb", res=(512, 512), spp=256)
+    r = Renderer(opts)            # builds tables + scene on the host, uploads to the GPU
+    r.render_start(); r.render_wait()
+    r.framebuffer                 # sRGB+A float32 [H, W, 4], row 0 = bottom (src/framebuffer.hpp:26-34)
+    r.xyza                        # the XYZ+alpha means the kernel produced (parity metric)
+
+Everything numeric happens in libssx_hip.so / libssx_host.so; there is no Python or PyTorch
+implementation of the integrator to fall back to.
+"""
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEFAULT_DATA_DIR = os.path.join(ROOT, "data")
+
+
+class SsxError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("ssx error %d: %s" % (code, message))
+        self.code = code
+
+
+@dataclass
+class Options:
+    """Renderer::Options (src/renderer.hpp:16-29) plus the additive options of this build."""
+    scene_name: str = "cornell-srgb"
+    res: Tuple[int, int] = (512, 512)
+    spp: int = 16
+    indirect_only: bool = False
+    output_path: str = ""
+    # additive (defaults = the reference's compile-time defaults)
+    observer: int = 1931                 # CIE_OBSERVER
+    seed: int = 0
+    texture: Optional[str] = None        # PNG path; default per scene below
+    light_scale: float = 30.0            # lightsc (src/scene.cpp:291-293)
+    device: int = 0
+    tile_first: int = 0
+    tile_stride: int = 1
+    spp_per_launch: int = 0
+    data_dir: str = field(default=DEFAULT_DATA_DIR)
+
+
+def default_texture(data_dir):
+    """The reference opens data/scenes/crystal-lizard-4096.png (src/scene.cpp:292,357), a blob
+    missing from the repository; like the reference's own commented alternatives we fall back to
+    the 512^2 version when it is absent."""
+    for name in ("crystal-lizard-4096.png", "crystal-lizard-512.png", "test-img.png"):
+        p = os.path.join(data_dir, "scenes", name)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+class Scene:
+    """Host-prepared scene + colour tables (libssx_host.so)."""
+
+    def __init__(self, name, observer=1931, texture=None, light_scale=30.0, data_dir=DEFAULT_DATA_DIR):
+        lib = _capi.host_lib()
+        self._lib = lib
+        self._h = C.c_void_p()
+        tex_path = None
+        self._tex = None
+        if name != "cornell":
+            if isinstance(texture, np.ndarray):
+                self._tex = np.ascontiguousarray(texture, dtype=np.uint8)
+            else:
+                tex_path = texture or default_texture(data_dir)
+                if tex_path and not os.path.isabs(tex_path) and not os.path.exists(tex_path):
+                    tex_path = os.path.join(data_dir, "scenes", tex_path)
+        tp, tw, th = (self._tex.ctypes.data, self._tex.shape[1], self._tex.shape[0]) if self._tex is not None else (None, 0, 0)
+        rc = lib.ssh_scene_create(name.encode(), data_dir.encode(), observer, tp, tw, th,
+                                  tex_path.encode() if tex_path else None, C.c_float(light_scale), C.byref(self._h))
+        if rc != 0:
+            raise SsxError(rc, lib.ssh_last_error().decode())
+        self.name = name
+
+    @property
+    def desc(self):
+        return self._lib.ssh_scene_desc(self._h)
+
+    def xyza_to_srgba(self, xyza):
+        xyza = np.ascontiguousarray(xyza, dtype=np.float32)
+        out = np.empty_like(xyza)
+        rc = self._lib.ssh_xyza_to_srgba(self._h, xyza.ctypes.data, out.ctypes.data, xyza.size // 4)
+        if rc != 0:
+            raise SsxError(rc, self._lib.ssh_last_error().decode())
+        return out
+
+    def color_values(self, name):
+        buf = (C.c_float * 16)()
+        n = self._lib.ssh_color_values(self._h, name.encode(), buf, 16)
+        if n < 0:
+            raise SsxError(n, "unknown colour table %r" % name)
+        return np.array(buf[:n], dtype=np.float32)
+
+    def close(self):
+        if self._h:
+            self._lib.ssh_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Renderer:
+    """Renderer (src/renderer.hpp:14-82): render_start / render_stop / render_wait / is_rendering,
+    public `framebuffer` and `scene`."""
+
+    def __init__(self, options: Options):
+        self.options = options
+        self.scene = Scene(options.scene_name, options.observer, options.texture, options.light_scale, options.data_dir)
+        self._lib = _capi.hip_lib()
+        self._ctx = C.c_void_p()
+        rc = self._lib.ssx_create(options.device, C.byref(self._ctx))
+        if rc != 0:
+            raise SsxError(rc, self._lib.ssx_last_error(None).decode())
+        self._check(self._lib.ssx_upload_scene(self._ctx, self.scene.desc))
+        W, H = options.res
+        self.xyza = np.zeros((H, W, 4), dtype=np.float32)
+        self.framebuffer = np.zeros((H, W, 4), dtype=np.float32)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SsxError(rc, self._lib.ssx_last_error(self._ctx).decode())
+
+    def params(self, **over):
+        o = self.options
+        p = _capi.SsxRenderParams()
+        p.struct_size = C.sizeof(_capi.SsxRenderParams)
+        p.width, p.height = o.res
+        p.spp = o.spp
+        p.indirect_only = int(o.indirect_only)
+        p.tile_first, p.tile_stride = o.tile_first, o.tile_stride
+        p.spp_per_launch = o.spp_per_launch
+        p.seed = o.seed
+        for k, v in over.items():
+            setattr(p, k, v)
+        return p
+
+    def render_start(self):
+        self._check(self._lib.ssx_render_start(self._ctx, C.byref(self.params())))
+
+    def render_stop(self):
+        self._check(self._lib.ssx_render_stop(self._ctx))
+
+    def is_rendering(self):
+        return bool(self._lib.ssx_is_rendering(self._ctx))
+
+    def progress(self):
+        return float(self._lib.ssx_progress(self._ctx))
+
+    def render_wait(self):
+        self._check(self._lib.ssx_render_wait(self._ctx, self.xyza.ctypes.data))
+        self.framebuffer = self.scene.xyza_to_srgba(self.xyza)  # src/renderer.cpp:298
+        if self.options.output_path:
+            self.save(self.options.output_path)
+        return self.framebuffer
+
+    def render_device(self, d_ptr, stream=0, **over):
+        """Enqueue the render on `stream` into the device buffer at d_ptr (W*H float4)."""
+        p = self.params(**over)
+        self._check(self._lib.ssx_render_device(self._ctx, C.byref(p), C.c_void_p(d_ptr), C.c_void_p(stream)))
+
+    def kernel_info(self):
+        v = [C.c_int() for _ in range(5)]
+        self._check(self._lib.ssx_kernel_info(self._ctx, *[C.byref(x) for x in v]))
+        return dict(zip(("vgprs", "sgprs", "lds_bytes", "scratch_bytes", "max_blocks_per_cu"), [x.value for x in v]))
+
+    def save(self, path):
+        fb = np.ascontiguousarray(self.framebuffer, dtype=np.float32)
+        rc = _capi.host_lib().ssh_save_image(path.encode(), fb.ctypes.data, fb.shape[1], fb.shape[0])
+        if rc != 0:
+            raise SsxError(rc, _capi.host_lib().ssh_last_error().decode())
+
+    def close(self):
+        if self._ctx:
+            self._lib.ssx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
