@@ -1,0 +1,157 @@
+"""Pins of the CPU oracle (runs without a GPU).
+
+What is pinned against what (DESIGN.md "Oracle"):
+  * PCG32              <- published pcg32 demo vectors (pcg-random.org, seed 42 / stream 54)
+  * <random> semantics <- vectors produced by the real libstdc++ in this image (golden/stdlib_vectors.json)
+  * colour pipeline    <- the reference's own known-answers: max sRGB round-trip error 1.851469e-5
+                          (src/main.cpp:242-245) and D65[560nm]==100 (src/util/color.cpp:115)
+  * tables / camera / hash / work statistics <- constants recorded in SURVEY.md (survey probe;
+                          secondary evidence, not reference-held)
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return ol.load()
+
+
+def test_pcg32_published_vectors(lib):
+    # pcg32_srandom_r(42, 54) of the PCG reference implementation, then six outputs
+    M, mult, inc = (1 << 64) - 1, 6364136223846793005, (54 << 1) | 1
+    state = (0 * mult + inc) & M
+    state = (state + 42) & M
+    state = (state * mult + inc) & M
+    r = ol.Rng(state, inc)
+    got = [lib.orc_rng_next(C.byref(r)) for _ in range(6)]
+    assert got == [0xA15C02B7, 0x7B47F409, 0xBA1D3330, 0x83D2F293, 0xBFA4784B, 0xCBED606E]
+
+
+def test_thread_seeding_kats(lib):
+    # FNV-1a64 of the thread index, seed(u32) replicated into state and inc
+    assert lib.orc_get_hashed_u32(0) == 0x4D25767F9DCE13F5
+    seeds = [lib.orc_get_hashed_u32(i) & 0xFFFFFFFF for i in range(8)]
+    assert seeds == [0x9DCE13F5, 0x47985764, 0x4A398D17, 0xF403D086, 0x44F721B1, 0xEEC16520, 0xF1629AD3, 0x9B2CDE42]
+    r = ol.Rng()
+    lib.orc_rng_seed_u32(C.byref(r), seeds[0])
+    assert r.state == r.inc == 0x9DCE13F59DCE13F5
+    assert [lib.orc_rng_next(C.byref(r)) for _ in range(3)] == [0xD2187738, 0x0243D744, 0x22E47900]
+    lib.orc_rng_seed_u32(C.byref(r), seeds[0])
+    assert np.float32(lib.orc_rand_1f(C.byref(r))) == np.float32(0.820685804)
+    assert lib.orc_rand_1d(C.byref(r)) == 0.13629871607032784
+
+
+def test_libstdcxx_distribution_vectors(lib):
+    cases = json.load(open(os.path.join(HERE, "golden", "stdlib_vectors.json")))["cases"]
+    for case in cases:
+        st, inc = int(case["state"]), int(case["inc"])
+        r = ol.Rng(st, inc)
+        assert [lib.orc_rng_next(C.byref(r)) for _ in range(8)] == case["u32"]
+        r = ol.Rng(st, inc)
+        assert [float(lib.orc_rand_1f(C.byref(r))) for _ in range(16)] == [float.fromhex(h) for h in case["rand_1f_hex"]]
+        r = ol.Rng(st, inc)
+        assert [lib.orc_rand_1d(C.byref(r)) for _ in range(16)] == [float.fromhex(h) for h in case["rand_1d_hex"]]
+        for n, want in case["rand_choice"].items():
+            r = ol.Rng(st, inc)
+            assert [lib.orc_rand_choice(C.byref(r), int(n)) for _ in range(24)] == want
+        for n, key in ((1, "state_after_24_choice1"), (6, "state_after_24_choice6")):
+            r = ol.Rng(st, inc)
+            for _ in range(24):
+                lib.orc_rand_choice(C.byref(r), n)
+            assert r.state == int(case[key])  # draws consumed, including n==1
+
+
+@pytest.fixture(scope="module")
+def cornell():
+    o = ol.Oracle("cornell", texture=None)
+    yield o
+    o.close()
+
+
+def test_reference_asserts_and_table_properties(cornell):
+    d65, low, high, _ = cornell.spectrum("D65_orig")
+    assert (low, high, len(d65)) == (300.0, 780.0, 97)
+    hero = (C.c_float * 4)()
+    cornell.lib.orc_spectrum_hero(cornell.lib.orc_color_spectrum(cornell.color, b"D65_orig"), 560.0, 100.0, hero)
+    assert hero[0] == 100.0  # assert at src/util/color.cpp:115
+    r, g, b = (cornell.spectrum(n)[0] for n in ("basis_r", "basis_g", "basis_b"))
+    s = r.astype(np.float64) + g + b  # partition of unity of the BT.709 basis
+    assert s.min() > 0.99999 and s.max() < 1.0000001  # float32-rounded table values
+
+
+def test_survey_constants(cornell):
+    d = cornell.lib.orc_color_d65_rad_xyz(cornell.color)
+    assert [np.float32(d[i]) for i in range(3)] == [np.float32(4261.94092), np.float32(4484.22705), np.float32(4882.4292)]
+    m = cornell.lib.orc_color_matrix(cornell.color, b"xyz_to_lrgb")
+    want = [7.22718483e-4, -2.16141823e-4, 1.24091002e-5, -3.42827989e-4, 4.1834166e-4, -4.55000518e-5,
+            -1.11187466e-4, 9.26680423e-6, 2.35773099e-4]
+    assert [np.float32(m[i]) for i in range(9)] == [np.float32(x) for x in want]
+    pv = cornell.lib.orc_scene_pv_inv(cornell.scene)
+    assert pv[0] == -0.3541185758710757 and pv[5] == 0.3541185758710757
+    assert [pv[i] for i in range(8, 16)] == [-1250.9999067932438, -1228.4999084696242, 3599.9997317791181,
+                                            -4.499999664723898, 1529.0000186413511, 1501.5000183060752,
+                                            -4399.0000536441758, 5.50000006705522]
+    p = ol.Oracle("plane-srgb", texture="test-img.png")
+    pv = p.lib.orc_scene_pv_inv(p.scene)
+    assert pv[0] == 0.19999999999999998
+    assert [pv[i] for i in (10, 11, 14, 15)] == [-22.49999832361949, -4.499999664723898, 26.500000335276098, 5.50000006705522]
+    np_, nl = C.c_int(), C.c_int()
+    p.lib.orc_scene_counts(p.scene, C.byref(np_), C.byref(nl), None)
+    assert (np_.value, nl.value) == (7, 6)
+    cornell.lib.orc_scene_counts(cornell.scene, C.byref(np_), C.byref(nl), None)
+    assert (np_.value, nl.value) == (19, 1)
+
+
+@pytest.mark.slow
+def test_reference_round_trip_known_answer(cornell):
+    """The only numeric known-answer in the reference: 'with CIE 1931, the expected maximum error
+    is 1.851469e-5' over all 2^24 sRGB8 colours (src/main.cpp:242-265)."""
+    e = cornell.lib.orc_round_trip_max_error(cornell.color, 0, 256, os.cpu_count() or 1)
+    assert "%.6e" % e == "1.851469e-05"
+
+
+def test_work_statistics_match_survey():
+    """Per-sample work of the integrator vs the instrumented reference run recorded in SURVEY.md
+    section 8 (different seeds, so statistical agreement only)."""
+    o = ol.Oracle("cornell-srgb", texture="crystal-lizard-512.png")
+    _, st = o.render(128, 128, 8, stats=True)
+    n = st.samples
+    assert abs(st.rays / n - 8.43) < 0.06
+    assert abs(st.tri_tests / n - 300.3) < 2.0
+    assert abs(st.tri_edge_pass / n - 12.25) < 0.1
+    assert abs(st.interactions / n - 4.29) < 0.03
+    assert abs(st.tex_samples / n - 1.27) < 0.03
+    assert abs(st.hits / n - 0.947) < 0.003
+    hist = [st.path_len_hist[i] / n for i in range(10)]
+    for got, want in zip(hist, [.053, .261, .118, .088, .067, .054, .044, .039, .032, .245]):
+        assert abs(got - want) < 0.006
+    p = ol.Oracle("plane-srgb", texture="crystal-lizard-512.png")
+    _, st = p.render(128, 128, 8, stats=True)
+    n = st.samples
+    assert st.path_len_hist[2] == n  # S = 2 always
+    assert abs(st.rays / n - 3.36) < 0.02 and abs(st.tri_tests / n - 40.5) < 0.3 and abs(st.tex_samples / n - 1.5) < 0.02
+
+
+def test_oracle_matches_committed_goldens():
+    g = np.load(os.path.join(HERE, "golden", "integrator_goldens.npz"))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_goldens", os.path.join(HERE, "golden", "make_goldens.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    for name, scene, obs, tex, W, H, spp, seed, io in mg.CASES:
+        o = ol.Oracle(scene, observer=obs, texture=tex)
+        img = o.render(W, H, spp, seed=seed, indirect_only=io)  # threaded: must not depend on thread count
+        assert np.array_equal(img.view(np.uint32), g[name + "__image"].view(np.uint32)), name
+        for (i, j, k), want in zip(g[name + "__ijk"], g[name + "__samples"]):
+            got = o.sample(int(i), int(j), int(k), W, H, seed=seed, indirect_only=io)
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (name, i, j, k)
+        o.close()
