@@ -37,7 +37,7 @@ def cpu_baseline(scene, W, H, texture, target_seconds=12.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
 
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     o = ol.Oracle(scene, texture=texture)
     t = time.time()
     o.render(W, H, 1, nthreads=cores)
