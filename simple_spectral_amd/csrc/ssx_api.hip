@@ -35,6 +35,7 @@ struct ssx_ctx {
 	uint32_t blob_words = 0;
 	std::vector<uint8_t*> d_textures;
 	double* d_accum = nullptr;  size_t accum_pixels = 0;
+	float4* d_samples = nullptr; size_t sample_slots = 0; // float4 capacity of the sample buffer
 	float* d_out = nullptr;     size_t out_pixels = 0;
 	bool have_scene = false;
 
@@ -180,7 +181,12 @@ int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
 	return SSX_OK;
 }
 
-struct LaunchPlan { SsxKernelArgs args; uint32_t blocks; size_t lds_bytes; };
+// Every launch writes its samples to [tile slot][k][64] float4 (16 B per sample) and the ordered
+// accumulate pass consumes them; the buffer bounds how many samples per pixel one launch may cover.
+constexpr size_t kSampleBufferBudget = (size_t)2 << 30; // bytes
+constexpr uint32_t kTargetUnits = 16384;               // wave work units wanted per launch (~8 per SIMD)
+
+struct LaunchPlan { SsxKernelArgs args; size_t lds_bytes; uint32_t max_spp_per_launch; };
 
 LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	LaunchPlan pl{};
@@ -192,17 +198,41 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	a.tile_first = p->tile_first; a.tile_stride = p->tile_stride;
 	a.indirect_only = p->indirect_only ? 1u : 0u;
 	a.seed = p->seed;
-	a.accum = ctx->d_accum;
-	uint32_t my_tiles = a.n_tiles > p->tile_first ? (a.n_tiles - p->tile_first + p->tile_stride - 1u) / p->tile_stride : 0u;
-	pl.blocks = (my_tiles + 3u) / 4u;
+	a.my_tiles = a.n_tiles > p->tile_first ? (a.n_tiles - p->tile_first + p->tile_stride - 1u) / p->tile_stride : 0u;
 	pl.lds_bytes = (size_t)ctx->blob_words * 4;
+	size_t per_spp = (size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u * sizeof(float4);
+	size_t cap = kSampleBufferBudget / per_spp;
+	pl.max_spp_per_launch = (uint32_t)(cap < 1 ? 1 : (cap > 65536 ? 65536 : cap));
 	return pl;
 }
 
+int ensure_samples(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t n_k) {
+	size_t need = (size_t)pl.args.my_tiles * 64u * n_k;
+	if (ctx->sample_slots < need) {
+		if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+		ctx->d_samples = nullptr; ctx->sample_slots = 0;
+		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_samples, need * sizeof(float4)));
+		ctx->sample_slots = need;
+	}
+	return SSX_OK;
+}
+
+// samples [k0,k1) of every owned pixel: megakernel, then the ordered f64 accumulation
 int launch_range(ssx_ctx* ctx, LaunchPlan& pl, uint32_t k0, uint32_t k1, hipStream_t stream) {
-	if (pl.blocks == 0) return SSX_OK;
-	pl.args.k0 = k0; pl.args.k1 = k1;
-	hipLaunchKernelGGL(ssx_render_kernel, dim3(pl.blocks), dim3(256), pl.lds_bytes, stream, pl.args);
+	SsxKernelArgs& a = pl.args;
+	if (a.my_tiles == 0 || k1 <= k0) return SSX_OK;
+	const uint32_t n_k = k1 - k0;
+	a.k0 = k0; a.k1 = k1;
+	a.samples = ctx->d_samples;
+	uint64_t g = ((uint64_t)n_k * a.my_tiles + kTargetUnits - 1) / kTargetUnits;
+	a.group_spp = (uint32_t)(g < 8 ? 8 : g);
+	if (a.group_spp > n_k) a.group_spp = n_k;
+	a.n_groups = (n_k + a.group_spp - 1) / a.group_spp;
+	const uint32_t units = a.my_tiles * a.n_groups;
+	hipLaunchKernelGGL(ssx_render_kernel, dim3((units + 3u) / 4u), dim3(256), pl.lds_bytes, stream, a);
+	SSX_HIP(ctx, hipGetLastError());
+	hipLaunchKernelGGL(ssx_accumulate_kernel, dim3((a.my_tiles * 64u + 255u) / 256u), dim3(256), 0, stream,
+	                   (const float4*)ctx->d_samples, ctx->d_accum, a.width, a.height, a.tiles_x, a.tile_first, a.tile_stride, a.my_tiles, n_k);
 	SSX_HIP(ctx, hipGetLastError());
 	return SSX_OK;
 }
@@ -226,6 +256,8 @@ void worker_main(ssx_ctx* ctx) {
 		LaunchPlan pl = make_plan(ctx, &p);
 		uint32_t chunk = p.spp_per_launch ? p.spp_per_launch : (p.spp + 31u) / 32u;
 		if (chunk == 0) chunk = 1;
+		if (chunk > pl.max_spp_per_launch) chunk = pl.max_spp_per_launch;
+		{ int r = ensure_samples(ctx, pl, chunk < p.spp ? chunk : p.spp); if (r) return r; }
 		for (uint32_t k0 = 0; k0 < p.spp && !ctx->stop_flag.load(); k0 += chunk) {
 			uint32_t k1 = (p.spp - k0 < chunk) ? p.spp : k0 + chunk;
 			int r = launch_range(ctx, pl, k0, k1, ctx->stream);
@@ -287,6 +319,7 @@ void ssx_destroy(ssx_ctx* ctx) {
 	if (ctx->d_blob) (void)hipFree(ctx->d_blob);
 	for (uint8_t* t : ctx->d_textures) (void)hipFree(t);
 	if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+	if (ctx->d_samples) (void)hipFree(ctx->d_samples);
 	if (ctx->d_out) (void)hipFree(ctx->d_out);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
@@ -334,6 +367,8 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, pixels * 4 * sizeof(double), stream));
 	LaunchPlan pl = make_plan(ctx, p);
 	uint32_t chunk = p->spp_per_launch ? p->spp_per_launch : p->spp;
+	if (chunk > pl.max_spp_per_launch) chunk = pl.max_spp_per_launch;
+	if ((rc = ensure_samples(ctx, pl, chunk < p->spp ? chunk : p->spp))) return rc;
 	for (uint32_t k0 = 0; k0 < p->spp; k0 += chunk) {
 		uint32_t k1 = (p->spp - k0 < chunk) ? p->spp : k0 + chunk;
 		if ((rc = launch_range(ctx, pl, k0, k1, stream))) return rc;

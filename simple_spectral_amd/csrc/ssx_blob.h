@@ -5,6 +5,7 @@
 // must stay <= SSX_BLOB_MAX_BYTES so several 256-lane workgroups fit in a CU's 160 KB LDS.
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 #define SSX_BLOB_MAX_BYTES (48u * 1024u)
 
@@ -59,6 +60,9 @@ struct SsxKernelArgs {
 	uint32_t tile_first, tile_stride;
 	uint32_t k0, k1;        // sample range of this launch
 	uint32_t indirect_only;
+	uint32_t my_tiles;      // tiles this device owns
+	uint32_t group_spp;     // samples per pixel in one wave's work unit
+	uint32_t n_groups;      // ceil((k1-k0)/group_spp)
 	uint64_t seed;
-	double* accum;          // double4 per pixel (sum of float(sample*0.001f))
+	float4* samples;        // [tile slot][k-k0][64] XYZA of every sample of this launch
 };

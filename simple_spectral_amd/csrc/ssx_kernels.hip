@@ -203,6 +203,15 @@ struct HitInfo {
 	float U, V, W, det_recip; // of the accepted triangle (for st interpolation)
 };
 
+// the 12 permuted floats of one quad: three 16-byte LDS reads (the table is 16-byte aligned)
+__device__ __forceinline__ void load_perm(const float* p, float out[12]) {
+	const float4* p4 = reinterpret_cast<const float4*>(p);
+	float4 a = p4[0], b = p4[1], c = p4[2];
+	out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
+	out[4] = b.x; out[5] = b.y; out[6] = b.z; out[7] = b.w;
+	out[8] = c.x; out[9] = c.y; out[10] = c.z; out[11] = c.w;
+}
+
 // One vertex in shear space: x' = (v-o)[kx] - Sx*(v-o)[kz], y' likewise, z raw = (v-o)[kz]
 struct SV { float x, y, z; };
 __device__ __forceinline__ SV shear_vertex(const float* pv, const RaySetup& rs) {
@@ -227,7 +236,8 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 	const uint32_t nq = L.hdr().n_quads;
 	uint64_t cand = 0;
 	for (uint32_t q = 0; q < nq; ++q) {
-		const float* pv = L.perm(q, rs.perm);
+		float pv[12];
+		load_perm(L.perm(q, rs.perm), pv);
 		SV a = shear_vertex(pv + 0, rs), b = shear_vertex(pv + 3, rs), c = shear_vertex(pv + 6, rs), d = shear_vertex(pv + 9, rs);
 		// tri0 = (A=a,B=b,C=c): UVW = cross(ABCy, ABCx)
 		float U0 = b.y * c.x - b.x * c.y;
@@ -251,10 +261,12 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		uint32_t bit = (uint32_t)__builtin_ctzll(cand);
 		cand &= cand - 1ull;
 		uint32_t q = bit >> 1, which = bit & 1u;
-		const float* pv = L.perm(q, rs.perm);
+		float pv[12];
+		load_perm(L.perm(q, rs.perm), pv);
 		SV A = shear_vertex(pv + 0, rs);
-		SV B = shear_vertex(pv + (which ? 6 : 3), rs);
-		SV C = shear_vertex(pv + (which ? 9 : 6), rs);
+		SV v1 = shear_vertex(pv + 3, rs), v2 = shear_vertex(pv + 6, rs), v3 = shear_vertex(pv + 9, rs);
+		SV B = which ? v2 : v1;
+		SV C = which ? v3 : v2;
 		float U = B.y * C.x - B.x * C.y;
 		float V = C.y * A.x - C.x * A.y;
 		float W = A.y * B.x - A.x * B.y;
@@ -419,185 +431,245 @@ __device__ __forceinline__ V3 reflect3(V3 vec, V3 n) { // math-helpers.hpp:40-42
 	return add(mk(-vec.x, -vec.y, -vec.z), scl(2.0f * dot3(vec, n), n));
 }
 
-// ------------------------------------------------------------------ one sample ----
+// ------------------------------------------------------------------ one path ----
 struct Frame { float direct[4]; float f_s[4]; float n_dot_l, pdf; };
 
-// renderer.cpp:104-277.  The recursion L() is unrolled into a forward pass that records, per
-// depth, direct = emission + NEE and the (n_dot_l, f_s, pdf) of the continuation, and a backward
-// fold rad_d = direct_d + ((rad_{d+1}*n_dot_l)*f_s)/pdf -- the same float operations in the same
-// order as the reference's post-order evaluation.
-__device__ __forceinline__ void render_sample(const Lds& L, const SsxKernelArgs& a, Rng& rng, uint32_t i, uint32_t j, float out[4]) {
+// Per-lane state of the path a lane is working on.  A lane always holds one (pixel, k) item of
+// its wave's work unit; when the path ends the lane writes the sample and takes the next item.
+struct Path {
+	Rng rng;
+	V3 orig, dir;
+	float lambda_0;
+	int ignore;        // quad the ray starts on (-1: camera)
+	uint32_t depth;
+	uint32_t out_index; // float4 slot in the sample buffer
+	bool hit_anything;
+};
+
+// renderer.cpp:113-138: camera ray (f64, as the reference) and hero wavelength of sample k of
+// pixel (i,j), from its own PCG32 stream (the seeding contract of include/ssx.h).
+__device__ __forceinline__ void start_sample(const Lds& L, const SsxKernelArgs& a, uint32_t i, uint32_t j, uint32_t k, Path& p) {
 	const SsxBlobHeader& h = L.hdr();
+	const uint64_t pixel = (uint64_t)j * (uint64_t)a.width + (uint64_t)i;
+	const uint64_t pa = mix64(a.seed + 0x9E3779B97F4A7C15ull * (pixel + 1ull));
+	const uint64_t b = mix64(pa + 0x9E3779B97F4A7C15ull * ((uint64_t)k + 1ull));
+	p.rng.state = b;
+	p.rng.inc = mix64(b ^ 0xDA3E39CB94B95BDBull) | 1ull;
 	// :113 -- g++ evaluates dvec2(rand_1d(rng),rand_1d(rng)) right to left: y first
-	double sub_y = rand_1d(rng);
-	double sub_x = rand_1d(rng);
+	double sub_y = rand_1d(p.rng);
+	double sub_x = rand_1d(p.rng);
 	double st_x = ((double)i + sub_x) / (double)a.width;
 	double st_y = ((double)j + sub_y) / (double)a.height;
 	double ndc_x = st_x * 2.0 - 1.0, ndc_y = st_y * 2.0 - 1.0;
 	V3 cam = mk(h.cam_pos[0], h.cam_pos[1], h.cam_pos[2]);
-	V3 dir;
-	{
-		double p[4];
+	double q[4];
 #pragma unroll
-		for (int r = 0; r < 4; ++r)
-			p[r] = (h.pv_inv[0 * 4 + r] * ndc_x + h.pv_inv[1 * 4 + r] * ndc_y) + (h.pv_inv[2 * 4 + r] * 0.0 + h.pv_inv[3 * 4 + r] * 1.0);
-		double w = p[3];
-		double px = p[0] / w, py = p[1] / w, pz = p[2] / w;
-		double dx = px - (double)cam.x, dy = py - (double)cam.y, dz = pz - (double)cam.z;
-		double inv = 1.0 / __builtin_sqrt((dx * dx + dy * dy) + dz * dz);
-		dir = mk((float)(dx * inv), (float)(dy * inv), (float)(dz * inv));
+	for (int r = 0; r < 4; ++r)
+		q[r] = (h.pv_inv[0 * 4 + r] * ndc_x + h.pv_inv[1 * 4 + r] * ndc_y) + (h.pv_inv[2 * 4 + r] * 0.0 + h.pv_inv[3 * 4 + r] * 1.0);
+	double w = q[3];
+	double px = q[0] / w, py = q[1] / w, pz = q[2] / w;
+	double dx = px - (double)cam.x, dy = py - (double)cam.y, dz = pz - (double)cam.z;
+	double inv = 1.0 / __builtin_sqrt((dx * dx + dy * dy) + dz * dz);
+	p.dir = mk((float)(dx * inv), (float)(dy * inv), (float)(dz * inv));
+	p.orig = cam;
+	p.lambda_0 = h.lambda_min + rand_1f(p.rng) * h.lambda_step; // :138
+	p.ignore = -1;
+	p.depth = 0;
+	p.hit_anything = false;
+}
+
+// One level of the recursion L() (renderer.cpp:147-255) for the lane's current ray: closest hit,
+// emission (camera ray only), next-event estimation with its shadow ray, BSDF sample.  Returns
+// true when the path continues (a Frame was pushed and p holds the next ray); otherwise `rad`
+// holds the radiance of this deepest level.
+__device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, Path& p, Frame* stack, float rad[4]) {
+	const SsxBlobHeader& h = L.hdr();
+	HitInfo hit;
+	trace(L, p.orig, p.dir, p.ignore, hit);
+	if (hit.tri < 0) { rad[0] = rad[1] = rad[2] = rad[3] = 0.0f; return false; }
+	p.hit_anything = true;
+	const uint32_t hq = (uint32_t)hit.tri >> 1, which = (uint32_t)hit.tri & 1u;
+	const SsxBlobQuad& Q = L.quad(hq);
+	const SsxBlobMaterial& M = L.material(Q.material);
+	V3 N = mk(Q.normal[which][0], Q.normal[which][1], Q.normal[which][2]);
+
+	float direct[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+	// emission: only the camera ray has last_was_delta (:169-172, :247)
+	if (p.depth == 0u && !a.indirect_only) {
+		Hero em = spectrum_hero(L, M.emission_spec, p.lambda_0, h.lambda_step);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) direct[k] += em.v[k];
 	}
-	float lambda_0 = h.lambda_min + rand_1f(rng) * h.lambda_step; // :138
-
-	Frame stack[SSX_MAX_DEPTH_ - 1u];
-	float rad[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-	bool hit_anything = false;
-	V3 orig = cam;
-	int ignore = -1;
-	uint32_t depth = 0;
-	for (;;) {
-		HitInfo hit;
-		trace(L, orig, dir, ignore, hit);
-		if (hit.tri < 0) { rad[0] = rad[1] = rad[2] = rad[3] = 0.0f; break; }
-		hit_anything = true;
-		const uint32_t hq = (uint32_t)hit.tri >> 1, which = (uint32_t)hit.tri & 1u;
-		const SsxBlobQuad& Q = L.quad(hq);
-		const SsxBlobMaterial& M = L.material(Q.material);
-		V3 N = mk(Q.normal[which][0], Q.normal[which][1], Q.normal[which][2]);
-
-		float direct[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-		// emission: only the camera ray has last_was_delta (:169-172, :247)
-		if (depth == 0u && !a.indirect_only) {
-			Hero em = spectrum_hero(L, M.emission_spec, lambda_0, h.lambda_step);
+	// depth+1 < MAX_DEPTH always holds here: a ray at depth MAX_DEPTH-1 is never started (below)
+	V3 hit_pos = add(p.orig, scl(hit.dist, p.dir)); // Ray::at
+	// hitrec.st (geometry.cpp:91-95) is read only by textured albedo
+	float st_x = 0.0f, st_y = 0.0f;
+	if (M.albedo_mode != 0u) {
+		float bx = hit.U * hit.det_recip, by = hit.V * hit.det_recip, bz = hit.W * hit.det_recip;
+		const float* s0 = Q.st[0];
+		const float* s1 = which ? Q.st[2] : Q.st[1];
+		const float* s2 = which ? Q.st[3] : Q.st[2];
+		st_x = (bx * s0[0] + by * s1[0]) + bz * s2[0];
+		st_y = (bx * s0[1] + by * s1[1]) + bz * s2[1];
+	}
+	// albedo(lambda) is shared by evaluate_bsdf and interact_bsdf (material.cpp:120-143)
+	Hero alb = material_albedo(L, M, st_x, st_y, p.lambda_0);
+	float f_lamb[4];
 #pragma unroll
-			for (int k = 0; k < 4; ++k) direct[k] += em.v[k];
-		}
-		// depth+1 < MAX_DEPTH always holds here: the loop never starts depth MAX_DEPTH-1 (see below)
-		V3 hit_pos = add(orig, scl(hit.dist, dir)); // Ray::at
-		// hitrec.st (geometry.cpp:91-95) is read only by textured albedo
-		float st_x = 0.0f, st_y = 0.0f;
-		if (M.albedo_mode != 0u) {
-			float bx = hit.U * hit.det_recip, by = hit.V * hit.det_recip, bz = hit.W * hit.det_recip;
-			const float* s0 = Q.st[0];
-			const float* s1 = which ? Q.st[2] : Q.st[1];
-			const float* s2 = which ? Q.st[3] : Q.st[2];
-			st_x = (bx * s0[0] + by * s1[0]) + bz * s2[0];
-			st_y = (bx * s0[1] + by * s1[1]) + bz * s2[1];
-		}
-		// albedo(lambda) is shared by evaluate_bsdf and interact_bsdf (material.cpp:120-143)
-		Hero alb = material_albedo(L, M, st_x, st_y, lambda_0);
-		float f_lamb[4];
-#pragma unroll
-		for (int k = 0; k < 4; ++k) f_lamb[k] = alb.v[k] / SSX_PI_F;
+	for (int k = 0; k < 4; ++k) f_lamb[k] = alb.v[k] / SSX_PI_F;
 
-		// direct lighting (:182-219)
-		if (!a.indirect_only || depth > 0u) {
-			V3 sdir; uint32_t light; float spdf;
-			sample_light(L, rng, hit_pos, sdir, light, spdf);
-			float n_dot_l = dot3(sdir, N);
-			if (n_dot_l > 0.0f) {
-				HitInfo sh;
-				trace(L, hit_pos, sdir, (int)hq, sh);
-				if (sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == light) {
-					const SsxBlobMaterial& LM = L.material(L.quad(light).material);
-					Hero emitted = spectrum_hero(L, LM.emission_spec, lambda_0, h.lambda_step);
+	// direct lighting (:182-219)
+	if (!a.indirect_only || p.depth > 0u) {
+		V3 sdir; uint32_t light; float spdf;
+		sample_light(L, p.rng, hit_pos, sdir, light, spdf);
+		float n_dot_l = dot3(sdir, N);
+		if (n_dot_l > 0.0f) {
+			HitInfo sh;
+			trace(L, hit_pos, sdir, (int)hq, sh);
+			if (sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == light) {
+				const SsxBlobMaterial& LM = L.material(L.quad(light).material);
+				Hero emitted = spectrum_hero(L, LM.emission_spec, p.lambda_0, h.lambda_step);
 #pragma unroll
-					for (int k = 0; k < 4; ++k) {
-						float fs = (M.kind == 0u) ? f_lamb[k] : 0.0f; // Mirror::evaluate_bsdf -> 0
-						direct[k] += ((emitted.v[k] * n_dot_l) * fs) / spdf;
-					}
+				for (int k = 0; k < 4; ++k) {
+					float fs = (M.kind == 0u) ? f_lamb[k] : 0.0f; // Mirror::evaluate_bsdf -> 0
+					direct[k] += ((emitted.v[k] * n_dot_l) * fs) / spdf;
 				}
 			}
 		}
+	}
 
-		// indirect lighting (:222-250)
-		V3 w_i; float pdf_w_i; float f_s[4];
-		if (M.kind == 0u) {
-			w_i = rand_coshemi(rng, pdf_w_i);
-			w_i = get_rotated_to(w_i, N);
+	// indirect lighting (:222-250)
+	V3 w_i; float pdf_w_i; float f_s[4];
+	if (M.kind == 0u) {
+		w_i = rand_coshemi(p.rng, pdf_w_i);
+		w_i = get_rotated_to(w_i, N);
 #pragma unroll
-			for (int k = 0; k < 4; ++k) f_s[k] = f_lamb[k];
-		} else {
-			w_i = reflect3(mk(-dir.x, -dir.y, -dir.z), N);
-			pdf_w_i = __builtin_inff();
+		for (int k = 0; k < 4; ++k) f_s[k] = f_lamb[k];
+	} else {
+		w_i = reflect3(mk(-p.dir.x, -p.dir.y, -p.dir.z), N);
+		pdf_w_i = __builtin_inff();
 #pragma unroll
-			for (int k = 0; k < 4; ++k) f_s[k] = alb.v[k];
-		}
-		bool cont = false;
-		float n_dot_l = 0.0f;
-		float dotfs = (f_s[0] * f_s[0] + f_s[1] * f_s[1]) + (f_s[2] * f_s[2] + f_s[3] * f_s[3]);
-		if (dotfs > 0.0f) {
-			if (__builtin_isfinite(pdf_w_i)) n_dot_l = dot3(w_i, N);
-			else { n_dot_l = 1.0f; pdf_w_i = 1.0f; }
-			cont = n_dot_l > 0.0f;
-		}
-		// A ray at depth MAX_DEPTH-1 can add nothing (no emission: last_was_delta is false; no
-		// further bounce: depth+1 == MAX_DEPTH) and hit_anything is already set, so it is not traced:
-		// its L() is 0 unless it hits, and (0*n)*f/p == 0 either way.
-		if (!cont || depth + 2u >= SSX_MAX_DEPTH_) {
-#pragma unroll
-			for (int k = 0; k < 4; ++k) rad[k] = direct[k];
-			if (cont) { // deepest level reached: child radiance is exactly 0 -> direct + ((0*n)*f)/p
-#pragma unroll
-				for (int k = 0; k < 4; ++k) rad[k] = direct[k] + ((0.0f * n_dot_l) * f_s[k]) / pdf_w_i;
-			}
-			break;
-		}
-		Frame& F = stack[depth];
-#pragma unroll
-		for (int k = 0; k < 4; ++k) { F.direct[k] = direct[k]; F.f_s[k] = f_s[k]; }
-		F.n_dot_l = n_dot_l; F.pdf = pdf_w_i;
-		orig = hit_pos; dir = w_i; ignore = (int)hq;
-		++depth;
+		for (int k = 0; k < 4; ++k) f_s[k] = alb.v[k];
 	}
-	// backward fold
-	while (depth > 0u) {
-		--depth;
-		const Frame& F = stack[depth];
-#pragma unroll
-		for (int k = 0; k < 4; ++k) rad[k] = F.direct[k] + ((rad[k] * F.n_dot_l) * F.f_s[k]) / F.pdf;
+	bool cont = false;
+	float n_dot_l = 0.0f;
+	float dotfs = (f_s[0] * f_s[0] + f_s[1] * f_s[1]) + (f_s[2] * f_s[2] + f_s[3] * f_s[3]);
+	if (dotfs > 0.0f) {
+		if (__builtin_isfinite(pdf_w_i)) n_dot_l = dot3(w_i, N);
+		else { n_dot_l = 1.0f; pdf_w_i = 1.0f; }
+		cont = n_dot_l > 0.0f;
 	}
-	Hero flux; // FLAT_FIELD_CORRECTION: flux = radiance (:262-263)
+	// A ray at depth MAX_DEPTH-1 can add nothing (no emission: last_was_delta is false; no further
+	// bounce: depth+1 == MAX_DEPTH) and hit_anything is already set, so it is not traced: its L()
+	// is exactly 0 and the parent adds ((0*n)*f)/p.
+	if (!cont || p.depth + 2u >= SSX_MAX_DEPTH_) {
 #pragma unroll
-	for (int k = 0; k < 4; ++k) flux.v[k] = rad[k];
-	float xyz[3];
-	flux_to_xyz(L, flux, lambda_0, xyz);
-	out[0] = xyz[0]; out[1] = xyz[1]; out[2] = xyz[2];
-	out[3] = hit_anything ? 1.0f : 0.0f;
+		for (int k = 0; k < 4; ++k) rad[k] = direct[k];
+		if (cont) {
+#pragma unroll
+			for (int k = 0; k < 4; ++k) rad[k] = direct[k] + ((0.0f * n_dot_l) * f_s[k]) / pdf_w_i;
+		}
+		return false;
+	}
+	Frame& F = stack[p.depth];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) { F.direct[k] = direct[k]; F.f_s[k] = f_s[k]; }
+	F.n_dot_l = n_dot_l; F.pdf = pdf_w_i;
+	p.orig = hit_pos; p.dir = w_i; p.ignore = (int)hq;
+	++p.depth;
+	return true;
 }
 
 } // namespace
 
-// One wave64 per 8x8 tile (Framebuffer::Tile, renderer.cpp:396-409), one lane per pixel; four
-// tiles per 256-lane workgroup share one LDS copy of the scene blob.
+// The megakernel.  Work unit of one wave64 = one 8x8 tile (Framebuffer::Tile, renderer.cpp:
+// 396-409) x a group of consecutive samples; its items (pixel of the tile, k) are enumerated
+// k-major and handed to lanes as they fall idle: every iteration the idle lanes ballot, take
+// consecutive item numbers by prefix count, and start those samples, so all 64 lanes trace a ray
+// in (almost) every iteration although path lengths differ (26 % of Cornell paths end after one
+// interaction, 24 % run all nine).  Each finished path's XYZA goes to the sample buffer at
+// [tile slot][k][pixel in tile]; ssx_accumulate_kernel then sums every pixel's samples in
+// ascending k in f64, which reproduces the reference's accumulation order exactly
+// (renderer.cpp:292-296) no matter which lane produced which sample.
 extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArgs a) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_blob[];
 	for (uint32_t w = threadIdx.x; w < a.blob_words; w += blockDim.x) lds_blob[w] = a.blob[w];
 	__syncthreads();
 	Lds L; L.w = lds_blob;
 
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-	const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wave;   // index among this device's tiles
-	const uint64_t tile64 = (uint64_t)a.tile_first + (uint64_t)slot * (uint64_t)a.tile_stride;
-	if (tile64 >= (uint64_t)a.n_tiles) return;
-	const uint32_t tile = (uint32_t)tile64;
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
+	if (unit >= a.my_tiles * a.n_groups) return;
+	const uint32_t slot = unit % a.my_tiles, grp = unit / a.my_tiles;
+	const uint32_t tile = a.tile_first + slot * a.tile_stride;
 	const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-	const uint32_t i = tx * 8u + (lane & 7u), j = ty * 8u + (lane >> 3);
-	if (i >= a.width || j >= a.height) return;
-	const uint64_t pixel = (uint64_t)j * (uint64_t)a.width + (uint64_t)i;
+	const uint32_t tw = min(8u, a.width - tx * 8u), th = min(8u, a.height - ty * 8u);
+	const uint32_t npx = tw * th;
+	const uint32_t ka = a.k0 + grp * a.group_spp;
+	const uint32_t kb = min(ka + a.group_spp, a.k1);
+	const uint32_t n_items = npx * (kb - ka);
+	const uint32_t n_k = a.k1 - a.k0;
 
-	double* acc_p = a.accum + 4u * pixel;
-	double acc[4] = { acc_p[0], acc_p[1], acc_p[2], acc_p[3] };
-	const uint64_t pa = mix64(a.seed + 0x9E3779B97F4A7C15ull * (pixel + 1ull));
-	for (uint32_t k = a.k0; k < a.k1; ++k) {
-		Rng rng;
-		uint64_t b = mix64(pa + 0x9E3779B97F4A7C15ull * ((uint64_t)k + 1ull));
-		rng.state = b;
-		rng.inc = mix64(b ^ 0xDA3E39CB94B95BDBull) | 1ull;
-		float s[4];
-		render_sample(L, a, rng, i, j, s);
+	Frame stack[SSX_MAX_DEPTH_ - 1u];
+	Path p;
+	bool active = false;
+	uint32_t next_item = 0; // wave-uniform
+	for (;;) {
+		// hand out items to idle lanes
+		const uint64_t idle = __ballot(!active);
+		if (!active) {
+			const uint32_t item = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+			if (item < n_items) {
+				const uint32_t r = item % npx, kk = ka + item / npx;
+				const uint32_t lx = r % tw, ly = r / tw;
+				start_sample(L, a, tx * 8u + lx, ty * 8u + ly, kk, p);
+				p.out_index = (slot * n_k + (kk - a.k0)) * 64u + ly * 8u + lx;
+				active = true;
+			}
+		}
+		next_item = min(n_items, next_item + (uint32_t)__popcll(idle));
+		if (!__any(active)) break;
+		if (active) {
+			float rad[4];
+			if (!path_step(L, a, p, stack, rad)) {
+				// backward fold of the recursion (post-order, renderer.cpp:247), then flux -> XYZ
+				while (p.depth > 0u) {
+					--p.depth;
+					const Frame& F = stack[p.depth];
 #pragma unroll
-		for (int c = 0; c < 4; ++c) acc[c] += (double)(s[c] * 0.001f); // renderer.cpp:294
+					for (int k = 0; k < 4; ++k) rad[k] = F.direct[k] + ((rad[k] * F.n_dot_l) * F.f_s[k]) / F.pdf;
+				}
+				Hero flux; // FLAT_FIELD_CORRECTION: flux = radiance (:262-263)
+#pragma unroll
+				for (int k = 0; k < 4; ++k) flux.v[k] = rad[k];
+				float xyz[3];
+				flux_to_xyz(L, flux, p.lambda_0, xyz);
+				a.samples[p.out_index] = make_float4(xyz[0], xyz[1], xyz[2], p.hit_anything ? 1.0f : 0.0f);
+				active = false;
+			}
+		}
+	}
+}
+
+// renderer.cpp:292-295: avg += sample*0.001f (float multiply, widened), in ascending k.
+// One thread per (tile slot, pixel of tile); consecutive threads read consecutive float4.
+extern "C" __global__ void __launch_bounds__(256) ssx_accumulate_kernel(const float4* samples, double* accum, uint32_t width, uint32_t height,
+                                                    uint32_t tiles_x, uint32_t tile_first, uint32_t tile_stride, uint32_t my_tiles, uint32_t n_k) {
+	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t slot = gid >> 6, lane = gid & 63u;
+	if (slot >= my_tiles) return;
+	const uint32_t tile = tile_first + slot * tile_stride;
+	const uint32_t i = (tile % tiles_x) * 8u + (lane & 7u), j = (tile / tiles_x) * 8u + (lane >> 3);
+	if (i >= width || j >= height) return;
+	double* acc_p = accum + 4u * ((size_t)j * width + i);
+	double acc[4] = { acc_p[0], acc_p[1], acc_p[2], acc_p[3] };
+	const float4* s = samples + (size_t)slot * n_k * 64u + lane;
+	for (uint32_t k = 0; k < n_k; ++k) {
+		const float4 v = s[(size_t)k * 64u];
+		acc[0] += (double)(v.x * 0.001f);
+		acc[1] += (double)(v.y * 0.001f);
+		acc[2] += (double)(v.z * 0.001f);
+		acc[3] += (double)(v.w * 0.001f);
 	}
 	acc_p[0] = acc[0]; acc_p[1] = acc[1]; acc_p[2] = acc[2]; acc_p[3] = acc[3];
 }
