@@ -35,7 +35,7 @@ struct ssx_ctx {
 	uint32_t blob_words = 0;
 	std::vector<uint8_t*> d_textures;
 	double* d_accum = nullptr;  size_t accum_pixels = 0;
-	float4* d_samples = nullptr; size_t sample_slots = 0; // float4 capacity of the sample buffer
+	SsxSampleRecord* d_samples = nullptr; size_t sample_slots = 0; // record capacity of the sample buffer
 	float* d_out = nullptr;     size_t out_pixels = 0;
 	bool have_scene = false;
 
@@ -137,6 +137,10 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 		const ssx_material& m = s->materials[i];
 		bm[i].kind = m.kind; bm[i].albedo_mode = m.albedo_mode; bm[i].albedo_spec = m.albedo_spectrum;
 		bm[i].albedo_tex = m.albedo_texture; bm[i].emission_spec = m.emission_spectrum;
+		// any nonzero emission sample?  (all-zero tables evaluate to exactly +0 at every wavelength)
+		const ssx_spectrum& es = s->spectra[m.emission_spectrum];
+		bm[i].is_emissive = 0;
+		for (uint32_t k = 0; k < es.n; ++k) if (s->samples[es.offset + k] != 0.0f) bm[i].is_emissive = 1;
 	}
 	SsxBlobSpectrum* bs = reinterpret_cast<SsxBlobSpectrum*>(blob.data() + h.off_spectra);
 	for (uint32_t i = 0; i < s->n_spectra; ++i) {
@@ -183,7 +187,7 @@ int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
 
 // Every launch writes its samples to [tile slot][k][64] float4 (16 B per sample) and the ordered
 // accumulate pass consumes them; the buffer bounds how many samples per pixel one launch may cover.
-constexpr size_t kSampleBufferBudget = (size_t)2 << 30; // bytes
+constexpr size_t kSampleBufferBudget = (size_t)8 << 30; // bytes (32 B per sample in flight; MI355X has 288 GB)
 constexpr uint32_t kTargetUnits = 16384;               // wave work units wanted per launch (~8 per SIMD)
 
 struct LaunchPlan { SsxKernelArgs args; size_t lds_bytes; uint32_t max_spp_per_launch; };
@@ -200,7 +204,7 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	a.seed = p->seed;
 	a.my_tiles = a.n_tiles > p->tile_first ? (a.n_tiles - p->tile_first + p->tile_stride - 1u) / p->tile_stride : 0u;
 	pl.lds_bytes = (size_t)ctx->blob_words * 4;
-	size_t per_spp = (size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u * sizeof(float4);
+	size_t per_spp = (size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u * sizeof(SsxSampleRecord);
 	size_t cap = kSampleBufferBudget / per_spp;
 	pl.max_spp_per_launch = (uint32_t)(cap < 1 ? 1 : (cap > 65536 ? 65536 : cap));
 	return pl;
@@ -211,13 +215,13 @@ int ensure_samples(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t n_k) {
 	if (ctx->sample_slots < need) {
 		if (ctx->d_samples) (void)hipFree(ctx->d_samples);
 		ctx->d_samples = nullptr; ctx->sample_slots = 0;
-		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_samples, need * sizeof(float4)));
+		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_samples, need * sizeof(SsxSampleRecord)));
 		ctx->sample_slots = need;
 	}
 	return SSX_OK;
 }
 
-// samples [k0,k1) of every owned pixel: megakernel, then the ordered f64 accumulation
+// samples [k0,k1) of every owned pixel: generate -> path megakernel -> ordered f64 accumulation
 int launch_range(ssx_ctx* ctx, LaunchPlan& pl, uint32_t k0, uint32_t k1, hipStream_t stream) {
 	SsxKernelArgs& a = pl.args;
 	if (a.my_tiles == 0 || k1 <= k0) return SSX_OK;
@@ -229,10 +233,12 @@ int launch_range(ssx_ctx* ctx, LaunchPlan& pl, uint32_t k0, uint32_t k1, hipStre
 	if (a.group_spp > n_k) a.group_spp = n_k;
 	a.n_groups = (n_k + a.group_spp - 1) / a.group_spp;
 	const uint32_t units = a.my_tiles * a.n_groups;
+	const uint64_t n_rec = (uint64_t)a.my_tiles * n_k * 64u;
+	hipLaunchKernelGGL(ssx_generate_kernel, dim3((uint32_t)((n_rec + 255u) / 256u)), dim3(256), 0, stream, a);
+	SSX_HIP(ctx, hipGetLastError());
 	hipLaunchKernelGGL(ssx_render_kernel, dim3((units + 3u) / 4u), dim3(256), pl.lds_bytes, stream, a);
 	SSX_HIP(ctx, hipGetLastError());
-	hipLaunchKernelGGL(ssx_accumulate_kernel, dim3((a.my_tiles * 64u + 255u) / 256u), dim3(256), 0, stream,
-	                   (const float4*)ctx->d_samples, ctx->d_accum, a.width, a.height, a.tiles_x, a.tile_first, a.tile_stride, a.my_tiles, n_k);
+	hipLaunchKernelGGL(ssx_accumulate_kernel, dim3((a.my_tiles * 64u + 255u) / 256u), dim3(256), pl.lds_bytes, stream, a, ctx->d_accum);
 	SSX_HIP(ctx, hipGetLastError());
 	return SSX_OK;
 }

@@ -52,6 +52,12 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 	uint32_t ptr_lo, ptr_hi, w, h;
 };
 
+// One sample in flight, 32 bytes, layout [tile slot][k-k0][pixel in tile].
+//   after ssx_generate_kernel: a = {camera ray dir.xyz, lambda_0}, b = PCG32 {state, inc}
+//   after ssx_render_kernel  : a = radiance hero sample, b = {lambda_0 bits, hit_anything, 0, 0}
+struct SsxSampleRecord { float4 a; uint4 b; };
+static_assert(sizeof(SsxSampleRecord) == 32, "layout");
+
 struct SsxKernelArgs {
 	const uint32_t* blob;   // device copy of the scene blob
 	uint32_t blob_words;
@@ -64,5 +70,5 @@ struct SsxKernelArgs {
 	uint32_t group_spp;     // samples per pixel in one wave's work unit
 	uint32_t n_groups;      // ceil((k1-k0)/group_spp)
 	uint64_t seed;
-	float4* samples;        // [tile slot][k-k0][64] XYZA of every sample of this launch
+	SsxSampleRecord* samples; // [tile slot][k-k0][64] records of this launch
 };

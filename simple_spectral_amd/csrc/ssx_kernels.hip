@@ -23,6 +23,15 @@
 #include "../../include/ssx_fmath.h"
 #include "ssx_blob.h"
 
+// Timing-only ablations (tools/ablate.py builds separate libraries with these; results are wrong
+// by construction and such builds are never loaded by the package or the tests).
+#ifdef SSX_ABL_TRANS
+#define ssx_sinf(x) ((x) * 0.5f)
+#define ssx_cosf(x) (1.0f - (x) * 0.25f)
+#define ssx_acosf(x) (1.5707964f - (x))
+#define ssx_sincosf(x, s, c) (*(s) = (x) * 0.5f, *(c) = 1.0f - (x) * 0.25f)
+#endif
+
 #define SSX_EPS 0.001f          // stdafx.hpp:58
 #define SSX_MAX_DEPTH_ 10u       // stdafx.hpp:47
 #define SSX_PI_F 3.14159265358979323846f
@@ -435,47 +444,44 @@ __device__ __forceinline__ V3 reflect3(V3 vec, V3 n) { // math-helpers.hpp:40-42
 struct Frame { float direct[4]; float f_s[4]; float n_dot_l, pdf; };
 
 // Per-lane state of the path a lane is working on.  A lane always holds one (pixel, k) item of
-// its wave's work unit; when the path ends the lane writes the sample and takes the next item.
+// its wave's work unit; when the path ends the lane writes the result and takes the next item.
 struct Path {
 	Rng rng;
 	V3 orig, dir;
 	float lambda_0;
 	int ignore;        // quad the ray starts on (-1: camera)
 	uint32_t depth;
-	uint32_t out_index; // float4 slot in the sample buffer
+	uint32_t rec_index; // record of this sample in the sample buffer
 	bool hit_anything;
 };
 
 // renderer.cpp:113-138: camera ray (f64, as the reference) and hero wavelength of sample k of
-// pixel (i,j), from its own PCG32 stream (the seeding contract of include/ssx.h).
-__device__ __forceinline__ void start_sample(const Lds& L, const SsxKernelArgs& a, uint32_t i, uint32_t j, uint32_t k, Path& p) {
-	const SsxBlobHeader& h = L.hdr();
+// pixel (i,j), from its own PCG32 stream (the seeding contract of include/ssx.h).  Runs in
+// ssx_generate_kernel with every lane busy; the record carries the stream on to the path kernel.
+__device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const SsxKernelArgs& a, uint32_t i, uint32_t j, uint32_t k, SsxSampleRecord& rec) {
 	const uint64_t pixel = (uint64_t)j * (uint64_t)a.width + (uint64_t)i;
 	const uint64_t pa = mix64(a.seed + 0x9E3779B97F4A7C15ull * (pixel + 1ull));
 	const uint64_t b = mix64(pa + 0x9E3779B97F4A7C15ull * ((uint64_t)k + 1ull));
-	p.rng.state = b;
-	p.rng.inc = mix64(b ^ 0xDA3E39CB94B95BDBull) | 1ull;
+	Rng rng;
+	rng.state = b;
+	rng.inc = mix64(b ^ 0xDA3E39CB94B95BDBull) | 1ull;
 	// :113 -- g++ evaluates dvec2(rand_1d(rng),rand_1d(rng)) right to left: y first
-	double sub_y = rand_1d(p.rng);
-	double sub_x = rand_1d(p.rng);
+	double sub_y = rand_1d(rng);
+	double sub_x = rand_1d(rng);
 	double st_x = ((double)i + sub_x) / (double)a.width;
 	double st_y = ((double)j + sub_y) / (double)a.height;
 	double ndc_x = st_x * 2.0 - 1.0, ndc_y = st_y * 2.0 - 1.0;
-	V3 cam = mk(h.cam_pos[0], h.cam_pos[1], h.cam_pos[2]);
 	double q[4];
 #pragma unroll
 	for (int r = 0; r < 4; ++r)
 		q[r] = (h.pv_inv[0 * 4 + r] * ndc_x + h.pv_inv[1 * 4 + r] * ndc_y) + (h.pv_inv[2 * 4 + r] * 0.0 + h.pv_inv[3 * 4 + r] * 1.0);
 	double w = q[3];
 	double px = q[0] / w, py = q[1] / w, pz = q[2] / w;
-	double dx = px - (double)cam.x, dy = py - (double)cam.y, dz = pz - (double)cam.z;
+	double dx = px - (double)h.cam_pos[0], dy = py - (double)h.cam_pos[1], dz = pz - (double)h.cam_pos[2];
 	double inv = 1.0 / __builtin_sqrt((dx * dx + dy * dy) + dz * dz);
-	p.dir = mk((float)(dx * inv), (float)(dy * inv), (float)(dz * inv));
-	p.orig = cam;
-	p.lambda_0 = h.lambda_min + rand_1f(p.rng) * h.lambda_step; // :138
-	p.ignore = -1;
-	p.depth = 0;
-	p.hit_anything = false;
+	rec.a = make_float4((float)(dx * inv), (float)(dy * inv), (float)(dz * inv),
+	                    h.lambda_min + rand_1f(rng) * h.lambda_step); // :138
+	rec.b = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), (uint32_t)rng.inc, (uint32_t)(rng.inc >> 32));
 }
 
 // One level of the recursion L() (renderer.cpp:147-255) for the lane's current ray: closest hit,
@@ -494,8 +500,9 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 	V3 N = mk(Q.normal[which][0], Q.normal[which][1], Q.normal[which][2]);
 
 	float direct[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-	// emission: only the camera ray has last_was_delta (:169-172, :247)
-	if (p.depth == 0u && !a.indirect_only) {
+	// emission: only the camera ray has last_was_delta (:169-172, :247).  A material whose emission
+	// table is all zeros (MaterialBase's default) would add exactly +0, so its lookup is skipped.
+	if (p.depth == 0u && !a.indirect_only && M.is_emissive != 0u) {
 		Hero em = spectrum_hero(L, M.emission_spec, p.lambda_0, h.lambda_step);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) direct[k] += em.v[k];
@@ -519,13 +526,18 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 	for (int k = 0; k < 4; ++k) f_lamb[k] = alb.v[k] / SSX_PI_F;
 
 	// direct lighting (:182-219)
+#ifndef SSX_ABL_NONEE
 	if (!a.indirect_only || p.depth > 0u) {
 		V3 sdir; uint32_t light; float spdf;
 		sample_light(L, p.rng, hit_pos, sdir, light, spdf);
 		float n_dot_l = dot3(sdir, N);
 		if (n_dot_l > 0.0f) {
 			HitInfo sh;
+#ifdef SSX_ABL_NOSHADOW
+			sh.tri = (int)(light * 2u);
+#else
 			trace(L, hit_pos, sdir, (int)hq, sh);
+#endif
 			if (sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == light) {
 				const SsxBlobMaterial& LM = L.material(L.quad(light).material);
 				Hero emitted = spectrum_hero(L, LM.emission_spec, p.lambda_0, h.lambda_step);
@@ -537,6 +549,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 			}
 		}
 	}
+#endif
 
 	// indirect lighting (:222-250)
 	V3 w_i; float pdf_w_i; float f_s[4];
@@ -582,15 +595,33 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 
 } // namespace
 
-// The megakernel.  Work unit of one wave64 = one 8x8 tile (Framebuffer::Tile, renderer.cpp:
-// 396-409) x a group of consecutive samples; its items (pixel of the tile, k) are enumerated
-// k-major and handed to lanes as they fall idle: every iteration the idle lanes ballot, take
-// consecutive item numbers by prefix count, and start those samples, so all 64 lanes trace a ray
-// in (almost) every iteration although path lengths differ (26 % of Cornell paths end after one
-// interaction, 24 % run all nine).  Each finished path's XYZA goes to the sample buffer at
-// [tile slot][k][pixel in tile]; ssx_accumulate_kernel then sums every pixel's samples in
-// ascending k in f64, which reproduces the reference's accumulation order exactly
-// (renderer.cpp:292-296) no matter which lane produced which sample.
+// Stage 1 of 3: one lane per sample.  Camera ray + hero wavelength (f64 camera maths of
+// renderer.cpp:113-138) for every (owned pixel, k in [k0,k1)) into the sample buffer,
+// layout [tile slot][k-k0][pixel in tile] so a wave writes 64 consecutive 32-byte records.
+extern "C" __global__ void __launch_bounds__(256) ssx_generate_kernel(SsxKernelArgs a) {
+	const SsxBlobHeader& h = *reinterpret_cast<const SsxBlobHeader*>(a.blob); // uniform: scalar loads
+	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t n_k = a.k1 - a.k0;
+	const uint64_t rec_index = gid;
+	const uint32_t lane = (uint32_t)(gid & 63u);
+	const uint64_t sk = gid >> 6;
+	const uint32_t slot = (uint32_t)(sk / n_k), kk = a.k0 + (uint32_t)(sk % n_k);
+	if (slot >= a.my_tiles) return;
+	const uint32_t tile = a.tile_first + slot * a.tile_stride;
+	const uint32_t i = (tile % a.tiles_x) * 8u + (lane & 7u), j = (tile / a.tiles_x) * 8u + (lane >> 3);
+	if (i >= a.width || j >= a.height) return;
+	SsxSampleRecord rec;
+	generate_sample(h, a, i, j, kk, rec);
+	a.samples[rec_index] = rec;
+}
+
+// Stage 2 of 3: the path megakernel.  Work unit of one wave64 = one 8x8 tile (Framebuffer::Tile,
+// renderer.cpp:396-409) x a group of consecutive samples; its items (pixel of the tile, k) are
+// enumerated k-major and handed to lanes as they fall idle: every iteration the idle lanes
+// ballot, take consecutive item numbers by prefix count, and load those samples' camera rays, so
+// all 64 lanes trace a ray in (almost) every iteration although path lengths differ (26 % of
+// Cornell paths end after one interaction, 24 % run all nine).  A finished path overwrites its
+// record with {radiance[4], lambda_0 (sign bit clear iff the path hit anything... see below)}.
 extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArgs a) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_blob[];
 	for (uint32_t w = threadIdx.x; w < a.blob_words; w += blockDim.x) lds_blob[w] = a.blob[w];
@@ -609,6 +640,9 @@ extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArg
 	const uint32_t kb = min(ka + a.group_spp, a.k1);
 	const uint32_t n_items = npx * (kb - ka);
 	const uint32_t n_k = a.k1 - a.k0;
+	const uint32_t rec_base = (slot * n_k + (ka - a.k0)) * 64u;
+	const SsxBlobHeader& h = L.hdr();
+	const V3 cam = mk(h.cam_pos[0], h.cam_pos[1], h.cam_pos[2]);
 
 	Frame stack[SSX_MAX_DEPTH_ - 1u];
 	Path p;
@@ -620,10 +654,19 @@ extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArg
 		if (!active) {
 			const uint32_t item = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
 			if (item < n_items) {
-				const uint32_t r = item % npx, kk = ka + item / npx;
-				const uint32_t lx = r % tw, ly = r / tw;
-				start_sample(L, a, tx * 8u + lx, ty * 8u + ly, kk, p);
-				p.out_index = (slot * n_k + (kk - a.k0)) * 64u + ly * 8u + lx;
+				uint32_t in_tile, kq;
+				if (npx == 64u) { in_tile = item & 63u; kq = item >> 6; }              // full tile (wave-uniform branch)
+				else { const uint32_t r = item % npx; kq = item / npx; in_tile = (r / tw) * 8u + r % tw; }
+				p.rec_index = rec_base + kq * 64u + in_tile;
+				const SsxSampleRecord rec = a.samples[p.rec_index];
+				p.dir = mk(rec.a.x, rec.a.y, rec.a.z);
+				p.lambda_0 = rec.a.w;
+				p.rng.state = ((uint64_t)rec.b.y << 32) | rec.b.x;
+				p.rng.inc = ((uint64_t)rec.b.w << 32) | rec.b.z;
+				p.orig = cam;
+				p.ignore = -1;
+				p.depth = 0;
+				p.hit_anything = false;
 				active = true;
 			}
 		}
@@ -632,44 +675,52 @@ extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArg
 		if (active) {
 			float rad[4];
 			if (!path_step(L, a, p, stack, rad)) {
-				// backward fold of the recursion (post-order, renderer.cpp:247), then flux -> XYZ
+				// backward fold of the recursion (post-order, renderer.cpp:247)
 				while (p.depth > 0u) {
 					--p.depth;
 					const Frame& F = stack[p.depth];
 #pragma unroll
 					for (int k = 0; k < 4; ++k) rad[k] = F.direct[k] + ((rad[k] * F.n_dot_l) * F.f_s[k]) / F.pdf;
 				}
-				Hero flux; // FLAT_FIELD_CORRECTION: flux = radiance (:262-263)
-#pragma unroll
-				for (int k = 0; k < 4; ++k) flux.v[k] = rad[k];
-				float xyz[3];
-				flux_to_xyz(L, flux, p.lambda_0, xyz);
-				a.samples[p.out_index] = make_float4(xyz[0], xyz[1], xyz[2], p.hit_anything ? 1.0f : 0.0f);
+				SsxSampleRecord out;
+				out.a = make_float4(rad[0], rad[1], rad[2], rad[3]);
+				out.b = make_uint4(__float_as_uint(p.lambda_0), p.hit_anything ? 1u : 0u, 0u, 0u);
+				a.samples[p.rec_index] = out;
 				active = false;
 			}
 		}
 	}
 }
 
-// renderer.cpp:292-295: avg += sample*0.001f (float multiply, widened), in ascending k.
-// One thread per (tile slot, pixel of tile); consecutive threads read consecutive float4.
-extern "C" __global__ void __launch_bounds__(256) ssx_accumulate_kernel(const float4* samples, double* accum, uint32_t width, uint32_t height,
-                                                    uint32_t tiles_x, uint32_t tile_first, uint32_t tile_stride, uint32_t my_tiles, uint32_t n_k) {
+// Stage 3 of 3: one lane per pixel.  Flux -> CIE XYZ of every sample (util/color.hpp:115-139,
+// FLAT_FIELD_CORRECTION: flux = radiance, renderer.cpp:262-263), then renderer.cpp:292-295:
+// avg += sample*0.001f (float multiply, widened) in ascending k -- the reference's accumulation
+// order, whichever lane of the path kernel produced the sample.
+extern "C" __global__ void __launch_bounds__(256) ssx_accumulate_kernel(SsxKernelArgs a, double* accum) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds_blob[];
+	for (uint32_t w = threadIdx.x; w < a.blob_words; w += blockDim.x) lds_blob[w] = a.blob[w];
+	__syncthreads();
+	Lds L; L.w = lds_blob;
 	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t slot = gid >> 6, lane = gid & 63u;
-	if (slot >= my_tiles) return;
-	const uint32_t tile = tile_first + slot * tile_stride;
-	const uint32_t i = (tile % tiles_x) * 8u + (lane & 7u), j = (tile / tiles_x) * 8u + (lane >> 3);
-	if (i >= width || j >= height) return;
-	double* acc_p = accum + 4u * ((size_t)j * width + i);
+	if (slot >= a.my_tiles) return;
+	const uint32_t tile = a.tile_first + slot * a.tile_stride;
+	const uint32_t i = (tile % a.tiles_x) * 8u + (lane & 7u), j = (tile / a.tiles_x) * 8u + (lane >> 3);
+	if (i >= a.width || j >= a.height) return;
+	const uint32_t n_k = a.k1 - a.k0;
+	double* acc_p = accum + 4u * ((size_t)j * a.width + i);
 	double acc[4] = { acc_p[0], acc_p[1], acc_p[2], acc_p[3] };
-	const float4* s = samples + (size_t)slot * n_k * 64u + lane;
+	const SsxSampleRecord* s = a.samples + (size_t)slot * n_k * 64u + lane;
 	for (uint32_t k = 0; k < n_k; ++k) {
-		const float4 v = s[(size_t)k * 64u];
-		acc[0] += (double)(v.x * 0.001f);
-		acc[1] += (double)(v.y * 0.001f);
-		acc[2] += (double)(v.z * 0.001f);
-		acc[3] += (double)(v.w * 0.001f);
+		const SsxSampleRecord rec = s[(size_t)k * 64u];
+		Hero flux; flux.v[0] = rec.a.x; flux.v[1] = rec.a.y; flux.v[2] = rec.a.z; flux.v[3] = rec.a.w;
+		float xyz[3];
+		flux_to_xyz(L, flux, __uint_as_float(rec.b.x), xyz);
+		const float alpha = rec.b.y ? 1.0f : 0.0f;
+		acc[0] += (double)(xyz[0] * 0.001f);
+		acc[1] += (double)(xyz[1] * 0.001f);
+		acc[2] += (double)(xyz[2] * 0.001f);
+		acc[3] += (double)(alpha * 0.001f);
 	}
 	acc_p[0] = acc[0]; acc_p[1] = acc[1]; acc_p[2] = acc[2]; acc_p[3] = acc[3];
 }

@@ -1,0 +1,107 @@
+// valu_rates.hip -- issue-rate micro-benchmark of the VALU instruction kinds the integrator uses.
+// One wave per SIMD x 8, dependent chains avoided (8 independent accumulators); reports cycles per
+// wave-instruction per SIMD.   hipcc --offload-arch=gfx950 -O3 valu_rates.hip -o valu_rates
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <string>
+
+#define REP8(x) x x x x x x x x
+#define N_ITER 4096
+
+#define KERNEL(name, decl, body, sink)                                                   \
+__global__ void __launch_bounds__(256) name(float* out, float seed) {                     \
+	decl;                                                                                 \
+	for (int it = 0; it < N_ITER; ++it) {                                                 \
+		REP8(body)                                                                        \
+	}                                                                                     \
+	sink;                                                                                 \
+}
+
+#define F8 float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7, b = seed * 0.5f + threadIdx.x
+#define SINKF if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678f) out[threadIdx.x] = a0
+#define OP1(ins) asm volatile(ins " %0, %0, %1" : "+v"(a0) : "v"(b)); asm volatile(ins " %0, %0, %1" : "+v"(a1) : "v"(b)); asm volatile(ins " %0, %0, %1" : "+v"(a2) : "v"(b)); asm volatile(ins " %0, %0, %1" : "+v"(a3) : "v"(b)); asm volatile(ins " %0, %0, %1" : "+v"(a4) : "v"(b)); asm volatile(ins " %0, %0, %1" : "+v"(a5) : "v"(b)); asm volatile(ins " %0, %0, %1" : "+v"(a6) : "v"(b)); asm volatile(ins " %0, %0, %1" : "+v"(a7) : "v"(b));
+#define OPU(ins) asm volatile(ins " %0, %0" : "+v"(a0)); asm volatile(ins " %0, %0" : "+v"(a1)); asm volatile(ins " %0, %0" : "+v"(a2)); asm volatile(ins " %0, %0" : "+v"(a3)); asm volatile(ins " %0, %0" : "+v"(a4)); asm volatile(ins " %0, %0" : "+v"(a5)); asm volatile(ins " %0, %0" : "+v"(a6)); asm volatile(ins " %0, %0" : "+v"(a7));
+#define OP3(ins) asm volatile(ins " %0, %0, %1, %1" : "+v"(a0) : "v"(b)); asm volatile(ins " %0, %0, %1, %1" : "+v"(a1) : "v"(b)); asm volatile(ins " %0, %0, %1, %1" : "+v"(a2) : "v"(b)); asm volatile(ins " %0, %0, %1, %1" : "+v"(a3) : "v"(b)); asm volatile(ins " %0, %0, %1, %1" : "+v"(a4) : "v"(b)); asm volatile(ins " %0, %0, %1, %1" : "+v"(a5) : "v"(b)); asm volatile(ins " %0, %0, %1, %1" : "+v"(a6) : "v"(b)); asm volatile(ins " %0, %0, %1, %1" : "+v"(a7) : "v"(b));
+
+KERNEL(k_add_f32, F8, OP1("v_add_f32"), SINKF)
+KERNEL(k_mul_f32, F8, OP1("v_mul_f32"), SINKF)
+KERNEL(k_fma_f32, F8, OP3("v_fma_f32"), SINKF)
+KERNEL(k_min3_f32, F8, OP3("v_min3_f32"), SINKF)
+KERNEL(k_rcp_f32, F8, OPU("v_rcp_f32"), SINKF)
+KERNEL(k_sqrt_f32, F8, OPU("v_sqrt_f32"), SINKF)
+KERNEL(k_rsq_f32, F8, OPU("v_rsq_f32"), SINKF)
+KERNEL(k_floor_f32, F8, OPU("v_floor_f32"), SINKF)
+KERNEL(k_cvt_i32_f32, F8, OPU("v_cvt_i32_f32"), SINKF)
+KERNEL(k_cvt_f64_f32x, F8, OPU("v_cvt_f32_u32"), SINKF)
+KERNEL(k_mul_lo_u32, F8, OP1("v_mul_lo_u32"), SINKF)
+KERNEL(k_mul_hi_u32, F8, OP1("v_mul_hi_u32"), SINKF)
+KERNEL(k_and_b32, F8, OP1("v_and_b32"), SINKF)
+KERNEL(k_lshl_b32, F8, OP1("v_lshlrev_b32"), SINKF)
+KERNEL(k_div_fixup, F8, OP3("v_div_fixup_f32"), SINKF)
+KERNEL(k_cndmask, F8, OP1("v_cndmask_b32"), SINKF)
+
+#define D8 double a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7, b = seed * 0.5 + threadIdx.x
+#define SINKD if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678) out[threadIdx.x] = (float)a0
+KERNEL(k_add_f64, D8, OP1("v_add_f64"), SINKD)
+KERNEL(k_mul_f64, D8, OP1("v_mul_f64"), SINKD)
+KERNEL(k_fma_f64, D8, OP3("v_fma_f64"), SINKD)
+KERNEL(k_rcp_f64, D8, OPU("v_rcp_f64"), SINKD)
+KERNEL(k_rsq_f64, D8, OPU("v_rsq_f64"), SINKD)
+KERNEL(k_pk_mul_f32, D8, OP1("v_pk_mul_f32"), SINKD)
+KERNEL(k_pk_add_f32, D8, OP1("v_pk_add_f32"), SINKD)
+KERNEL(k_pk_fma_f32, D8, OP3("v_pk_fma_f32"), SINKD)
+KERNEL(k_lshl_b64, D8, asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a0)); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a1)); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a2)); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a3)); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a4)); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a5)); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a6)); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a7));, SINKD)
+
+// LDS read rates with a per-lane address pattern like the permuted-vertex table
+__global__ void __launch_bounds__(256) k_ds_read_b128(float* out, float seed) {
+	__shared__ float4 buf[1024];
+	for (int i = threadIdx.x; i < 1024; i += 256) buf[i] = make_float4(seed, i, 1, 2);
+	__syncthreads();
+	float4 acc = make_float4(0, 0, 0, 0);
+	int idx = (threadIdx.x % 6) * 3;
+	for (int it = 0; it < N_ITER; ++it) {
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			float4 v = buf[(idx + u * 18) & 1023];
+			acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+			asm volatile("" : "+v"(idx));
+		}
+	}
+	if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[threadIdx.x] = acc.x;
+}
+
+typedef void (*kern_t)(float*, float);
+struct Entry { const char* name; kern_t k; };
+
+int main() {
+	Entry es[] = {
+		{"v_add_f32", k_add_f32}, {"v_mul_f32", k_mul_f32}, {"v_fma_f32", k_fma_f32}, {"v_min3_f32", k_min3_f32},
+		{"v_cndmask_b32", k_cndmask}, {"v_and_b32", k_and_b32}, {"v_lshlrev_b32", k_lshl_b32}, {"v_floor_f32", k_floor_f32},
+		{"v_cvt_i32_f32", k_cvt_i32_f32}, {"v_cvt_f32_u32", k_cvt_f64_f32x}, {"v_div_fixup_f32", k_div_fixup},
+		{"v_rcp_f32", k_rcp_f32}, {"v_sqrt_f32", k_sqrt_f32}, {"v_rsq_f32", k_rsq_f32},
+		{"v_mul_lo_u32", k_mul_lo_u32}, {"v_mul_hi_u32", k_mul_hi_u32},
+		{"v_pk_mul_f32", k_pk_mul_f32}, {"v_pk_add_f32", k_pk_add_f32}, {"v_pk_fma_f32", k_pk_fma_f32},
+		{"v_add_f64", k_add_f64}, {"v_mul_f64", k_mul_f64}, {"v_fma_f64", k_fma_f64}, {"v_rcp_f64", k_rcp_f64}, {"v_rsq_f64", k_rsq_f64},
+		{"v_lshlrev_b64", k_lshl_b64}, {"ds_read_b128(+4 v_add)", k_ds_read_b128},
+	};
+	float* d; hipMalloc(&d, 4096);
+	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
+	double clk = prop.clockRate * 1e3; // Hz
+	int cus = prop.multiProcessorCount;
+	printf("device %s, %d CUs, clock %.0f MHz\n", prop.gcnArchName, cus, clk / 1e6);
+	for (int wpS : {1, 2, 4}) {   // waves per SIMD
+		printf("--- %d wave(s) per SIMD: cycles per wave-instruction per SIMD (at nominal clock)\n", wpS);
+		for (auto& e : es) {
+			dim3 grid(cus * wpS), block(256);
+			hipLaunchKernelGGL(e.k, grid, block, 0, 0, d, 1.0f);
+			hipDeviceSynchronize();
+			hipEvent_t t0, t1; hipEventCreate(&t0); hipEventCreate(&t1);
+			hipEventRecord(t0); hipLaunchKernelGGL(e.k, grid, block, 0, 0, d, 1.0f); hipEventRecord(t1); hipEventSynchronize(t1);
+			float ms; hipEventElapsedTime(&ms, t0, t1);
+			double instr_per_simd = (double)N_ITER * 64 * wpS; // 64 instrs per iteration per wave
+			printf("  %-24s %7.3f ms  -> %.2f cyc/instr\n", e.name, ms, ms * 1e-3 * clk / instr_per_simd);
+		}
+	}
+	return 0;
+}
