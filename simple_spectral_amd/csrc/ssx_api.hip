@@ -100,7 +100,6 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	h.off_perm = off;      off = align4(off + s->n_quads * SSX_PERM_WORDS_PER_QUAD);
 	h.off_quads = off;     off = align4(off + s->n_quads * (uint32_t)(sizeof(SsxBlobQuad) / 4));
 	h.off_lights = off;    off = align4(off + s->n_lights);
-	h.off_materials = off; off = align4(off + s->n_materials * (uint32_t)(sizeof(SsxBlobMaterial) / 4));
 	h.off_spectra = off;   off = align4(off + s->n_spectra * (uint32_t)(sizeof(SsxBlobSpectrum) / 4));
 	const uint32_t off_samples = off; off = align4(off + s->n_samples);
 	h.off_lut = off;       off = align4(off + 256u);
@@ -128,20 +127,22 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 		}
 		memcpy(bq[q].normal[0], Q.normal0, 12);
 		memcpy(bq[q].normal[1], Q.normal1, 12);
-		bq[q].material = Q.material;
-		bq[q].is_light = Q.is_light;
-	}
-	memcpy(blob.data() + h.off_lights, s->lights, 4 * s->n_lights);
-	SsxBlobMaterial* bm = reinterpret_cast<SsxBlobMaterial*>(blob.data() + h.off_materials);
-	for (uint32_t i = 0; i < s->n_materials; ++i) {
-		const ssx_material& m = s->materials[i];
-		bm[i].kind = m.kind; bm[i].albedo_mode = m.albedo_mode; bm[i].albedo_spec = m.albedo_spectrum;
-		bm[i].albedo_tex = m.albedo_texture; bm[i].emission_spec = m.emission_spectrum;
+		const ssx_material& m = s->materials[Q.material];
+		bq[q].kind = m.kind; bq[q].albedo_mode = m.albedo_mode; bq[q].albedo_tex = m.albedo_texture;
+		auto desc = [&](uint32_t id) {
+			SsxBlobSpectrum d;
+			d.offset = off_samples + s->spectra[id].offset; d.n = s->spectra[id].n;
+			d.low = s->spectra[id].low; d.delta_recip = s->spectra[id].delta_recip;
+			return d;
+		};
+		bq[q].albedo = desc(m.albedo_mode == SSX_ALBEDO_CONSTANT ? m.albedo_spectrum : m.emission_spectrum);
+		bq[q].emission = desc(m.emission_spectrum);
 		// any nonzero emission sample?  (all-zero tables evaluate to exactly +0 at every wavelength)
 		const ssx_spectrum& es = s->spectra[m.emission_spectrum];
-		bm[i].is_emissive = 0;
-		for (uint32_t k = 0; k < es.n; ++k) if (s->samples[es.offset + k] != 0.0f) bm[i].is_emissive = 1;
+		bq[q].is_emissive = 0;
+		for (uint32_t k = 0; k < es.n; ++k) if (s->samples[es.offset + k] != 0.0f) bq[q].is_emissive = 1;
 	}
+	memcpy(blob.data() + h.off_lights, s->lights, 4 * s->n_lights);
 	SsxBlobSpectrum* bs = reinterpret_cast<SsxBlobSpectrum*>(blob.data() + h.off_spectra);
 	for (uint32_t i = 0; i < s->n_spectra; ++i) {
 		bs[i].offset = off_samples + s->spectra[i].offset;

@@ -17,24 +17,27 @@
 // distinct 16-byte bank slots, so lanes with different p do not conflict.
 #define SSX_PERM_WORDS_PER_QUAD (6u * 12u)
 
-struct SsxBlobQuad {   // 36 words (144 B): stride 36 mod 32 = 4 banks, 16-byte aligned
-	float pos[4][3];   // v00, v10, v11, v01 (light sampling needs the unpermuted positions)
-	float st[4][2];
-	float normal[2][3]; // tri0, tri1
-	uint32_t material;
-	uint32_t is_light;
-	uint32_t pad[8];
-};
-static_assert(sizeof(SsxBlobQuad) == 144, "layout");
-
-struct SsxBlobMaterial { // 8 words
-	uint32_t kind, albedo_mode, albedo_spec, albedo_tex, emission_spec, is_emissive, pad0, pad1;
-};
 struct SsxBlobSpectrum { // 4 words
 	uint32_t offset; // word offset of the first sample from the blob start
 	uint32_t n;
 	float low, delta_recip;
 };
+
+// Everything shading needs about a quad in ONE record (its material's fields are copied in, so a
+// hit costs one dependent LDS round trip before the spectrum data instead of three).
+struct SsxBlobQuad {   // 40 words (160 B): 16-byte aligned, stride 40 mod 32 = 8 banks
+	float pos[4][3];   // v00, v10, v11, v01 (light sampling needs the unpermuted positions)
+	float st[4][2];
+	float normal[2][3]; // tri0, tri1
+	uint32_t kind;        // SSX_MTL_*
+	uint32_t albedo_mode; // SSX_ALBEDO_*
+	uint32_t albedo_tex;
+	uint32_t is_emissive; // emission table has a nonzero sample
+	SsxBlobSpectrum albedo;
+	SsxBlobSpectrum emission;
+	uint32_t pad[2];
+};
+static_assert(sizeof(SsxBlobQuad) == 160, "layout");
 
 struct SsxBlobHeader {
 	double pv_inv[16];
@@ -42,9 +45,10 @@ struct SsxBlobHeader {
 	float lambda_min, lambda_step;
 	uint32_t n_quads, n_lights, n_materials, n_spectra;
 	uint32_t spec_xbar, spec_ybar, spec_zbar, spec_basis_r, spec_basis_g, spec_basis_b;
-	uint32_t off_perm, off_quads, off_lights, off_materials, off_spectra, off_lut, off_tex;
+	uint32_t off_perm, off_quads, off_lights, off_spectra, off_lut, off_tex;
 	uint32_t n_textures;
 	uint32_t total_words;
+	uint32_t pad;
 };
 static_assert(sizeof(SsxBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 

@@ -102,9 +102,6 @@ struct Lds {
 	__device__ __forceinline__ const SsxBlobQuad& quad(uint32_t q) const {
 		return reinterpret_cast<const SsxBlobQuad*>(w + hdr().off_quads)[q];
 	}
-	__device__ __forceinline__ const SsxBlobMaterial& material(uint32_t m) const {
-		return reinterpret_cast<const SsxBlobMaterial*>(w + hdr().off_materials)[m];
-	}
 	__device__ __forceinline__ SsxBlobSpectrum spectrum(uint32_t s) const {
 		return reinterpret_cast<const SsxBlobSpectrum*>(w + hdr().off_spectra)[s];
 	}
@@ -117,24 +114,37 @@ struct Lds {
 
 struct Hero { float v[4]; };
 
-// spectrum.cpp:39-67: linear reconstruction, zero outside the table; lambda_i = l0 + float(i)*STEP
-__device__ __forceinline__ Hero spectrum_hero(const Lds& L, uint32_t spec_id, float lambda_0, float step) {
-	SsxBlobSpectrum sp = L.spectrum(spec_id);
+// spectrum.cpp:39-67: linear reconstruction, zero outside the table; lambda_i = l0 + float(i)*STEP.
+// Branch-free: both table reads of all four wavelengths are issued together at clamped indices and
+// the out-of-range ones replaced by 0 afterwards (same values as the reference's guarded reads).
+__device__ __forceinline__ Hero spectrum_hero(const Lds& L, const SsxBlobSpectrum sp, float lambda_0, float step) {
 	const float* data = reinterpret_cast<const float*>(L.w + sp.offset);
-	Hero out;
+	float frac[4], v0[4], v1[4];
+	bool ok0[4], ok1[4];
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		float lambda = lambda_0 + (float)i * step;
 		float x = (lambda - sp.low) * sp.delta_recip;
 		float i0f = __builtin_floorf(x);
-		float frac = x - i0f;
+		frac[i] = x - i0f;
 		int i0 = (int)i0f;
 		int i1 = i0 + 1;
-		float val0 = (i0 >= 0 && (uint32_t)i0 < sp.n) ? data[i0] : 0.0f;
-		float val1 = (i1 >= 0 && (uint32_t)i1 < sp.n) ? data[i1] : 0.0f;
-		out.v[i] = val0 * (1.0f - frac) + val1 * frac; // math-helpers.hpp:10-12
+		ok0[i] = (uint32_t)i0 < sp.n; // i0 >= 0 && i0 < n
+		ok1[i] = (uint32_t)i1 < sp.n;
+		uint32_t c0 = min((uint32_t)max(i0, 0), sp.n - 1u), c1 = min((uint32_t)max(i1, 0), sp.n - 1u);
+		v0[i] = data[c0];
+		v1[i] = data[c1];
+	}
+	Hero out;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		float val0 = ok0[i] ? v0[i] : 0.0f, val1 = ok1[i] ? v1[i] : 0.0f;
+		out.v[i] = val0 * (1.0f - frac[i]) + val1 * frac[i]; // math-helpers.hpp:10-12
 	}
 	return out;
+}
+__device__ __forceinline__ Hero spectrum_hero(const Lds& L, uint32_t spec_id, float lambda_0, float step) {
+	return spectrum_hero(L, L.spectrum(spec_id), lambda_0, step);
 }
 
 // material.cpp:45-97 + util/color.cpp:167-173 ("ours" basis uplift)
@@ -159,9 +169,9 @@ __device__ __forceinline__ Hero texture_sample(const Lds& L, uint32_t tex_index,
 	return out;
 }
 
-__device__ __forceinline__ Hero material_albedo(const Lds& L, const SsxBlobMaterial& m, float st_x, float st_y, float lambda_0) {
-	if (m.albedo_mode == 0u) return spectrum_hero(L, m.albedo_spec, lambda_0, L.hdr().lambda_step);
-	return texture_sample(L, m.albedo_tex, st_x, st_y, lambda_0);
+__device__ __forceinline__ Hero material_albedo(const Lds& L, const SsxBlobQuad& Q, float st_x, float st_y, float lambda_0) {
+	if (Q.albedo_mode == 0u) return spectrum_hero(L, Q.albedo, lambda_0, L.hdr().lambda_step);
+	return texture_sample(L, Q.albedo_tex, st_x, st_y, lambda_0);
 }
 
 // util/color.hpp:115-139
@@ -496,14 +506,14 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 	p.hit_anything = true;
 	const uint32_t hq = (uint32_t)hit.tri >> 1, which = (uint32_t)hit.tri & 1u;
 	const SsxBlobQuad& Q = L.quad(hq);
-	const SsxBlobMaterial& M = L.material(Q.material);
+	const SsxBlobQuad& M = Q; // the material's fields live in the quad record
 	V3 N = mk(Q.normal[which][0], Q.normal[which][1], Q.normal[which][2]);
 
 	float direct[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 	// emission: only the camera ray has last_was_delta (:169-172, :247).  A material whose emission
 	// table is all zeros (MaterialBase's default) would add exactly +0, so its lookup is skipped.
 	if (p.depth == 0u && !a.indirect_only && M.is_emissive != 0u) {
-		Hero em = spectrum_hero(L, M.emission_spec, p.lambda_0, h.lambda_step);
+		Hero em = spectrum_hero(L, M.emission, p.lambda_0, h.lambda_step);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) direct[k] += em.v[k];
 	}
@@ -520,7 +530,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 		st_y = (bx * s0[1] + by * s1[1]) + bz * s2[1];
 	}
 	// albedo(lambda) is shared by evaluate_bsdf and interact_bsdf (material.cpp:120-143)
-	Hero alb = material_albedo(L, M, st_x, st_y, p.lambda_0);
+	Hero alb = material_albedo(L, Q, st_x, st_y, p.lambda_0);
 	float f_lamb[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) f_lamb[k] = alb.v[k] / SSX_PI_F;
@@ -539,8 +549,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 			trace(L, hit_pos, sdir, (int)hq, sh);
 #endif
 			if (sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == light) {
-				const SsxBlobMaterial& LM = L.material(L.quad(light).material);
-				Hero emitted = spectrum_hero(L, LM.emission_spec, p.lambda_0, h.lambda_step);
+				Hero emitted = spectrum_hero(L, L.quad(light).emission, p.lambda_0, h.lambda_step);
 #pragma unroll
 				for (int k = 0; k < 4; ++k) {
 					float fs = (M.kind == 0u) ? f_lamb[k] : 0.0f; // Mirror::evaluate_bsdf -> 0

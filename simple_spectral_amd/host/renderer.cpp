@@ -1,0 +1,187 @@
+#include "renderer.hpp"
+
+#include "image_io.hpp"
+
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+namespace ssx {
+
+Framebuffer::Framebuffer(const size_t r[2]) : res{ r[0], r[1] }, pixels_(4 * r[0] * r[1]) {
+	for (size_t j = 0; j < res[1]; ++j) for (size_t i = 0; i < res[0]; ++i) {
+		const float v = (((i / 8) ^ (j / 8)) % 2 == 0) ? 0.7f : 0.3f;
+		float* p = (*this)(i, j);
+		p[0] = p[1] = p[2] = v; p[3] = 1.0f;
+	}
+}
+void Framebuffer::save(const std::string& path) const { save_image(path, pixels_.data(), res[0], res[1]); }
+
+// The C ABI, resolved from libssx_hip.so at run time so that libssx_host.so itself has no HIP
+// dependency (it must load on machines without a GPU for table/scene/image work).
+struct Renderer::Api {
+	void* handle = nullptr;
+	int (*create)(int, ssx_ctx**) = nullptr;
+	void (*destroy)(ssx_ctx*) = nullptr;
+	int (*upload_scene)(ssx_ctx*, const ssx_scene_desc*) = nullptr;
+	int (*render_start)(ssx_ctx*, const ssx_render_params*) = nullptr;
+	int (*render_stop)(ssx_ctx*) = nullptr;
+	int (*is_rendering)(ssx_ctx*) = nullptr;
+	float (*progress)(ssx_ctx*) = nullptr;
+	int (*render_wait)(ssx_ctx*, float*) = nullptr;
+	const char* (*last_error)(const ssx_ctx*) = nullptr;
+
+	explicit Api(const std::string& path) {
+		handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+		if (!handle) throw HostError{ SSX_ERR_DEVICE, std::string("cannot load the HIP library (no CPU fallback exists): ") + dlerror() };
+		auto sym = [&](const char* name) {
+			void* p = dlsym(handle, name);
+			if (!p) throw HostError{ SSX_ERR_DEVICE, std::string("libssx_hip.so lacks symbol ") + name };
+			return p;
+		};
+		create = reinterpret_cast<decltype(create)>(sym("ssx_create"));
+		destroy = reinterpret_cast<decltype(destroy)>(sym("ssx_destroy"));
+		upload_scene = reinterpret_cast<decltype(upload_scene)>(sym("ssx_upload_scene"));
+		render_start = reinterpret_cast<decltype(render_start)>(sym("ssx_render_start"));
+		render_stop = reinterpret_cast<decltype(render_stop)>(sym("ssx_render_stop"));
+		is_rendering = reinterpret_cast<decltype(is_rendering)>(sym("ssx_is_rendering"));
+		progress = reinterpret_cast<decltype(progress)>(sym("ssx_progress"));
+		render_wait = reinterpret_cast<decltype(render_wait)>(sym("ssx_render_wait"));
+		last_error = reinterpret_cast<decltype(last_error)>(sym("ssx_last_error"));
+	}
+	~Api() { if (handle) dlclose(handle); }
+};
+
+namespace {
+std::string default_hip_library() {
+	Dl_info info;
+	if (dladdr(reinterpret_cast<void*>(&default_hip_library), &info) && info.dli_fname) {
+		std::string self = info.dli_fname;
+		const size_t slash = self.rfind('/');
+		return (slash == std::string::npos ? std::string(".") : self.substr(0, slash)) + "/libssx_hip.so";
+	}
+	return "libssx_hip.so";
+}
+bool file_exists(const std::string& p) { return std::ifstream(p).good(); }
+} // namespace
+
+Renderer::Renderer(const Options& opts) : options(opts), framebuffer(opts.res), xyza(4 * opts.res[0] * opts.res[1], 0.0f) {
+	// Scene selection and its warnings (src/renderer.cpp:17-38, EXPLICIT_LIGHT_SAMPLING build)
+	if (options.scene_name == "plane-srgb")
+		std::fprintf(stderr, "Warning: Plane converges much faster without explicit light sampling!  (See \"stdafx.hpp\" to disable.)\n");
+	else if (options.scene_name != "cornell" && options.scene_name != "cornell-srgb") {
+		std::fprintf(stderr, "Unrecognized scene \"%s\"!  (Supported scenes: \"cornell\", \"cornell-srgb\", \"plane-srgb\")\n", options.scene_name.c_str());
+		throw HostError{ -3, "Unrecognized scene" };
+	}
+	color = std::make_unique<ColorData>(options.data_dir, options.observer);
+	Texture tex;
+	const Texture* texp = nullptr;
+	if (options.scene_name != "cornell") {
+		std::string path = options.texture_path;
+		if (path.empty()) { // the reference opens the 4096^2 blob; fall back to its own listed alternative
+			path = options.data_dir + "/scenes/crystal-lizard-4096.png";
+			if (!file_exists(path)) path = options.data_dir + "/scenes/crystal-lizard-512.png";
+		}
+		tex = load_png_rgb8(path);
+		texp = &tex;
+	}
+	scene = std::make_unique<Scene>(*color, options.scene_name, options.data_dir, texp, options.light_scale);
+
+	api_ = std::make_unique<Api>(options.hip_library.empty() ? default_hip_library() : options.hip_library);
+	const int n = options.gpus < 1 ? 1 : options.gpus;
+	for (int d = 0; d < n; ++d) {
+		ssx_ctx* ctx = nullptr;
+		int rc = api_->create(d, &ctx);
+		if (rc) throw HostError{ rc, std::string("ssx_create: ") + api_->last_error(nullptr) };
+		ctxs_.push_back(ctx);
+		rc = api_->upload_scene(ctx, &scene->desc());
+		if (rc) throw HostError{ rc, std::string("ssx_upload_scene: ") + api_->last_error(ctx) };
+	}
+}
+
+Renderer::~Renderer() {
+	for (ssx_ctx* c : ctxs_) api_->destroy(c);
+}
+
+void Renderer::render_start() {
+	time_start_ = std::chrono::steady_clock::now();
+	for (size_t d = 0; d < ctxs_.size(); ++d) {
+		ssx_render_params p{};
+		p.struct_size = sizeof p;
+		p.width = static_cast<uint32_t>(options.res[0]); p.height = static_cast<uint32_t>(options.res[1]);
+		p.spp = static_cast<uint32_t>(options.spp);
+		p.indirect_only = options.indirect_only ? 1u : 0u;
+		p.tile_first = static_cast<uint32_t>(d); p.tile_stride = static_cast<uint32_t>(ctxs_.size());
+		p.spp_per_launch = 0;
+		p.seed = options.seed;
+		int rc = api_->render_start(ctxs_[d], &p);
+		if (rc) throw HostError{ rc, std::string("ssx_render_start: ") + api_->last_error(ctxs_[d]) };
+	}
+	started_ = true;
+}
+
+void Renderer::render_stop() { for (ssx_ctx* c : ctxs_) api_->render_stop(c); }
+
+bool Renderer::is_rendering() const {
+	for (ssx_ctx* c : ctxs_) if (api_->is_rendering(c)) return true;
+	return false;
+}
+
+double Renderer::progress() const {
+	double s = 0;
+	for (ssx_ctx* c : ctxs_) s += api_->progress(c);
+	return ctxs_.empty() ? 0.0 : s / static_cast<double>(ctxs_.size());
+}
+
+void Renderer::print_progress() const {
+	auto pretty = [](double secs) {
+		const double days = std::floor(secs / 86400.0); secs -= 86400.0 * days;
+		const double hours = std::floor(secs / 3600.0); secs -= 3600.0 * hours;
+		const double mins = std::floor(secs / 60.0); secs -= 60.0 * mins;
+		if (days > 0.0) std::printf("%d days + ", static_cast<int>(days));
+		std::printf("%02d:%02d:%06.3f", static_cast<int>(hours), static_cast<int>(mins), secs);
+	};
+	const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - time_start_).count();
+	const double part = is_rendering() ? progress() : 1.0;
+	if (part < 1.0) {
+		if (part > 0.0) {
+			std::printf("\rRender %.3f%% (ETA ", part * 100.0);
+			pretty(elapsed / part - elapsed);
+			std::printf(")           ");
+			std::fflush(stdout);
+		} else {
+			std::printf("\rRender started                               ");
+		}
+	} else {
+		std::printf("\rRender completed in ");
+		pretty(elapsed);
+		std::printf("             \n");
+	}
+}
+
+void Renderer::render_wait() {
+	if (!started_) return;
+	const size_t n = 4 * options.res[0] * options.res[1];
+	std::vector<float> part(n);
+	std::fill(xyza.begin(), xyza.end(), 0.0f);
+	for (ssx_ctx* c : ctxs_) {
+		int rc = api_->render_wait(c, part.data());
+		if (rc) throw HostError{ rc, std::string("ssx_render_wait: ") + api_->last_error(c) };
+		// every pixel is nonzero in exactly one device's buffer: x + 0 is exact, so this sum is the
+		// same image a single device produces (the multi-process path does it with one RCCL reduce)
+		for (size_t k = 0; k < n; ++k) xyza[k] += part[k];
+	}
+	started_ = false;
+	// framebuffer(i,j) = sRGB_A_F32(ciexyz_to_srgb(XYZ), alpha)  (src/renderer.cpp:298)
+	for (size_t p = 0; p < options.res[0] * options.res[1]; ++p) {
+		color->ciexyz_to_srgb(&xyza[4 * p], framebuffer.data() + 4 * p);
+		framebuffer.data()[4 * p + 3] = xyza[4 * p + 3];
+	}
+	print_progress();
+	if (!options.output_path.empty()) framebuffer.save(options.output_path); // src/renderer.cpp:393
+}
+
+} // namespace ssx

@@ -1,0 +1,55 @@
+"""The C++ host: CLI argument behaviour (CPU) and an end-to-end render through the binary (GPU)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from simple_spectral_amd import build as sbuild
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "simple-spectral")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    sbuild.build_host()
+    assert os.path.exists(CLI)
+    return CLI
+
+
+def run(cli, *args):
+    return subprocess.run([cli] + list(args), cwd=ROOT, capture_output=True, text=True)
+
+
+def test_cli_argument_errors_mirror_the_reference(cli):
+    r = run(cli)
+    assert r.returncode == 255 and "Required argument `--scene`/`-s` not found!" in r.stderr and "Simple Spectral" in r.stdout
+    r = run(cli, "--scene=nope", "-w=8", "-h=8", "-spp=1", "-o=/tmp/x.png")
+    assert r.returncode == 255 and 'Unrecognized scene "nope"' in r.stderr  # src/main.cpp:92-101
+    r = run(cli, "-s=cornell", "-w=0", "-h=8", "-spp=1", "-o=/tmp/x.png")
+    assert r.returncode == 255 and "Invalid width or height!" in r.stderr   # src/main.cpp:106-112
+    r = run(cli, "-s=cornell", "-w=8", "-h=8", "-spp=x", "-o=/tmp/x.png")
+    assert r.returncode == 255 and "Invalid number of samples!" in r.stderr
+    r = run(cli, "-s=cornell", "-w=8", "-h=8", "-spp=1", "-io=1", "-o=/tmp/x.png")
+    assert r.returncode == 255 and "does not take a value" in r.stderr     # src/main.cpp:130-136
+    r = run(cli, "-s=cornell", "-w=8", "-h=8", "-spp=1")
+    assert r.returncode == 255 and "Required argument `--output`/`-o` not found!" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_renders_the_same_image_as_the_oracle(cli, tmp_path):
+    from PIL import Image
+    out = str(tmp_path / "o.png")
+    r = run(cli, "--scene=cornell-srgb", "--width=40", "-h=24", "--samples=6", "--output=" + out, "extra-arg",
+            "--texture=data/scenes/test-img.png", "--seed=9")
+    assert r.returncode == 0, r.stderr
+    assert "Render completed in" in r.stdout and 'ignoring extraneous argument' in r.stderr and '"extra-arg"' in r.stderr
+    o = ol.Oracle("cornell-srgb", texture="test-img.png")
+    srgba = o.to_srgba(o.render(40, 24, 6, seed=9))
+    want = np.round(np.clip(255.0 * srgba, 0, 255)).astype(np.uint8)[::-1]   # src/framebuffer.cpp:141-165
+    assert np.array_equal(np.asarray(Image.open(out)), want)
+    pfm = str(tmp_path / "o.pfm")
+    r = run(cli, "-s=plane-srgb", "-w=16", "-h=16", "-spp=2", "-o=" + pfm, "--texture=data/scenes/test-img.png", "-io")
+    assert r.returncode == 0 and "Plane converges much faster" in r.stderr and os.path.getsize(pfm) == len("PF\n16 16\n-1.0\n") + 16 * 16 * 12
