@@ -97,6 +97,16 @@ def hip_lib():
         if not os.path.exists(path):
             raise RuntimeError("%s is missing: run `python -m simple_spectral_amd.build` (needs hipcc). "
                                "simple_spectral_amd has no CPU or PyTorch fallback path." % path)
+        # torch ships its own HIP runtime; if the process uses torch on the GPU, let it initialise
+        # first (initialising it after this library has opened the device is not reliable)
+        import sys
+        if "torch" in sys.modules:
+            try:
+                t = sys.modules["torch"]
+                if t.cuda.is_available():
+                    t.cuda.init()
+            except Exception:
+                pass
         lib = C.CDLL(path)
         vp = C.c_void_p
         lib.ssx_last_error.restype = C.c_char_p

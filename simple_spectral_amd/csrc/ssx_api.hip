@@ -36,6 +36,7 @@ struct ssx_ctx {
 	std::vector<uint8_t*> d_textures;
 	double* d_accum = nullptr;  size_t accum_pixels = 0;
 	SsxSampleRecord* d_samples = nullptr; size_t sample_slots = 0; // record capacity of the sample buffer
+	SsxFrame* d_frames = nullptr;
 	float* d_out = nullptr;     size_t out_pixels = 0;
 	bool have_scene = false;
 
@@ -188,7 +189,8 @@ int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
 
 // Every launch writes its samples to [tile slot][k][64] float4 (16 B per sample) and the ordered
 // accumulate pass consumes them; the buffer bounds how many samples per pixel one launch may cover.
-constexpr size_t kSampleBufferBudget = (size_t)8 << 30; // bytes (32 B per sample in flight; MI355X has 288 GB)
+constexpr size_t kSampleBufferBudget = (size_t)32 << 30; // bytes: 32 B record + 8 x 48 B frames per sample in flight (288 GB HBM)
+constexpr size_t kBytesPerSampleInFlight = sizeof(SsxSampleRecord) + SSX_MAX_FRAMES * sizeof(SsxFrame);
 constexpr uint32_t kTargetUnits = 16384;               // wave work units wanted per launch (~8 per SIMD)
 
 struct LaunchPlan { SsxKernelArgs args; size_t lds_bytes; uint32_t max_spp_per_launch; };
@@ -205,7 +207,7 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	a.seed = p->seed;
 	a.my_tiles = a.n_tiles > p->tile_first ? (a.n_tiles - p->tile_first + p->tile_stride - 1u) / p->tile_stride : 0u;
 	pl.lds_bytes = (size_t)ctx->blob_words * 4;
-	size_t per_spp = (size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u * sizeof(SsxSampleRecord);
+	size_t per_spp = (size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u * kBytesPerSampleInFlight;
 	size_t cap = kSampleBufferBudget / per_spp;
 	pl.max_spp_per_launch = (uint32_t)(cap < 1 ? 1 : (cap > 65536 ? 65536 : cap));
 	return pl;
@@ -215,20 +217,32 @@ int ensure_samples(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t n_k) {
 	size_t need = (size_t)pl.args.my_tiles * 64u * n_k;
 	if (ctx->sample_slots < need) {
 		if (ctx->d_samples) (void)hipFree(ctx->d_samples);
-		ctx->d_samples = nullptr; ctx->sample_slots = 0;
+		if (ctx->d_frames) (void)hipFree(ctx->d_frames);
+		ctx->d_samples = nullptr; ctx->d_frames = nullptr; ctx->sample_slots = 0;
 		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_samples, need * sizeof(SsxSampleRecord)));
+		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_frames, need * SSX_MAX_FRAMES * sizeof(SsxFrame)));
 		ctx->sample_slots = need;
 	}
 	return SSX_OK;
 }
 
-// samples [k0,k1) of every owned pixel: generate -> path megakernel -> ordered f64 accumulation
+// samples [k0,k1) of every owned pixel: generate -> path megakernel -> resolve (fold + XYZ) -> ordered f64 accumulation
 int launch_range(ssx_ctx* ctx, LaunchPlan& pl, uint32_t k0, uint32_t k1, hipStream_t stream) {
 	SsxKernelArgs& a = pl.args;
 	if (a.my_tiles == 0 || k1 <= k0) return SSX_OK;
 	const uint32_t n_k = k1 - k0;
 	a.k0 = k0; a.k1 = k1;
 	a.samples = ctx->d_samples;
+	a.frames = ctx->d_frames;
+	a.n_records = (uint64_t)a.my_tiles * n_k * 64u;
+#ifdef SSX_PROFILE_REGIONS
+	{
+		static uint64_t* d_prof = nullptr;
+		if (!d_prof) { SSX_HIP(ctx, hipMalloc((void**)&d_prof, 16 * sizeof(uint64_t))); }
+		SSX_HIP(ctx, hipMemsetAsync(d_prof, 0, 16 * sizeof(uint64_t), stream));
+		a.prof = d_prof;
+	}
+#endif
 	uint64_t g = ((uint64_t)n_k * a.my_tiles + kTargetUnits - 1) / kTargetUnits;
 	a.group_spp = (uint32_t)(g < 8 ? 8 : g);
 	if (a.group_spp > n_k) a.group_spp = n_k;
@@ -239,8 +253,21 @@ int launch_range(ssx_ctx* ctx, LaunchPlan& pl, uint32_t k0, uint32_t k1, hipStre
 	SSX_HIP(ctx, hipGetLastError());
 	hipLaunchKernelGGL(ssx_render_kernel, dim3((units + 3u) / 4u), dim3(256), pl.lds_bytes, stream, a);
 	SSX_HIP(ctx, hipGetLastError());
-	hipLaunchKernelGGL(ssx_accumulate_kernel, dim3((a.my_tiles * 64u + 255u) / 256u), dim3(256), pl.lds_bytes, stream, a, ctx->d_accum);
+	hipLaunchKernelGGL(ssx_resolve_kernel, dim3((uint32_t)((n_rec + 255u) / 256u)), dim3(256), pl.lds_bytes, stream, a);
 	SSX_HIP(ctx, hipGetLastError());
+	hipLaunchKernelGGL(ssx_accumulate_kernel, dim3((a.my_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, a, ctx->d_accum);
+	SSX_HIP(ctx, hipGetLastError());
+#ifdef SSX_PROFILE_REGIONS
+	{
+		uint64_t h[16];
+		SSX_HIP(ctx, hipStreamSynchronize(stream));
+		SSX_HIP(ctx, hipMemcpy(h, a.prof, sizeof h, hipMemcpyDeviceToHost));
+		static const char* names[12] = { "refill", "trace_primary", "hit+albedo", "sample_light", "trace_shadow", "nee_contrib", "bsdf_sample", "frame_push", "finish/fold", "total_wave_cycles", "wave_iterations", "active_lanes" };
+		fprintf(stderr, "[region profile] ");
+		for (int r = 0; r < 12; ++r) fprintf(stderr, "%s=%llu ", names[r], (unsigned long long)h[r]);
+		fprintf(stderr, "\n");
+	}
+#endif
 	return SSX_OK;
 }
 
@@ -327,6 +354,7 @@ void ssx_destroy(ssx_ctx* ctx) {
 	for (uint8_t* t : ctx->d_textures) (void)hipFree(t);
 	if (ctx->d_accum) (void)hipFree(ctx->d_accum);
 	if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+	if (ctx->d_frames) (void)hipFree(ctx->d_frames);
 	if (ctx->d_out) (void)hipFree(ctx->d_out);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;

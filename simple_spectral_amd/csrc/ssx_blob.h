@@ -58,9 +58,17 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 
 // One sample in flight, 32 bytes, layout [tile slot][k-k0][pixel in tile].
 //   after ssx_generate_kernel: a = {camera ray dir.xyz, lambda_0}, b = PCG32 {state, inc}
-//   after ssx_render_kernel  : a = radiance hero sample, b = {lambda_0 bits, hit_anything, 0, 0}
+//   after ssx_render_kernel  : a = radiance of the deepest level, b = {lambda_0 bits, hit_anything, #frames, 0}
+//   after ssx_resolve_kernel : a = {X, Y, Z, alpha}
 struct SsxSampleRecord { float4 a; uint4 b; };
 static_assert(sizeof(SsxSampleRecord) == 32, "layout");
+
+// One level of the recursion L() of one sample (48 B): direct = emission + next-event estimate,
+// and the factors of the continuation  rad_d = direct + ((rad_{d+1} * n_dot_l) * f_s) / pdf.
+// Layout [depth][record]; written by the path kernel, read once by ssx_resolve_kernel.
+struct SsxFrame { float4 direct; float4 f_s; float2 np; float2 pad; };
+static_assert(sizeof(SsxFrame) == 48, "layout");
+#define SSX_MAX_FRAMES 8u  // depths 0..MAX_DEPTH-3 can continue (see path_step)
 
 struct SsxKernelArgs {
 	const uint32_t* blob;   // device copy of the scene blob
@@ -75,4 +83,7 @@ struct SsxKernelArgs {
 	uint32_t n_groups;      // ceil((k1-k0)/group_spp)
 	uint64_t seed;
 	SsxSampleRecord* samples; // [tile slot][k-k0][64] records of this launch
+	SsxFrame* frames;         // [depth][record]
+	uint64_t n_records;       // my_tiles * (k1-k0) * 64
+	uint64_t* prof;           // region-timing builds only (NULL otherwise)
 };

@@ -32,6 +32,19 @@
 #define ssx_sincosf(x, s, c) (*(s) = (x) * 0.5f, *(c) = 1.0f - (x) * 0.25f)
 #endif
 
+// Region timing build (tools/region_profile.py): wave-level s_memtime deltas per region of the
+// megakernel iteration, summed into a.prof[region].  Compiled out of the product library.
+#ifdef SSX_PROFILE_REGIONS
+#define SSX_NREG 12
+#define SSX_MARK(r) do { uint64_t now_ = __builtin_readcyclecounter(); prof_t[(r)] += now_ - prof_last; prof_last = __builtin_readcyclecounter(); } while (0)
+#define SSX_PROF_ARGS , uint64_t* prof_t, uint64_t& prof_last
+#define SSX_PROF_PASS , prof_t, prof_last
+#else
+#define SSX_MARK(r) do {} while (0)
+#define SSX_PROF_ARGS
+#define SSX_PROF_PASS
+#endif
+
 #define SSX_EPS 0.001f          // stdafx.hpp:58
 #define SSX_MAX_DEPTH_ 10u       // stdafx.hpp:47
 #define SSX_PI_F 3.14159265358979323846f
@@ -451,7 +464,7 @@ __device__ __forceinline__ V3 reflect3(V3 vec, V3 n) { // math-helpers.hpp:40-42
 }
 
 // ------------------------------------------------------------------ one path ----
-struct Frame { float direct[4]; float f_s[4]; float n_dot_l, pdf; };
+
 
 // Per-lane state of the path a lane is working on.  A lane always holds one (pixel, k) item of
 // its wave's work unit; when the path ends the lane writes the result and takes the next item.
@@ -498,10 +511,11 @@ __device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const Ss
 // emission (camera ray only), next-event estimation with its shadow ray, BSDF sample.  Returns
 // true when the path continues (a Frame was pushed and p holds the next ray); otherwise `rad`
 // holds the radiance of this deepest level.
-__device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, Path& p, Frame* stack, float rad[4]) {
+__device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, Path& p, float rad[4] SSX_PROF_ARGS) {
 	const SsxBlobHeader& h = L.hdr();
 	HitInfo hit;
 	trace(L, p.orig, p.dir, p.ignore, hit);
+	SSX_MARK(1);
 	if (hit.tri < 0) { rad[0] = rad[1] = rad[2] = rad[3] = 0.0f; return false; }
 	p.hit_anything = true;
 	const uint32_t hq = (uint32_t)hit.tri >> 1, which = (uint32_t)hit.tri & 1u;
@@ -534,6 +548,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 	float f_lamb[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) f_lamb[k] = alb.v[k] / SSX_PI_F;
+	SSX_MARK(2);
 
 	// direct lighting (:182-219)
 #ifndef SSX_ABL_NONEE
@@ -541,6 +556,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 		V3 sdir; uint32_t light; float spdf;
 		sample_light(L, p.rng, hit_pos, sdir, light, spdf);
 		float n_dot_l = dot3(sdir, N);
+		SSX_MARK(3);
 		if (n_dot_l > 0.0f) {
 			HitInfo sh;
 #ifdef SSX_ABL_NOSHADOW
@@ -548,6 +564,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 #else
 			trace(L, hit_pos, sdir, (int)hq, sh);
 #endif
+			SSX_MARK(4);
 			if (sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == light) {
 				Hero emitted = spectrum_hero(L, L.quad(light).emission, p.lambda_0, h.lambda_step);
 #pragma unroll
@@ -560,6 +577,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 	}
 #endif
 
+	SSX_MARK(5);
 	// indirect lighting (:222-250)
 	V3 w_i; float pdf_w_i; float f_s[4];
 	if (M.kind == 0u) {
@@ -573,6 +591,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 #pragma unroll
 		for (int k = 0; k < 4; ++k) f_s[k] = alb.v[k];
 	}
+	SSX_MARK(6);
 	bool cont = false;
 	float n_dot_l = 0.0f;
 	float dotfs = (f_s[0] * f_s[0] + f_s[1] * f_s[1]) + (f_s[2] * f_s[2] + f_s[3] * f_s[3]);
@@ -593,18 +612,23 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 		}
 		return false;
 	}
-	Frame& F = stack[p.depth];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) { F.direct[k] = direct[k]; F.f_s[k] = f_s[k]; }
-	F.n_dot_l = n_dot_l; F.pdf = pdf_w_i;
+	// record this level for the backward fold (done by ssx_resolve_kernel): [depth][record] so that
+	// the 64 lanes of a wave, which hold (mostly) consecutive records, store contiguously
+	{
+		SsxFrame* F = a.frames + ((size_t)p.depth * a.n_records + p.rec_index);
+		F->direct = make_float4(direct[0], direct[1], direct[2], direct[3]);
+		F->f_s = make_float4(f_s[0], f_s[1], f_s[2], f_s[3]);
+		F->np = make_float2(n_dot_l, pdf_w_i);
+	}
 	p.orig = hit_pos; p.dir = w_i; p.ignore = (int)hq;
 	++p.depth;
+	SSX_MARK(7);
 	return true;
 }
 
 } // namespace
 
-// Stage 1 of 3: one lane per sample.  Camera ray + hero wavelength (f64 camera maths of
+// Stage 1 of 4: one lane per sample.  Camera ray + hero wavelength (f64 camera maths of
 // renderer.cpp:113-138) for every (owned pixel, k in [k0,k1)) into the sample buffer,
 // layout [tile slot][k-k0][pixel in tile] so a wave writes 64 consecutive 32-byte records.
 extern "C" __global__ void __launch_bounds__(256) ssx_generate_kernel(SsxKernelArgs a) {
@@ -624,13 +648,14 @@ extern "C" __global__ void __launch_bounds__(256) ssx_generate_kernel(SsxKernelA
 	a.samples[rec_index] = rec;
 }
 
-// Stage 2 of 3: the path megakernel.  Work unit of one wave64 = one 8x8 tile (Framebuffer::Tile,
+// Stage 2 of 4: the path megakernel.  Work unit of one wave64 = one 8x8 tile (Framebuffer::Tile,
 // renderer.cpp:396-409) x a group of consecutive samples; its items (pixel of the tile, k) are
 // enumerated k-major and handed to lanes as they fall idle: every iteration the idle lanes
 // ballot, take consecutive item numbers by prefix count, and load those samples' camera rays, so
 // all 64 lanes trace a ray in (almost) every iteration although path lengths differ (26 % of
-// Cornell paths end after one interaction, 24 % run all nine).  A finished path overwrites its
-// record with {radiance[4], lambda_0 (sign bit clear iff the path hit anything... see below)}.
+// Cornell paths end after one interaction, 24 % run all nine).  The recursion L() of the
+// reference is evaluated as a forward pass here (each level's direct light and continuation
+// factors go to the frame buffer, write-only) and a backward fold in ssx_resolve_kernel.
 extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArgs a) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_blob[];
 	for (uint32_t w = threadIdx.x; w < a.blob_words; w += blockDim.x) lds_blob[w] = a.blob[w];
@@ -653,10 +678,15 @@ extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArg
 	const SsxBlobHeader& h = L.hdr();
 	const V3 cam = mk(h.cam_pos[0], h.cam_pos[1], h.cam_pos[2]);
 
-	Frame stack[SSX_MAX_DEPTH_ - 1u];
 	Path p;
 	bool active = false;
 	uint32_t next_item = 0; // wave-uniform
+#ifdef SSX_PROFILE_REGIONS
+	uint64_t prof_t[SSX_NREG] = {};
+	uint64_t prof_last = __builtin_readcyclecounter();
+	const uint64_t prof_start = prof_last;
+	uint64_t prof_iters = 0, prof_lanes = 0;
+#endif
 	for (;;) {
 		// hand out items to idle lanes
 		const uint64_t idle = __ballot(!active);
@@ -681,35 +711,76 @@ extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArg
 		}
 		next_item = min(n_items, next_item + (uint32_t)__popcll(idle));
 		if (!__any(active)) break;
+		SSX_MARK(0);
+#ifdef SSX_PROFILE_REGIONS
+		prof_iters += 1; prof_lanes += (uint64_t)__popcll(__ballot(active));
+#endif
 		if (active) {
 			float rad[4];
-			if (!path_step(L, a, p, stack, rad)) {
-				// backward fold of the recursion (post-order, renderer.cpp:247)
-				while (p.depth > 0u) {
-					--p.depth;
-					const Frame& F = stack[p.depth];
-#pragma unroll
-					for (int k = 0; k < 4; ++k) rad[k] = F.direct[k] + ((rad[k] * F.n_dot_l) * F.f_s[k]) / F.pdf;
-				}
+			if (!path_step(L, a, p, rad SSX_PROF_PASS)) {
+				// deepest level reached: its radiance, the number of recorded frames, lambda_0 and the
+				// hit flag replace the sample's record; the fold happens in ssx_resolve_kernel
 				SsxSampleRecord out;
 				out.a = make_float4(rad[0], rad[1], rad[2], rad[3]);
-				out.b = make_uint4(__float_as_uint(p.lambda_0), p.hit_anything ? 1u : 0u, 0u, 0u);
+				out.b = make_uint4(__float_as_uint(p.lambda_0), p.hit_anything ? 1u : 0u, p.depth, 0u);
 				a.samples[p.rec_index] = out;
 				active = false;
 			}
 		}
+		SSX_MARK(8);
 	}
+#ifdef SSX_PROFILE_REGIONS
+	if ((threadIdx.x & 63u) == 0u && a.prof) {
+		for (int r = 0; r < SSX_NREG - 3; ++r) atomicAdd((unsigned long long*)&a.prof[r], (unsigned long long)prof_t[r]);
+		atomicAdd((unsigned long long*)&a.prof[SSX_NREG - 3], (unsigned long long)(__builtin_readcyclecounter() - prof_start));
+		atomicAdd((unsigned long long*)&a.prof[SSX_NREG - 2], (unsigned long long)prof_iters);
+		atomicAdd((unsigned long long*)&a.prof[SSX_NREG - 1], (unsigned long long)prof_lanes);
+	}
+#endif
 }
 
-// Stage 3 of 3: one lane per pixel.  Flux -> CIE XYZ of every sample (util/color.hpp:115-139,
-// FLAT_FIELD_CORRECTION: flux = radiance, renderer.cpp:262-263), then renderer.cpp:292-295:
-// avg += sample*0.001f (float multiply, widened) in ascending k -- the reference's accumulation
-// order, whichever lane of the path kernel produced the sample.
-extern "C" __global__ void __launch_bounds__(256) ssx_accumulate_kernel(SsxKernelArgs a, double* accum) {
+// Stage 3 of 4: one lane per sample.  Backward fold of the recursion (renderer.cpp:247:
+// radiance += L(next) * n_dot_l * f_s / pdf, evaluated innermost first = the reference's
+// post-order) over the frames the path kernel recorded, then flux -> CIE XYZ (util/color.hpp:
+// 115-139; FLAT_FIELD_CORRECTION: flux = radiance, renderer.cpp:262-263).  The record becomes
+// {X, Y, Z, alpha}.
+extern "C" __global__ void __launch_bounds__(256) ssx_resolve_kernel(SsxKernelArgs a) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_blob[];
 	for (uint32_t w = threadIdx.x; w < a.blob_words; w += blockDim.x) lds_blob[w] = a.blob[w];
 	__syncthreads();
 	Lds L; L.w = lds_blob;
+	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= a.n_records) return;
+	// records of lanes outside a ragged image were never generated
+	{
+		const uint32_t lane = (uint32_t)(r & 63u);
+		const uint32_t n_k = a.k1 - a.k0;
+		const uint32_t slot = (uint32_t)((r >> 6) / n_k);
+		const uint32_t tile = a.tile_first + slot * a.tile_stride;
+		const uint32_t i = (tile % a.tiles_x) * 8u + (lane & 7u), j = (tile / a.tiles_x) * 8u + (lane >> 3);
+		if (i >= a.width || j >= a.height) return;
+	}
+	const SsxSampleRecord rec = a.samples[r];
+	float rad[4] = { rec.a.x, rec.a.y, rec.a.z, rec.a.w };
+	uint32_t depth = rec.b.z;
+	while (depth > 0u) {
+		--depth;
+		const SsxFrame F = a.frames[(size_t)depth * a.n_records + r];
+		rad[0] = F.direct.x + ((rad[0] * F.np.x) * F.f_s.x) / F.np.y;
+		rad[1] = F.direct.y + ((rad[1] * F.np.x) * F.f_s.y) / F.np.y;
+		rad[2] = F.direct.z + ((rad[2] * F.np.x) * F.f_s.z) / F.np.y;
+		rad[3] = F.direct.w + ((rad[3] * F.np.x) * F.f_s.w) / F.np.y;
+	}
+	Hero flux; flux.v[0] = rad[0]; flux.v[1] = rad[1]; flux.v[2] = rad[2]; flux.v[3] = rad[3];
+	float xyz[3];
+	flux_to_xyz(L, flux, __uint_as_float(rec.b.x), xyz);
+	a.samples[r].a = make_float4(xyz[0], xyz[1], xyz[2], rec.b.y ? 1.0f : 0.0f);
+}
+
+// Stage 4 of 4: one lane per pixel.  renderer.cpp:292-295: avg += sample*0.001f (float multiply,
+// widened) in ascending k -- the reference's accumulation order, whichever lane of the path
+// kernel produced the sample.  Consecutive lanes read consecutive records.
+extern "C" __global__ void __launch_bounds__(256) ssx_accumulate_kernel(SsxKernelArgs a, double* accum) {
 	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t slot = gid >> 6, lane = gid & 63u;
 	if (slot >= a.my_tiles) return;
@@ -721,15 +792,11 @@ extern "C" __global__ void __launch_bounds__(256) ssx_accumulate_kernel(SsxKerne
 	double acc[4] = { acc_p[0], acc_p[1], acc_p[2], acc_p[3] };
 	const SsxSampleRecord* s = a.samples + (size_t)slot * n_k * 64u + lane;
 	for (uint32_t k = 0; k < n_k; ++k) {
-		const SsxSampleRecord rec = s[(size_t)k * 64u];
-		Hero flux; flux.v[0] = rec.a.x; flux.v[1] = rec.a.y; flux.v[2] = rec.a.z; flux.v[3] = rec.a.w;
-		float xyz[3];
-		flux_to_xyz(L, flux, __uint_as_float(rec.b.x), xyz);
-		const float alpha = rec.b.y ? 1.0f : 0.0f;
-		acc[0] += (double)(xyz[0] * 0.001f);
-		acc[1] += (double)(xyz[1] * 0.001f);
-		acc[2] += (double)(xyz[2] * 0.001f);
-		acc[3] += (double)(alpha * 0.001f);
+		const float4 v = s[(size_t)k * 64u].a;
+		acc[0] += (double)(v.x * 0.001f);
+		acc[1] += (double)(v.y * 0.001f);
+		acc[2] += (double)(v.z * 0.001f);
+		acc[3] += (double)(v.w * 0.001f);
 	}
 	acc_p[0] = acc[0]; acc_p[1] = acc[1]; acc_p[2] = acc[2]; acc_p[3] = acc[3];
 }

@@ -25,3 +25,13 @@ def _have_gpu():
 @pytest.fixture(scope="session")
 def have_gpu():
     return _have_gpu()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_runtime_first():
+    """torch bundles its own libamdhip64; when a GPU is present initialise it before
+    libssx_hip.so (which links /opt/rocm's) creates its contexts, the order bench.py uses too."""
+    if _have_gpu():
+        import torch
+        torch.cuda.init()
+    yield

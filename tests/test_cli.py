@@ -48,7 +48,7 @@ def test_cli_renders_the_same_image_as_the_oracle(cli, tmp_path):
     assert "Render completed in" in r.stdout and 'ignoring extraneous argument' in r.stderr and '"extra-arg"' in r.stderr
     o = ol.Oracle("cornell-srgb", texture="test-img.png")
     srgba = o.to_srgba(o.render(40, 24, 6, seed=9))
-    want = np.round(np.clip(255.0 * srgba, 0, 255)).astype(np.uint8)[::-1]   # src/framebuffer.cpp:141-165
+    want = np.floor(np.clip(np.float32(255.0) * srgba, 0, 255) + np.float32(0.5)).astype(np.uint8)[::-1]   # std::round, src/framebuffer.cpp:141-165
     assert np.array_equal(np.asarray(Image.open(out)), want)
     pfm = str(tmp_path / "o.pfm")
     r = run(cli, "-s=plane-srgb", "-w=16", "-h=16", "-spp=2", "-o=" + pfm, "--texture=data/scenes/test-img.png", "-io")

@@ -100,11 +100,13 @@ def test_launch_chunking_and_tile_partition_do_not_change_the_image():
 def test_device_buffer_entry_point_matches_host_path():
     torch = pytest.importorskip("torch")
     r = Renderer(Options(scene_name="plane-srgb", res=(40, 24), spp=6, seed=2, texture="test-img.png"))
+    ref = ol.Oracle("plane-srgb", texture="test-img.png").render(40, 24, 6, seed=2)
     out = torch.zeros((24, 40, 4), dtype=torch.float32, device="cuda")
     r.render_device(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
+    assert np.array_equal(bits(out.cpu().numpy()), bits(ref)), "ssx_render_device differs from the oracle"
     r.render_start(); r.render_wait()
-    assert np.array_equal(bits(out.cpu().numpy()), bits(r.xyza))
+    assert np.array_equal(bits(r.xyza), bits(ref)), "start/wait differs from the oracle"
 
 
 def test_full_size_properties_config2():

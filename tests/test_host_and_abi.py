@@ -107,7 +107,7 @@ def test_png_decoder_and_writers(tmp_path):
     png = str(tmp_path / "o.png")
     assert host.ssh_save_image(png.encode(), fb.ctypes.data, W, H) == 0
     back = np.asarray(Image.open(png))  # RGBA8, top row first
-    want = np.round(np.clip(255.0 * fb, 0, 255)).astype(np.uint8)[::-1]
+    want = np.floor(np.clip(np.float32(255.0) * fb, 0, 255) + np.float32(0.5)).astype(np.uint8)[::-1]  # std::round (half away from zero)
     assert back.shape == (H, W, 4) and np.array_equal(back, want)
     pfm = str(tmp_path / "o.pfm")
     assert host.ssh_save_image(pfm.encode(), fb.ctypes.data, W, H) == 0
