@@ -25,6 +25,11 @@ sys.path.insert(0, ROOT)
 # Algorithmic FP32 work per sample, SURVEY.md section 8(d): 33*T + 28*P + 550*S + 150 with the
 # measured per-sample counts (T tri tests, P edge-test passes, S surface interactions).
 FLOP_PER_SAMPLE = {"cornell-srgb": 1.28e4, "cornell": 1.28e4, "plane-srgb": 2.8e3}
+# Algorithmic HBM bytes per sample of the 4-stage pipeline: the 32-byte
+# record is written by generate, read+rewritten by the path kernel, read by resolve (16 B written
+# back), read by accumulate = 144 B; plus one 48-byte frame written and read per continued bounce
+# (frames/sample = interactions that continue: 3.29 Cornell, 1 plane [oracle statistics]).
+FRAMES_PER_SAMPLE = {"cornell-srgb": 3.29, "cornell": 3.29, "plane-srgb": 1.0}
 # gfx950 FP32 vector peak is 157.3 TFLOP/s counting FMA as 2; the parity contract forbids
 # contraction, so the ceiling that applies is the non-fused issue rate, half of it.
 PEAK_VALU_TFLOPS = 78.6
@@ -50,6 +55,19 @@ def cpu_baseline(scene, W, H, texture, target_seconds=12.0):
             "sample": "%s %dx%d spp=%d (%.1f s, oracle/libssx_oracle.so, %d threads, 8x8 tile queue)" % (scene, W, H, spp, dt, cores)}
 
 
+def measured_traffic(args, world):
+    """HBM bytes per launch of the megakernel from the PMC passes (FETCH_SIZE, WRITE_SIZE collected
+    in separate rocprofv3 --pmc runs, FETCH_SIZE doubled per MI355X_MICROARCH.md for wide coalesced
+    reads), as recorded by tools/collect_traffic.py for this exact workload; None otherwise."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        t = json.load(open(path))
+        key = "%s %d spp%d obs%d gpus%d" % (args.scene, args.res, args.spp, args.observer, world)
+        return t.get(key)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,6 +76,7 @@ def main():
     ap.add_argument("--scene", default="cornell-srgb")
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel PER GPU")
+    ap.add_argument("--observer", type=int, default=1931)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -83,7 +102,7 @@ def main():
     spp_total = args.spp * world
     texture = "crystal-lizard-512.png"
     r = Renderer(Options(scene_name=args.scene, res=(W, H), spp=spp_total, texture=texture, device=local_rank,
-                         tile_first=rank, tile_stride=world, seed=0))
+                         tile_first=rank, tile_stride=world, seed=0, observer=args.observer))
     out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
 
@@ -124,20 +143,19 @@ def main():
         per_gpu_samples = W * H * args.spp
         flop = FLOP_PER_SAMPLE.get(args.scene, 1.28e4)
         achieved_tflops = per_gpu_samples * flop / (kernel_ms * 1e-3) / 1e12
-        # algorithmic HBM traffic: one float4 store + one double4 read-modify-write per pixel,
-        # texture fetches hit L2 -> bytes per launch
-        hbm_bytes = (W * H // world) * (16 + 64)
+        # algorithmic HBM traffic per launch: sample records + frames, plus 16+64 B per pixel
+        hbm_bytes = per_gpu_samples * (144 + 96 * FRAMES_PER_SAMPLE.get(args.scene, 3.29)) + (W * H // world) * (16 + 64)
         info = r.kernel_info()
         line = {
             "metric": "Msamples/s (w*h*spp/s) %s %dx%d" % (args.scene, W, H),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s %dx%d spp=%d/GPU (total spp %d) CIE1931 hero-wavelength megakernel" % (args.scene, W, H, args.spp, spp_total),
+            "config": {"workload": "%s %dx%d spp=%d/GPU (total spp %d) CIE%d hero-wavelength megakernel" % (args.scene, W, H, args.spp, spp_total, args.observer),
                        "parallelism": "tile-split x%d + RCCL reduce" % world if world > 1 else "single GPU",
                        "texture": texture, "seed": 0},
             "roofline": {"bound": "valu", "achieved": round(achieved_tflops, 3), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved_tflops / PEAK_VALU_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved_tflops / PEAK_VALU_TFLOPS, 4), "traffic": measured_traffic(args, world),
                          "kernel": "ssx_render_kernel", "kernel_ms": round(kernel_ms, 3),
                          "flop_per_sample": flop, "note": "FP32 VALU-issue bound, no MFMA, HBM idle by design; peak = 157.3/2 (no FMA contraction under the parity contract)",
                          "hbm": {"achieved": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",

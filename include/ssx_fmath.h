@@ -140,16 +140,17 @@ SSX_FM_FN float ssx_acosf(float xf) {
 	double x = (double)xf;
 	double ax = x < 0.0 ? -x : x;
 	if (!(ax <= 1.0)) { float q = xf - xf; return q / q; }
-	if (ax <= 0.5) {
-		double z = x * x;
-		double t = SSX_FMA(x * z, ssx_fm_asin_poly(z), x); /* asin(x) */
-		return (float)(pio2_hi - (t - pio2_lo));
-	}
-	double z = (1.0 - ax) * 0.5;            /* exact */
-	double s = __builtin_sqrt(z);           /* correctly rounded */
-	double t = SSX_FMA(s * z, ssx_fm_asin_poly(z), s); /* asin(s) = acos(ax)/2 */
-	double r = t + t;
-	if (x < 0.0) r = pi_hi - (r - pi_lo);
+	/* One polynomial evaluation for both ranges (wave lanes take both, so two copies would both run):
+	 *   |x| <= 0.5:  z = x^2,        s = x,        t = asin(x);       acos = pi/2 - t
+	 *   |x| >  0.5:  z = (1-|x|)/2,  s = sqrt(z),  t = acos(|x|)/2;   acos = 2t  or  pi - 2t     */
+	const int big = ax > 0.5;
+	double z = big ? (1.0 - ax) * 0.5 : x * x;       /* (1-|x|)/2 is exact */
+	double s = big ? __builtin_sqrt(z) : x;          /* correctly rounded sqrt */
+	double t = SSX_FMA(s * z, ssx_fm_asin_poly(z), s);
+	double m = big ? t + t : t;
+	double c_hi = big ? pi_hi : pio2_hi, c_lo = big ? pi_lo : pio2_lo;
+	double r = c_hi - (m - c_lo);
+	if (big && !(x < 0.0)) r = m;
 	return (float)r;
 }
 

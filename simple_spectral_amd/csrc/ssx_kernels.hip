@@ -351,34 +351,30 @@ __device__ __forceinline__ void sphtri_make(V3 A, V3 B, V3 C, SphTri& t) {
 	float denom1 = sin_c * sin_a;
 	float denom2 = sin_a * sin_b;
 	t.b = b; t.cos_c = cos_c;
-	if (denom0 > 0 && denom1 > 0 && denom2 > 0) {
-		float cos_alpha = clamp_glm(numer0 / denom0, -1.0f, 1.0f);
+	// results are kept in scalars and selected, never stored through the struct in branches (that
+	// made the compiler spill them to scratch)
+	const bool regular = denom0 > 0 && denom1 > 0 && denom2 > 0;
+	// cos_alpha = clamp(numer0/denom0) and acos of it are shared by the regular case (:64,:67) and
+	// the "only a is 0 or pi" case (:111-112)
+	const float cos_alpha0 = clamp_glm(numer0 / denom0, -1.0f, 1.0f);
+	const float alpha_raw = ssx_acosf(cos_alpha0);
+	float alpha = clamp_glm(alpha_raw, 0.0f, under_pi), cos_alpha = cos_alpha0, area = 0.0f;
+	if (regular) {
 		float cos_beta  = clamp_glm(numer1 / denom1, -1.0f, 1.0f);
 		float cos_gamma = clamp_glm(numer2 / denom2, -1.0f, 1.0f);
-		float alpha = clamp_glm(ssx_acosf(cos_alpha), 0.0f, under_pi);
 		float beta  = clamp_glm(ssx_acosf(cos_beta ), 0.0f, under_pi);
 		float gamma = clamp_glm(ssx_acosf(cos_gamma), 0.0f, under_pi);
-		float area = alpha + beta + gamma - SSX_PI_F;
+		area = alpha + beta + gamma - SSX_PI_F;
 		if (area >= 0); else area = 0;
-		t.alpha = alpha; t.cos_alpha = cos_alpha; t.area = area;
-		return;
-	}
-	t.area = 0;
-	// degenerate ladder (:76-123): alpha/cos_alpha are the only vertex-angle members read later
-	if (sin_a > 0) {
-		if (sin_b > 0) {
-			if (sin_c > 0) { t.alpha = nanv; t.cos_alpha = nanv; }
-			else { t.cos_alpha = 1; t.alpha = SSX_PI_F * 0.5f; }
-		} else {
-			if (sin_c > 0) { t.cos_alpha = 1; t.alpha = SSX_PI_F * 0.5f; }
-			else { t.alpha = nanv; t.cos_alpha = nanv; }
-		}
 	} else {
-		if (sin_b > 0) {
-			if (sin_c > 0) { t.cos_alpha = clamp_glm(numer0 / denom0, -1.0f, 1.0f); t.alpha = ssx_acosf(t.cos_alpha); }
-			else { t.alpha = nanv; t.cos_alpha = nanv; }
-		} else { t.alpha = nanv; t.cos_alpha = nanv; }
+		// degenerate ladder (:74-123): only alpha / cos_alpha of the vertex angles are read later
+		const bool sa = sin_a > 0, sb = sin_b > 0, sc = sin_c > 0;
+		const bool half_pi = sa && (sb != sc);        // only c, or only b, is 0 or pi: alpha = pi/2, cos_alpha = 1
+		const bool only_a = !sa && sb && sc;          // cos_alpha = clamp(numer0/denom0), alpha = acos(cos_alpha) unclamped
+		alpha = half_pi ? SSX_PI_F * 0.5f : (only_a ? alpha_raw : nanv);
+		cos_alpha = half_pi ? 1.0f : (only_a ? cos_alpha0 : nanv);
 	}
+	t.alpha = alpha; t.cos_alpha = cos_alpha; t.area = area;
 }
 
 __device__ __forceinline__ V3 func_bar(V3 x, V3 y) { // util/random.cpp:139-144
@@ -603,19 +599,17 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 	// A ray at depth MAX_DEPTH-1 can add nothing (no emission: last_was_delta is false; no further
 	// bounce: depth+1 == MAX_DEPTH) and hit_anything is already set, so it is not traced: its L()
 	// is exactly 0 and the parent adds ((0*n)*f)/p.
+	// In that case direct + ((0*n_dot_l)*f_s)/pdf == direct exactly: n_dot_l, f_s (finite table
+	// values / pi) and pdf (in (EPS/pi, 1/pi], or 1 for a mirror) are finite and pdf > 0.
 	if (!cont || p.depth + 2u >= SSX_MAX_DEPTH_) {
 #pragma unroll
 		for (int k = 0; k < 4; ++k) rad[k] = direct[k];
-		if (cont) {
-#pragma unroll
-			for (int k = 0; k < 4; ++k) rad[k] = direct[k] + ((0.0f * n_dot_l) * f_s[k]) / pdf_w_i;
-		}
 		return false;
 	}
 	// record this level for the backward fold (done by ssx_resolve_kernel): [depth][record] so that
 	// the 64 lanes of a wave, which hold (mostly) consecutive records, store contiguously
 	{
-		SsxFrame* F = a.frames + ((size_t)p.depth * a.n_records + p.rec_index);
+		SsxFrame* F = a.frames + (p.depth * (uint32_t)a.n_records + p.rec_index); // < 2^32 frames per launch (host budget)
 		F->direct = make_float4(direct[0], direct[1], direct[2], direct[3]);
 		F->f_s = make_float4(f_s[0], f_s[1], f_s[2], f_s[3]);
 		F->np = make_float2(n_dot_l, pdf_w_i);
@@ -765,7 +759,7 @@ extern "C" __global__ void __launch_bounds__(256) ssx_resolve_kernel(SsxKernelAr
 	uint32_t depth = rec.b.z;
 	while (depth > 0u) {
 		--depth;
-		const SsxFrame F = a.frames[(size_t)depth * a.n_records + r];
+		const SsxFrame F = a.frames[depth * (uint32_t)a.n_records + (uint32_t)r];
 		rad[0] = F.direct.x + ((rad[0] * F.np.x) * F.f_s.x) / F.np.y;
 		rad[1] = F.direct.y + ((rad[1] * F.np.x) * F.f_s.y) / F.np.y;
 		rad[2] = F.direct.z + ((rad[2] * F.np.x) * F.f_s.z) / F.np.y;

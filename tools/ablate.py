@@ -36,6 +36,7 @@ if __name__ == "__main__":
     if "--build" in sys.argv:
         build()
     else:
-        for name in VARIANTS:
-            for scene in ("cornell-srgb", "cornell"):
+        names = [a for a in sys.argv[1:] if not a.startswith("-")] or list(VARIANTS)
+        for name in names:
+            for scene in ("cornell-srgb",):
                 run(name, scene)
