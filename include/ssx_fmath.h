@@ -26,6 +26,9 @@
 #define SSX_FM_FN static inline
 #endif
 
+/* Out-of-domain results are a quiet NaN constant (no arithmetic needed to make one). */
+#define SSX_FM_NAN __builtin_nanf("")
+
 /* fma is an exactly specified IEEE operation: hardware v_fma_f64 on gfx950, vfmadd or the
  * correctly rounded software fma() of libm on the host. */
 #define SSX_FMA(a, b, c) __builtin_fma((a), (b), (c))
@@ -78,8 +81,7 @@ SSX_FM_FN void ssx_sincosf(float xf, float* s_out, float* c_out) {
 	double x = (double)xf;
 	double ax = x < 0.0 ? -x : x;
 	if (!(ax <= 1048576.0)) { /* NaN, inf, out of domain */
-		float q = xf - xf; q = q / q;
-		*s_out = q; *c_out = q;
+		*s_out = SSX_FM_NAN; *c_out = SSX_FM_NAN;
 		return;
 	}
 	double r;
@@ -97,7 +99,7 @@ SSX_FM_FN void ssx_sincosf(float xf, float* s_out, float* c_out) {
 SSX_FM_FN float ssx_sinf(float xf) {
 	double x = (double)xf;
 	double ax = x < 0.0 ? -x : x;
-	if (!(ax <= 1048576.0)) { float q = xf - xf; return q / q; }
+	if (!(ax <= 1048576.0)) return SSX_FM_NAN;
 	double r;
 	int n = ssx_fm_reduce(x, &r);
 	double v = (n & 1) ? ssx_fm_kcos(r) : ssx_fm_ksin(r);
@@ -108,7 +110,7 @@ SSX_FM_FN float ssx_sinf(float xf) {
 SSX_FM_FN float ssx_cosf(float xf) {
 	double x = (double)xf;
 	double ax = x < 0.0 ? -x : x;
-	if (!(ax <= 1048576.0)) { float q = xf - xf; return q / q; }
+	if (!(ax <= 1048576.0)) return SSX_FM_NAN;
 	double r;
 	int n = ssx_fm_reduce(x, &r);
 	double v = (n & 1) ? ssx_fm_ksin(r) : ssx_fm_kcos(r);
@@ -139,7 +141,7 @@ SSX_FM_FN float ssx_acosf(float xf) {
 	const double pi_hi   = 0x1.921fb54442d18p+1, pi_lo   = 0x1.1a62633145c07p-53;
 	double x = (double)xf;
 	double ax = x < 0.0 ? -x : x;
-	if (!(ax <= 1.0)) { float q = xf - xf; return q / q; }
+	if (!(ax <= 1.0)) return SSX_FM_NAN;
 	/* One polynomial evaluation for both ranges (wave lanes take both, so two copies would both run):
 	 *   |x| <= 0.5:  z = x^2,        s = x,        t = asin(x);       acos = pi/2 - t
 	 *   |x| >  0.5:  z = (1-|x|)/2,  s = sqrt(z),  t = acos(|x|)/2;   acos = 2t  or  pi - 2t     */

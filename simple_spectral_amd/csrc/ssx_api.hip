@@ -96,6 +96,10 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	h.spec_xbar = s->spec_xbar; h.spec_ybar = s->spec_ybar; h.spec_zbar = s->spec_zbar;
 	h.spec_basis_r = s->spec_basis_r; h.spec_basis_g = s->spec_basis_g; h.spec_basis_b = s->spec_basis_b;
 	h.n_textures = s->n_textures;
+	{
+		const ssx_spectrum &r = s->spectra[s->spec_basis_r], &g = s->spectra[s->spec_basis_g], &b = s->spectra[s->spec_basis_b];
+		h.basis_one_grid = (r.n == g.n && r.n == b.n && r.low == g.low && r.low == b.low && r.delta_recip == g.delta_recip && r.delta_recip == b.delta_recip) ? 1u : 0u;
+	}
 
 	uint32_t off = (uint32_t)(sizeof(SsxBlobHeader) / 4);
 	h.off_perm = off;      off = align4(off + s->n_quads * SSX_PERM_WORDS_PER_QUAD);

@@ -48,7 +48,7 @@ struct SsxBlobHeader {
 	uint32_t off_perm, off_quads, off_lights, off_spectra, off_lut, off_tex;
 	uint32_t n_textures;
 	uint32_t total_words;
-	uint32_t pad;
+	uint32_t basis_one_grid; // the three basis tables share (low, delta_recip, n)
 };
 static_assert(sizeof(SsxBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 

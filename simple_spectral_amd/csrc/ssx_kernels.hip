@@ -130,31 +130,41 @@ struct Hero { float v[4]; };
 // spectrum.cpp:39-67: linear reconstruction, zero outside the table; lambda_i = l0 + float(i)*STEP.
 // Branch-free: both table reads of all four wavelengths are issued together at clamped indices and
 // the out-of-range ones replaced by 0 afterwards (same values as the reference's guarded reads).
-__device__ __forceinline__ Hero spectrum_hero(const Lds& L, const SsxBlobSpectrum sp, float lambda_0, float step) {
-	const float* data = reinterpret_cast<const float*>(L.w + sp.offset);
-	float frac[4], v0[4], v1[4];
-	bool ok0[4], ok1[4];
+// The index/fraction part depends only on the table's grid (low, delta_recip, n), so tables on one
+// grid (the three basis spectra) share it.
+struct HeroIndex { uint32_t c0[4], c1[4]; float frac[4]; bool ok0[4], ok1[4]; };
+__device__ __forceinline__ HeroIndex hero_index(const SsxBlobSpectrum sp, float lambda_0, float step) {
+	HeroIndex h;
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		float lambda = lambda_0 + (float)i * step;
 		float x = (lambda - sp.low) * sp.delta_recip;
 		float i0f = __builtin_floorf(x);
-		frac[i] = x - i0f;
+		h.frac[i] = x - i0f;
 		int i0 = (int)i0f;
 		int i1 = i0 + 1;
-		ok0[i] = (uint32_t)i0 < sp.n; // i0 >= 0 && i0 < n
-		ok1[i] = (uint32_t)i1 < sp.n;
-		uint32_t c0 = min((uint32_t)max(i0, 0), sp.n - 1u), c1 = min((uint32_t)max(i1, 0), sp.n - 1u);
-		v0[i] = data[c0];
-		v1[i] = data[c1];
+		h.ok0[i] = (uint32_t)i0 < sp.n; // i0 >= 0 && i0 < n
+		h.ok1[i] = (uint32_t)i1 < sp.n;
+		h.c0[i] = min((uint32_t)max(i0, 0), sp.n - 1u);
+		h.c1[i] = min((uint32_t)max(i1, 0), sp.n - 1u);
 	}
+	return h;
+}
+__device__ __forceinline__ Hero hero_gather(const Lds& L, uint32_t offset, const HeroIndex& h) {
+	const float* data = reinterpret_cast<const float*>(L.w + offset);
+	float v0[4], v1[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) { v0[i] = data[h.c0[i]]; v1[i] = data[h.c1[i]]; }
 	Hero out;
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		float val0 = ok0[i] ? v0[i] : 0.0f, val1 = ok1[i] ? v1[i] : 0.0f;
-		out.v[i] = val0 * (1.0f - frac[i]) + val1 * frac[i]; // math-helpers.hpp:10-12
+		float val0 = h.ok0[i] ? v0[i] : 0.0f, val1 = h.ok1[i] ? v1[i] : 0.0f;
+		out.v[i] = val0 * (1.0f - h.frac[i]) + val1 * h.frac[i]; // math-helpers.hpp:10-12
 	}
 	return out;
+}
+__device__ __forceinline__ Hero spectrum_hero(const Lds& L, const SsxBlobSpectrum sp, float lambda_0, float step) {
+	return hero_gather(L, sp.offset, hero_index(sp, lambda_0, step));
 }
 __device__ __forceinline__ Hero spectrum_hero(const Lds& L, uint32_t spec_id, float lambda_0, float step) {
 	return spectrum_hero(L, L.spectrum(spec_id), lambda_0, step);
@@ -173,9 +183,16 @@ __device__ __forceinline__ Hero texture_sample(const Lds& L, uint32_t tex_index,
 	const uint8_t* px = rgb + 3u * ((size_t)j * (size_t)t.w + (size_t)i);
 	float r = L.lut(px[0]), g = L.lut(px[1]), b = L.lut(px[2]);
 	const SsxBlobHeader& h = L.hdr();
-	Hero br = spectrum_hero(L, h.spec_basis_r, lambda_0, h.lambda_step);
-	Hero bg = spectrum_hero(L, h.spec_basis_g, lambda_0, h.lambda_step);
-	Hero bb = spectrum_hero(L, h.spec_basis_b, lambda_0, h.lambda_step);
+	Hero br, bg, bb;
+	const SsxBlobSpectrum sr = L.spectrum(h.spec_basis_r), sg = L.spectrum(h.spec_basis_g), sb = L.spectrum(h.spec_basis_b);
+	if (h.basis_one_grid) { // wave-uniform: r, g, b tables have the same (low, delta_recip, n)
+		const HeroIndex hi = hero_index(sr, lambda_0, h.lambda_step);
+		br = hero_gather(L, sr.offset, hi); bg = hero_gather(L, sg.offset, hi); bb = hero_gather(L, sb.offset, hi);
+	} else {
+		br = spectrum_hero(L, sr, lambda_0, h.lambda_step);
+		bg = spectrum_hero(L, sg, lambda_0, h.lambda_step);
+		bb = spectrum_hero(L, sb, lambda_0, h.lambda_step);
+	}
 	Hero out;
 #pragma unroll
 	for (int k = 0; k < 4; ++k) out.v[k] = (r * br.v[k] + g * bg.v[k]) + b * bb.v[k];
@@ -608,12 +625,16 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 	}
 	// record this level for the backward fold (done by ssx_resolve_kernel): [depth][record] so that
 	// the 64 lanes of a wave, which hold (mostly) consecutive records, store contiguously
+#ifndef SSX_ABL_NOSTORES
 	{
 		SsxFrame* F = a.frames + (p.depth * (uint32_t)a.n_records + p.rec_index); // < 2^32 frames per launch (host budget)
 		F->direct = make_float4(direct[0], direct[1], direct[2], direct[3]);
 		F->f_s = make_float4(f_s[0], f_s[1], f_s[2], f_s[3]);
 		F->np = make_float2(n_dot_l, pdf_w_i);
 	}
+#else
+	if (n_dot_l == 123.456f) a.frames[p.rec_index].np = make_float2(direct[0] + f_s[1], pdf_w_i);
+#endif
 	p.orig = hit_pos; p.dir = w_i; p.ignore = (int)hq;
 	++p.depth;
 	SSX_MARK(7);
