@@ -25,9 +25,8 @@ sys.path.insert(0, ROOT)
 # Algorithmic FP32 work per sample, SURVEY.md section 8(d): 33*T + 28*P + 550*S + 150 with the
 # measured per-sample counts (T tri tests, P edge-test passes, S surface interactions).
 FLOP_PER_SAMPLE = {"cornell-srgb": 1.28e4, "cornell": 1.28e4, "plane-srgb": 2.8e3}
-# Algorithmic HBM bytes per sample of the 4-stage pipeline: the 32-byte
-# record is written by generate, read+rewritten by the path kernel, read by resolve (16 B written
-# back), read by accumulate = 144 B; plus one 48-byte frame written and read per continued bounce
+# Algorithmic HBM bytes per sample of the path megakernel: the 32-byte
+# record is read and rewritten, and one 48-byte frame is written per continued bounce
 # (frames/sample = interactions that continue: 3.29 Cornell, 1 plane [oracle statistics]).
 FRAMES_PER_SAMPLE = {"cornell-srgb": 3.29, "cornell": 3.29, "plane-srgb": 1.0}
 # gfx950 FP32 vector peak is 157.3 TFLOP/s counting FMA as 2; the parity contract forbids
@@ -119,6 +118,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    r.set_timing(True)  # HIP events on the launch stream around each of the four kernels
     # kernel duration: HIP events on the launch stream around each render (memset + megakernel +
     # finalize; the two small kernels are microseconds next to the megakernel)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -131,7 +131,9 @@ def main():
             dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
     fence()
     elapsed = time.perf_counter() - t0
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    pipeline_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    stage_ms = {k: v / max(args.steps, 1) for k, v in r.get_timing().items()}
+    kernel_ms = stage_ms["path"]  # the dominant kernel (ssx_render_kernel), mean per launch
     if world > 1:
         tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -143,8 +145,8 @@ def main():
         per_gpu_samples = W * H * args.spp
         flop = FLOP_PER_SAMPLE.get(args.scene, 1.28e4)
         achieved_tflops = per_gpu_samples * flop / (kernel_ms * 1e-3) / 1e12
-        # algorithmic HBM traffic per launch: sample records + frames, plus 16+64 B per pixel
-        hbm_bytes = per_gpu_samples * (144 + 96 * FRAMES_PER_SAMPLE.get(args.scene, 3.29)) + (W * H // world) * (16 + 64)
+        # algorithmic HBM traffic of the megakernel per launch: record read + rewrite, frames written
+        hbm_bytes = per_gpu_samples * (64 + 48 * FRAMES_PER_SAMPLE.get(args.scene, 3.29))
         info = r.kernel_info()
         line = {
             "metric": "Msamples/s (w*h*spp/s) %s %dx%d" % (args.scene, W, H),
@@ -157,6 +159,7 @@ def main():
             "roofline": {"bound": "valu", "achieved": round(achieved_tflops, 3), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved_tflops / PEAK_VALU_TFLOPS, 4), "traffic": measured_traffic(args, world),
                          "kernel": "ssx_render_kernel", "kernel_ms": round(kernel_ms, 3),
+                         "pipeline_ms": round(pipeline_ms, 3), "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
                          "flop_per_sample": flop, "note": "FP32 VALU-issue bound, no MFMA, HBM idle by design; peak = 157.3/2 (no FMA contraction under the parity contract)",
                          "hbm": {"achieved": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 7)},

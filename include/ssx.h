@@ -148,6 +148,12 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* params, void* d_xyz
 /* Last error text for ctx (or for ssx_create when ctx is NULL). */
 const char* ssx_last_error(const ssx_ctx* ctx);
 
+/* Measurement aid: when enabled, HIP events are recorded on the launch stream around the four
+ * stages of every launch; ssx_get_timing waits for them and returns (and clears) the summed
+ * milliseconds {generate, path megakernel, resolve, accumulate} since the last call. */
+int ssx_set_timing(ssx_ctx* ctx, int enable);
+int ssx_get_timing(ssx_ctx* ctx, float stage_ms[4]);
+
 /* Introspection: ABI version, and per-kernel resource usage for reports. */
 int ssx_abi_version(void);
 int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* scratch_bytes, int* max_blocks_per_cu);

@@ -48,6 +48,12 @@ struct ssx_ctx {
 	int worker_rc = 0;
 	ssx_render_params cur{};
 
+	// optional per-kernel timing (ssx_set_timing): events on the launch stream around each stage
+	bool timing = false;
+	hipEvent_t ev[5] = {};
+	float stage_ms[4] = { 0, 0, 0, 0 };
+	bool ev_pending = false;
+
 	std::string error;
 };
 
@@ -230,6 +236,19 @@ int ensure_samples(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t n_k) {
 	return SSX_OK;
 }
 
+// adds the stage durations of the last recorded launch to ctx->stage_ms
+int collect_timing(ssx_ctx* ctx) {
+	if (!ctx->ev_pending) return SSX_OK;
+	SSX_HIP(ctx, hipEventSynchronize(ctx->ev[4]));
+	for (int k = 0; k < 4; ++k) {
+		float ms = 0;
+		SSX_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]));
+		ctx->stage_ms[k] += ms;
+	}
+	ctx->ev_pending = false;
+	return SSX_OK;
+}
+
 // samples [k0,k1) of every owned pixel: generate -> path megakernel -> resolve (fold + XYZ) -> ordered f64 accumulation
 int launch_range(ssx_ctx* ctx, LaunchPlan& pl, uint32_t k0, uint32_t k1, hipStream_t stream) {
 	SsxKernelArgs& a = pl.args;
@@ -253,14 +272,26 @@ int launch_range(ssx_ctx* ctx, LaunchPlan& pl, uint32_t k0, uint32_t k1, hipStre
 	a.n_groups = (n_k + a.group_spp - 1) / a.group_spp;
 	const uint32_t units = a.my_tiles * a.n_groups;
 	const uint64_t n_rec = (uint64_t)a.my_tiles * n_k * 64u;
+	if (ctx->timing) {
+		if (ctx->ev_pending) { int r = collect_timing(ctx); if (r) return r; }
+		for (hipEvent_t& e : ctx->ev) if (!e) SSX_HIP(ctx, hipEventCreate(&e));
+		SSX_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
+	}
 	hipLaunchKernelGGL(ssx_generate_kernel, dim3((uint32_t)((n_rec + 255u) / 256u)), dim3(256), 0, stream, a);
 	SSX_HIP(ctx, hipGetLastError());
+	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
 	hipLaunchKernelGGL(ssx_render_kernel, dim3((units + 3u) / 4u), dim3(256), pl.lds_bytes, stream, a);
 	SSX_HIP(ctx, hipGetLastError());
-	hipLaunchKernelGGL(ssx_resolve_kernel, dim3((uint32_t)((n_rec + 255u) / 256u)), dim3(256), pl.lds_bytes, stream, a);
+	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
+	{
+		const uint64_t want = (n_rec + 255u) / 256u;
+		hipLaunchKernelGGL(ssx_resolve_kernel, dim3((uint32_t)(want < 8192u ? want : 8192u)), dim3(256), pl.lds_bytes, stream, a);
+	}
 	SSX_HIP(ctx, hipGetLastError());
+	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
 	hipLaunchKernelGGL(ssx_accumulate_kernel, dim3((a.my_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, a, ctx->d_accum);
 	SSX_HIP(ctx, hipGetLastError());
+	if (ctx->timing) { SSX_HIP(ctx, hipEventRecord(ctx->ev[4], stream)); ctx->ev_pending = true; }
 #ifdef SSX_PROFILE_REGIONS
 	{
 		uint64_t h[16];
@@ -360,6 +391,7 @@ void ssx_destroy(ssx_ctx* ctx) {
 	if (ctx->d_samples) (void)hipFree(ctx->d_samples);
 	if (ctx->d_frames) (void)hipFree(ctx->d_frames);
 	if (ctx->d_out) (void)hipFree(ctx->d_out);
+	for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -455,6 +487,23 @@ int ssx_render_wait(ssx_ctx* ctx, float* xyza_out) {
 		SSX_HIP(ctx, hipSetDevice(ctx->device));
 		SSX_HIP(ctx, hipMemcpy(xyza_out, ctx->d_out, (size_t)ctx->cur.width * ctx->cur.height * 4 * sizeof(float), hipMemcpyDeviceToHost));
 	}
+	return SSX_OK;
+}
+
+int ssx_set_timing(ssx_ctx* ctx, int enable) {
+	if (!ctx) return SSX_ERR_ARG;
+	ctx->timing = enable != 0;
+	for (float& m : ctx->stage_ms) m = 0;
+	ctx->ev_pending = false;
+	return SSX_OK;
+}
+
+int ssx_get_timing(ssx_ctx* ctx, float stage_ms[4]) {
+	if (!ctx || !stage_ms) return SSX_ERR_ARG;
+	SSX_HIP(ctx, hipSetDevice(ctx->device));
+	int rc = collect_timing(ctx);
+	if (rc) return rc;
+	for (int k = 0; k < 4; ++k) { stage_ms[k] = ctx->stage_ms[k]; ctx->stage_ms[k] = 0; }
 	return SSX_OK;
 }
 

@@ -764,32 +764,32 @@ extern "C" __global__ void __launch_bounds__(256) ssx_resolve_kernel(SsxKernelAr
 	for (uint32_t w = threadIdx.x; w < a.blob_words; w += blockDim.x) lds_blob[w] = a.blob[w];
 	__syncthreads();
 	Lds L; L.w = lds_blob;
-	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= a.n_records) return;
-	// records of lanes outside a ragged image were never generated
-	{
-		const uint32_t lane = (uint32_t)(r & 63u);
-		const uint32_t n_k = a.k1 - a.k0;
-		const uint32_t slot = (uint32_t)((r >> 6) / n_k);
-		const uint32_t tile = a.tile_first + slot * a.tile_stride;
-		const uint32_t i = (tile % a.tiles_x) * 8u + (lane & 7u), j = (tile / a.tiles_x) * 8u + (lane >> 3);
-		if (i >= a.width || j >= a.height) return;
+	// persistent blocks, grid-stride over the records: the scene tables are staged once per block
+	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_records; r += (uint64_t)gridDim.x * blockDim.x) {
+		if (a.width % 8u != 0u || a.height % 8u != 0u) { // records of lanes outside a ragged image were never generated
+			const uint32_t lane = (uint32_t)(r & 63u);
+			const uint32_t n_k = a.k1 - a.k0;
+			const uint32_t slot = (uint32_t)((r >> 6) / n_k);
+			const uint32_t tile = a.tile_first + slot * a.tile_stride;
+			const uint32_t i = (tile % a.tiles_x) * 8u + (lane & 7u), j = (tile / a.tiles_x) * 8u + (lane >> 3);
+			if (i >= a.width || j >= a.height) continue;
+		}
+		const SsxSampleRecord rec = a.samples[r];
+		float rad[4] = { rec.a.x, rec.a.y, rec.a.z, rec.a.w };
+		uint32_t depth = rec.b.z;
+		while (depth > 0u) {
+			--depth;
+			const SsxFrame F = a.frames[depth * (uint32_t)a.n_records + (uint32_t)r];
+			rad[0] = F.direct.x + ((rad[0] * F.np.x) * F.f_s.x) / F.np.y;
+			rad[1] = F.direct.y + ((rad[1] * F.np.x) * F.f_s.y) / F.np.y;
+			rad[2] = F.direct.z + ((rad[2] * F.np.x) * F.f_s.z) / F.np.y;
+			rad[3] = F.direct.w + ((rad[3] * F.np.x) * F.f_s.w) / F.np.y;
+		}
+		Hero flux; flux.v[0] = rad[0]; flux.v[1] = rad[1]; flux.v[2] = rad[2]; flux.v[3] = rad[3];
+		float xyz[3];
+		flux_to_xyz(L, flux, __uint_as_float(rec.b.x), xyz);
+		a.samples[r].a = make_float4(xyz[0], xyz[1], xyz[2], rec.b.y ? 1.0f : 0.0f);
 	}
-	const SsxSampleRecord rec = a.samples[r];
-	float rad[4] = { rec.a.x, rec.a.y, rec.a.z, rec.a.w };
-	uint32_t depth = rec.b.z;
-	while (depth > 0u) {
-		--depth;
-		const SsxFrame F = a.frames[depth * (uint32_t)a.n_records + (uint32_t)r];
-		rad[0] = F.direct.x + ((rad[0] * F.np.x) * F.f_s.x) / F.np.y;
-		rad[1] = F.direct.y + ((rad[1] * F.np.x) * F.f_s.y) / F.np.y;
-		rad[2] = F.direct.z + ((rad[2] * F.np.x) * F.f_s.z) / F.np.y;
-		rad[3] = F.direct.w + ((rad[3] * F.np.x) * F.f_s.w) / F.np.y;
-	}
-	Hero flux; flux.v[0] = rad[0]; flux.v[1] = rad[1]; flux.v[2] = rad[2]; flux.v[3] = rad[3];
-	float xyz[3];
-	flux_to_xyz(L, flux, __uint_as_float(rec.b.x), xyz);
-	a.samples[r].a = make_float4(xyz[0], xyz[1], xyz[2], rec.b.y ? 1.0f : 0.0f);
 }
 
 // Stage 4 of 4: one lane per pixel.  renderer.cpp:292-295: avg += sample*0.001f (float multiply,

@@ -172,6 +172,15 @@ class Renderer:
         p = self.params(**over)
         self._check(self._lib.ssx_render_device(self._ctx, C.byref(p), C.c_void_p(d_ptr), C.c_void_p(stream)))
 
+    def set_timing(self, enable=True):
+        self._check(self._lib.ssx_set_timing(self._ctx, int(enable)))
+
+    def get_timing(self):
+        """Summed ms {generate, path, resolve, accumulate} of the launches since the last call."""
+        ms = (C.c_float * 4)()
+        self._check(self._lib.ssx_get_timing(self._ctx, ms))
+        return dict(zip(("generate", "path", "resolve", "accumulate"), [float(x) for x in ms]))
+
     def kernel_info(self):
         v = [C.c_int() for _ in range(5)]
         self._check(self._lib.ssx_kernel_info(self._ctx, *[C.byref(x) for x in v]))
