@@ -76,8 +76,12 @@ typedef struct ssx_material {
 /* sRGB_ReflectanceTexture (src/material.hpp:14-45): RGB8, rows top to bottom. */
 typedef struct ssx_texture { uint32_t width, height; const uint8_t* rgb; } ssx_texture;
 
+/* RENDER_MODE_SPECTRAL_ALGNUM (src/stdafx.hpp:63-73): how a texel's linear RGB becomes a
+ * reflectance spectrum (Color::lrgb_to_specrefl, src/util/color.cpp:167-232). */
+enum { SSX_UPLIFT_OURS = 1, SSX_UPLIFT_JH = 3 };
+
 /* Everything the kernel reads: the flattened Scene (src/scene.hpp:16-66) + Color::data tables
- * (src/util/color.hpp:22-68).  Uplift = "ours" basis (RENDER_MODE_SPECTRAL_ALGNUM 1). */
+ * (src/util/color.hpp:22-68). */
 typedef struct ssx_scene_desc {
 	uint32_t struct_size; /* sizeof(ssx_scene_desc) */
 	uint32_t reserved;
@@ -96,6 +100,12 @@ typedef struct ssx_scene_desc {
 	/* srgb_to_lrgb(u8*(1/255)) for u8=0..255 (src/material.cpp:52-56, src/util/color.hpp:91-97):
 	 * built by the host with the platform powf, exactly as the reference evaluates it per texel. */
 	float srgb_to_linear[256];
+	/* uplift variant; for SSX_UPLIFT_JH the Jakob-Hanika model (src/jakob-and-hanika-2019/
+	 * rgb2spec.h:9-13): scale[jh_res], data[3*jh_res^3*3]; unused (0/NULL) for SSX_UPLIFT_OURS */
+	uint32_t uplift;
+	uint32_t jh_res;
+	const float* jh_scale;
+	const float* jh_data;
 } ssx_scene_desc;
 
 /* One render = Renderer::render_start..render_wait (src/renderer.cpp:396-430) for this device's

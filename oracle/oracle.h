@@ -121,6 +121,10 @@ typedef struct {
 	float D65_orig_XYZ[3], D65_rad_XYZ[3];
 	orc_spectrum basis_r, basis_g, basis_b;
 	float matr_lrgb_to_xyz[9], matr_xyz_to_lrgb[9]; /* column-major m[col*3+row] */
+	/* RENDER_MODE_SPECTRAL_JH: _RGB2Spec (jakob-and-hanika-2019/rgb2spec.h:9-13); jh_res == 0 -> "ours" */
+	int jh_res;
+	float* jh_scale;
+	float* jh_data;
 } orc_color;
 
 /* counters for the survey's per-sample work statistics */
@@ -136,6 +140,10 @@ const char* orc_last_error(void);
 /* Color::init (color.cpp:72-155).  data_dir holds the CSV tables. */
 orc_color* orc_color_create(const char* data_dir, int observer);
 void orc_color_destroy(orc_color*);
+/* switch the uplift to Jakob-Hanika with the given model (copied); res = 0 switches back */
+int orc_color_set_jh(orc_color*, int res, const float* scale, const float* data);
+void orc_jh_fetch(const orc_color*, const float rgb[3], float out[3]);  /* rgb2spec.c:77-118 */
+float orc_jh_eval_precise(const float coeff[3], float lambda);          /* rgb2spec.c:129-133 */
 
 /* Scene::get_new_* (scene.cpp:32-415).  name in {cornell, cornell-srgb, plane-srgb}.
  * tex_rgb/tex_w/tex_h: decoded RGB8 texture for the -srgb scenes (rows top-to-bottom). */

@@ -331,6 +331,7 @@ void orc_color_destroy(orc_color* cd) {
 	orc_spectrum_free(&cd->xbar); orc_spectrum_free(&cd->ybar); orc_spectrum_free(&cd->zbar);
 	orc_spectrum_free(&cd->D65_orig); orc_spectrum_free(&cd->D65_rad);
 	orc_spectrum_free(&cd->basis_r); orc_spectrum_free(&cd->basis_g); orc_spectrum_free(&cd->basis_b);
+	free(cd->jh_scale); free(cd->jh_data);
 	free(cd);
 }
 
@@ -349,8 +350,68 @@ void orc_srgb_to_lrgb(const float srgb[3], float lrgb[3]) {
 	}
 }
 
-/* color.cpp:167-173: r*basis.r[l0] + g*basis.g[l0] + b*basis.b[l0] (scalar*vec4, left to right) */
+/* ---- Jakob & Hanika 2019 (reference src/jakob-and-hanika-2019/rgb2spec.c) ---- */
+int orc_color_set_jh(orc_color* cd, int res, const float* scale, const float* data) {
+	free(cd->jh_scale); free(cd->jh_data);
+	cd->jh_scale = cd->jh_data = NULL; cd->jh_res = 0;
+	if (res <= 0) return 0;
+	if (cd->observer != 1931) { orc_set_error("%s", "JH needs the CIE 1931 observer (stdafx.hpp:107-109)"); return -3; }
+	size_t n = (size_t)3 * res * res * res * 3;
+	cd->jh_scale = (float*)malloc(sizeof(float) * (size_t)res);
+	cd->jh_data = (float*)malloc(sizeof(float) * n);
+	memcpy(cd->jh_scale, scale, sizeof(float) * (size_t)res);
+	memcpy(cd->jh_data, data, sizeof(float) * n);
+	cd->jh_res = res;
+	return 0;
+}
+/* rgb2spec.c:56-74 */
+static int rgb2spec_find_interval(const float* values, int size_, float x) {
+	int left = 0, last_interval = size_ - 2, size = last_interval;
+	while (size > 0) {
+		int half = size >> 1, middle = left + half + 1;
+		if (values[middle] < x) { left = middle; size -= half + 1; }
+		else size = half;
+	}
+	return left < last_interval ? left : last_interval;
+}
+/* (uint32_t) of NaN/inf is undefined in the reference (a black texel gives z == 0 -> scale = inf,
+ * x = NaN); the build defines it as 0, here and in the kernel. */
+static uint32_t jh_to_u32(float v) { return (v >= 0.0f && v < 4294967296.0f) ? (uint32_t)v : 0u; }
+/* rgb2spec.c:77-118 */
+void orc_jh_fetch(const orc_color* cd, const float rgb[3], float out[3]) {
+	int i = 0, res = cd->jh_res;
+	for (int j = 1; j < 3; ++j) if (rgb[j] >= rgb[i]) i = j;
+	float z = rgb[i], scale = (res - 1) / z, x = rgb[(i + 1) % 3] * scale, y = rgb[(i + 2) % 3] * scale;
+	uint32_t xi = jh_to_u32(x), yi = jh_to_u32(y);
+	if (xi > (uint32_t)(res - 2)) xi = (uint32_t)(res - 2);
+	if (yi > (uint32_t)(res - 2)) yi = (uint32_t)(res - 2);
+	uint32_t zi = (uint32_t)rgb2spec_find_interval(cd->jh_scale, res, z);
+	uint32_t offset = (((i * res + zi) * res + yi) * res + xi) * 3, dx = 3, dy = 3 * res, dz = 3 * res * res;
+	float x1 = x - xi, x0 = 1.f - x1, y1 = y - yi, y0 = 1.f - y1;
+	float z1 = (z - cd->jh_scale[zi]) / (cd->jh_scale[zi + 1] - cd->jh_scale[zi]), z0 = 1.f - z1;
+	const float* d = cd->jh_data;
+	for (int j = 0; j < 3; ++j) {
+		out[j] = ((d[offset] * x0 + d[offset + dx] * x1) * y0 + (d[offset + dy] * x0 + d[offset + dy + dx] * x1) * y1) * z0 +
+		         ((d[offset + dz] * x0 + d[offset + dz + dx] * x1) * y0 + (d[offset + dz + dy] * x0 + d[offset + dz + dy + dx] * x1) * y1) * z1;
+		offset++;
+	}
+}
+/* rgb2spec.c:120-133 with rgb2spec_fma = a*b+c (no __FMA__ on the x86-64 baseline) */
+float orc_jh_eval_precise(const float coeff[3], float lambda) {
+	float x = (coeff[0] * lambda + coeff[1]) * lambda + coeff[2];
+	float y = 1.f / sqrtf(x * x + 1.f);
+	return (.5f * x) * y + .5f;
+}
+
+/* color.cpp:167-173 (ours): r*basis.r[l0] + g*basis.g[l0] + b*basis.b[l0] (scalar*vec4, left to right);
+ * color.cpp:203-232 (JH): fetch the coefficients, evaluate at lambda_0 + i*LAMBDA_STEP */
 void orc_lrgb_to_specrefl(const orc_color* cd, const float lrgb[3], float lambda_0, float out[4]) {
+	if (cd->jh_res > 0) {
+		float coeffs[3];
+		orc_jh_fetch(cd, lrgb, coeffs);
+		for (size_t i = 0; i < ORC_NWAVE; ++i) out[i] = orc_jh_eval_precise(coeffs, lambda_0 + (float)i * cd->lambda_step);
+		return;
+	}
 	float br[4], bg[4], bb[4];
 	orc_spectrum_hero(&cd->basis_r, lambda_0, cd->lambda_step, br);
 	orc_spectrum_hero(&cd->basis_g, lambda_0, cd->lambda_step, bg);

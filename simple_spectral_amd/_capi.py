@@ -43,6 +43,8 @@ class SsxSceneDesc(C.Structure):
         ("lights", C.POINTER(C.c_uint32)), ("n_lights", C.c_uint32),
         ("textures", C.POINTER(SsxTexture)), ("n_textures", C.c_uint32),
         ("srgb_to_linear", C.c_float * 256),
+        ("uplift", C.c_uint32), ("jh_res", C.c_uint32),
+        ("jh_scale", C.POINTER(C.c_float)), ("jh_data", C.POINTER(C.c_float)),
     ]
 
 
@@ -52,13 +54,14 @@ class SsxRenderParams(C.Structure):
                 ("spp_per_launch", C.c_uint32), ("seed", C.c_uint64)]
 
 
+SSX_UPLIFT_OURS, SSX_UPLIFT_JH = 1, 3
 SSX_OK, SSX_ERR_DATA, SSX_ERR_ARG, SSX_ERR_SCENE, SSX_ERR_DEVICE, SSX_ERR_STATE = 0, -1, -2, -3, -10, -11
 
 # every symbol include/ssx.h and include/ssx_host.h declare (tests check the libraries export them)
 HIP_SYMBOLS = ["ssx_create", "ssx_destroy", "ssx_upload_scene", "ssx_render_start", "ssx_render_stop",
                "ssx_is_rendering", "ssx_progress", "ssx_render_wait", "ssx_render_device", "ssx_last_error",
                "ssx_abi_version", "ssx_kernel_info", "ssx_set_timing", "ssx_get_timing"]
-HOST_SYMBOLS = ["ssh_scene_create", "ssh_scene_destroy", "ssh_scene_desc", "ssh_xyza_to_srgba", "ssh_save_image",
+HOST_SYMBOLS = ["ssh_scene_create", "ssh_scene_create_ex", "ssh_scene_destroy", "ssh_scene_desc", "ssh_xyza_to_srgba", "ssh_save_image",
                 "ssh_load_png_rgb8", "ssh_free", "ssh_color_values", "ssh_last_error"]
 
 _hip = None
@@ -76,6 +79,8 @@ def host_lib():
         lib.ssh_last_error.restype = C.c_char_p
         lib.ssh_scene_create.argtypes = [C.c_char_p, C.c_char_p, C.c_int, vp, C.c_uint32, C.c_uint32, C.c_char_p,
                                          C.c_float, C.POINTER(vp)]
+        lib.ssh_scene_create_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_int, vp, C.c_uint32, C.c_uint32, C.c_char_p,
+                                            C.c_float, C.c_uint32, C.c_char_p, C.c_uint32, C.POINTER(vp)]
         lib.ssh_scene_destroy.argtypes = [vp]
         lib.ssh_scene_desc.restype = C.POINTER(SsxSceneDesc)
         lib.ssh_scene_desc.argtypes = [vp]

@@ -16,9 +16,9 @@ HIP_SRC = [os.path.join(PKG, "csrc", f) for f in ("ssx_api.hip",)]
 HIP_DEPS = [os.path.join(PKG, "csrc", f) for f in ("ssx_api.hip", "ssx_kernels.hip", "ssx_blob.h")] + [
     os.path.join(ROOT, "include", f) for f in ("ssx.h", "ssx_fmath.h")]
 HOST_SRC = [os.path.join(PKG, "host", f) for f in
-            ("spectrum.cpp", "color.cpp", "scene.cpp", "image_io.cpp", "renderer.cpp", "host_api.cpp")]
+            ("spectrum.cpp", "color.cpp", "jh2019.cpp", "scene.cpp", "image_io.cpp", "renderer.cpp", "host_api.cpp")]
 HOST_DEPS = HOST_SRC + [os.path.join(PKG, "host", f) for f in
-                        ("spectrum.hpp", "color.hpp", "scene.hpp", "image_io.hpp", "renderer.hpp")] + [
+                        ("spectrum.hpp", "color.hpp", "jh2019.hpp", "scene.hpp", "image_io.hpp", "renderer.hpp")] + [
     os.path.join(ROOT, "include", f) for f in ("ssx.h", "ssx_host.h")]
 CLI_SRC = os.path.join(PKG, "host", "main.cpp")
 CLI_BIN = os.path.join(ROOT, "simple-spectral")

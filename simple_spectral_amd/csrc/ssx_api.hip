@@ -34,6 +34,7 @@ struct ssx_ctx {
 	uint32_t* d_blob = nullptr;
 	uint32_t blob_words = 0;
 	std::vector<uint8_t*> d_textures;
+	float* d_jh_data = nullptr;
 	double* d_accum = nullptr;  size_t accum_pixels = 0;
 	SsxSampleRecord* d_samples = nullptr; size_t sample_slots = 0; // record capacity of the sample buffer
 	SsxFrame* d_frames = nullptr;
@@ -73,7 +74,7 @@ int fail(ssx_ctx* ctx, int code, const std::string& msg) { ctx->error = msg; ret
 uint32_t align4(uint32_t words) { return (words + 3u) & ~3u; }
 
 // Packs ssx_scene_desc into the blob layout of ssx_blob.h.
-int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>& d_tex, std::vector<uint32_t>& blob) {
+int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>& d_tex, const float* d_jh, std::vector<uint32_t>& blob) {
 	if (s->n_quads == 0 || s->n_quads > SSX_MAX_QUADS) return fail(ctx, SSX_ERR_SCENE, fmt("n_quads=%u outside 1..%u", s->n_quads, SSX_MAX_QUADS));
 	if (s->n_lights == 0) return fail(ctx, SSX_ERR_SCENE, "scene has no lights (reference asserts !lights.empty(), scene.cpp:30)");
 	if (s->n_textures > SSX_MAX_TEXTURES) return fail(ctx, SSX_ERR_SCENE, "too many textures");
@@ -115,6 +116,12 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	const uint32_t off_samples = off; off = align4(off + s->n_samples);
 	h.off_lut = off;       off = align4(off + 256u);
 	h.off_tex = off;       off = align4(off + s->n_textures * (uint32_t)(sizeof(SsxBlobTexture) / 4));
+	h.uplift = s->uplift;
+	if (s->uplift == SSX_UPLIFT_JH) {
+		h.jh_res = s->jh_res;
+		h.off_jh_scale = off;  off = align4(off + s->jh_res);
+		h.jh_data_lo = (uint32_t)(uintptr_t)d_jh; h.jh_data_hi = (uint32_t)((uint64_t)(uintptr_t)d_jh >> 32);
+	}
 	h.total_words = off;
 	if ((size_t)off * 4 > SSX_BLOB_MAX_BYTES) return fail(ctx, SSX_ERR_SCENE, fmt("scene tables need %u bytes of LDS (max %u)", off * 4, SSX_BLOB_MAX_BYTES));
 
@@ -163,6 +170,7 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	}
 	memcpy(blob.data() + off_samples, s->samples, 4 * (size_t)s->n_samples);
 	memcpy(blob.data() + h.off_lut, s->srgb_to_linear, 4 * 256);
+	if (s->uplift == SSX_UPLIFT_JH) memcpy(blob.data() + h.off_jh_scale, s->jh_scale, 4 * (size_t)s->jh_res);
 	SsxBlobTexture* bt = reinterpret_cast<SsxBlobTexture*>(blob.data() + h.off_tex);
 	for (uint32_t i = 0; i < s->n_textures; ++i) {
 		uint64_t p = (uint64_t)(uintptr_t)d_tex[i];
@@ -386,6 +394,7 @@ void ssx_destroy(ssx_ctx* ctx) {
 	if (ctx->worker.joinable()) { ctx->stop_flag.store(1); ctx->worker.join(); }
 	(void)hipSetDevice(ctx->device);
 	if (ctx->d_blob) (void)hipFree(ctx->d_blob);
+	if (ctx->d_jh_data) (void)hipFree(ctx->d_jh_data);
 	for (uint8_t* t : ctx->d_textures) (void)hipFree(t);
 	if (ctx->d_accum) (void)hipFree(ctx->d_accum);
 	if (ctx->d_samples) (void)hipFree(ctx->d_samples);
@@ -414,8 +423,17 @@ int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 		ctx->d_textures.push_back(d);
 		SSX_HIP(ctx, hipMemcpy(d, t.rgb, bytes, hipMemcpyHostToDevice));
 	}
+	if (s->uplift != SSX_UPLIFT_OURS && s->uplift != SSX_UPLIFT_JH) return fail(ctx, SSX_ERR_SCENE, "unsupported uplift variant (1 = basis, 3 = Jakob-Hanika)");
+	if (ctx->d_jh_data) { (void)hipFree(ctx->d_jh_data); ctx->d_jh_data = nullptr; }
+	if (s->uplift == SSX_UPLIFT_JH) {
+		// rgb2spec_load returns NULL for a missing table and the reference then crashes (color.cpp:144,220)
+		if (!s->jh_scale || !s->jh_data || s->jh_res < 2 || s->jh_res > 256) return fail(ctx, SSX_ERR_DATA, "Jakob-Hanika model missing or invalid");
+		size_t bytes = (size_t)3 * s->jh_res * s->jh_res * s->jh_res * 3 * sizeof(float);
+		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_jh_data, bytes));
+		SSX_HIP(ctx, hipMemcpy(ctx->d_jh_data, s->jh_data, bytes, hipMemcpyHostToDevice));
+	}
 	std::vector<uint32_t> blob;
-	int rc = pack_blob(ctx, s, ctx->d_textures, blob);
+	int rc = pack_blob(ctx, s, ctx->d_textures, ctx->d_jh_data, blob);
 	if (rc) return rc;
 	if (ctx->d_blob) { (void)hipFree(ctx->d_blob); ctx->d_blob = nullptr; }
 	SSX_HIP(ctx, hipMalloc((void**)&ctx->d_blob, blob.size() * 4));

@@ -49,6 +49,9 @@ struct SsxBlobHeader {
 	uint32_t n_textures;
 	uint32_t total_words;
 	uint32_t basis_one_grid; // the three basis tables share (low, delta_recip, n)
+	// Jakob-Hanika uplift (uplift == 3): scale[jh_res] in the blob, coefficient table in HBM
+	uint32_t uplift, jh_res, off_jh_scale, jh_data_lo, jh_data_hi;
+	uint32_t pad[3];
 };
 static_assert(sizeof(SsxBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 

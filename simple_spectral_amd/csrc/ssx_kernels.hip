@@ -170,6 +170,55 @@ __device__ __forceinline__ Hero spectrum_hero(const Lds& L, uint32_t spec_id, fl
 	return spectrum_hero(L, L.spectrum(spec_id), lambda_0, step);
 }
 
+// Jakob-Hanika uplift: util/color.cpp:203-232 -> jakob-and-hanika-2019/rgb2spec.c:56-133
+// (find_interval, trilinear fetch of the three coefficients, eval_precise without FMA: the
+// reference only fuses when __FMA__ is defined, which the x86-64 baseline build does not).
+__device__ __forceinline__ uint32_t jh_to_u32(float v) { return (v >= 0.0f && v < 4294967296.0f) ? (uint32_t)v : 0u; } // NaN/inf (black texel) -> 0
+__device__ __forceinline__ Hero jh_uplift(const Lds& L, float r, float g, float b, float lambda_0) {
+	const SsxBlobHeader& h = L.hdr();
+	const int res = (int)h.jh_res;
+	const float* scale_tab = reinterpret_cast<const float*>(L.w + h.off_jh_scale);
+	const float* data = reinterpret_cast<const float*>(((uint64_t)h.jh_data_hi << 32) | (uint64_t)h.jh_data_lo);
+	// largest component, later index wins ties (rgb2spec.c:82-86)
+	int i = 0;
+	float z = r;
+	if (g >= z) { i = 1; z = g; }
+	if (b >= z) { i = 2; z = b; }
+	const float c1v = (i == 0) ? g : ((i == 1) ? b : r), c2v = (i == 0) ? b : ((i == 1) ? r : g); // rgb[(i+1)%3], rgb[(i+2)%3]
+	const float scale = (float)(res - 1) / z;
+	const float x = c1v * scale, y = c2v * scale;
+	const uint32_t xi = min(jh_to_u32(x), (uint32_t)(res - 2)), yi = min(jh_to_u32(y), (uint32_t)(res - 2));
+	// rgb2spec_find_interval(model->scale, res, z)
+	int left = 0, last_interval = res - 2, size = last_interval;
+	while (size > 0) {
+		const int half = size >> 1, middle = left + half + 1;
+		if (scale_tab[middle] < z) { left = middle; size -= half + 1; }
+		else size = half;
+	}
+	const uint32_t zi = (uint32_t)min(left, last_interval);
+	const uint32_t ures = (uint32_t)res;
+	const uint32_t offset = ((((uint32_t)i * ures + zi) * ures + yi) * ures + xi) * 3u;
+	const uint32_t dx = 3u, dy = 3u * ures, dz = 3u * ures * ures;
+	const float x1 = x - (float)xi, x0 = 1.0f - x1, y1 = y - (float)yi, y0 = 1.0f - y1;
+	const float z1 = (z - scale_tab[zi]) / (scale_tab[zi + 1u] - scale_tab[zi]), z0 = 1.0f - z1;
+	float coeff[3];
+#pragma unroll
+	for (uint32_t j = 0; j < 3u; ++j) {
+		const float* d = data + offset + j;
+		coeff[j] = ((d[0] * x0 + d[dx] * x1) * y0 + (d[dy] * x0 + d[dy + dx] * x1) * y1) * z0 +
+		           ((d[dz] * x0 + d[dz + dx] * x1) * y0 + (d[dz + dy] * x0 + d[dz + dy + dx] * x1) * y1) * z1;
+	}
+	Hero out;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const float lambda = lambda_0 + (float)k * h.lambda_step; // color.cpp:227
+		const float xx = (coeff[0] * lambda + coeff[1]) * lambda + coeff[2];
+		const float yy = 1.0f / __builtin_sqrtf(xx * xx + 1.0f);
+		out.v[k] = (0.5f * xx) * yy + 0.5f;
+	}
+	return out;
+}
+
 // material.cpp:45-97 + util/color.cpp:167-173 ("ours" basis uplift)
 __device__ __forceinline__ Hero texture_sample(const Lds& L, uint32_t tex_index, float st_x, float st_y, float lambda_0) {
 	const SsxBlobTexture t = L.texture(tex_index);
@@ -183,6 +232,7 @@ __device__ __forceinline__ Hero texture_sample(const Lds& L, uint32_t tex_index,
 	const uint8_t* px = rgb + 3u * ((size_t)j * (size_t)t.w + (size_t)i);
 	float r = L.lut(px[0]), g = L.lut(px[1]), b = L.lut(px[2]);
 	const SsxBlobHeader& h = L.hdr();
+	if (h.uplift == 3u) return jh_uplift(L, r, g, b, lambda_0); // RENDER_MODE_SPECTRAL_JH (wave-uniform)
 	Hero br, bg, bb;
 	const SsxBlobSpectrum sr = L.spectrum(h.spec_basis_r), sg = L.spectrum(h.spec_basis_g), sb = L.spectrum(h.spec_basis_b);
 	if (h.basis_one_grid) { // wave-uniform: r, g, b tables have the same (low, delta_recip, n)

@@ -11,6 +11,7 @@
 
 struct ssh_scene {
 	std::unique_ptr<ssx::ColorData> color;
+	std::unique_ptr<ssx::JHModel> jh;
 	std::unique_ptr<ssx::Scene> scene;
 };
 
@@ -23,14 +24,29 @@ extern "C" {
 
 const char* ssh_last_error(void) { return g_error.c_str(); }
 
-int ssh_scene_create(const char* scene_name, const char* data_dir, int observer,
-                     const uint8_t* tex_rgb, uint32_t tex_w, uint32_t tex_h, const char* texture_path,
-                     float light_scale, ssh_scene** out) {
+int ssh_scene_create_ex(const char* scene_name, const char* data_dir, int observer,
+                        const uint8_t* tex_rgb, uint32_t tex_w, uint32_t tex_h, const char* texture_path,
+                        float light_scale, uint32_t uplift, const char* jh_coeff_path, uint32_t jh_res,
+                        ssh_scene** out) {
 	if (!scene_name || !data_dir || !out) { g_error = "NULL argument"; return SSX_ERR_ARG; }
 	*out = nullptr;
 	try {
 		auto s = std::make_unique<ssh_scene>();
 		s->color = std::make_unique<ssx::ColorData>(data_dir, observer);
+		if (uplift == SSX_UPLIFT_JH) {
+			if (observer != 1931) throw ssx::HostError{ -3, "Only our algorithm currently implements support for the newest CIE standard observer!" };
+			const std::string path = jh_coeff_path ? jh_coeff_path : "";
+			bool loaded = false;
+			if (!path.empty()) {
+				try { s->jh = std::make_unique<ssx::JHModel>(ssx::jh_load(path)); loaded = true; } catch (const ssx::HostError&) {}
+			}
+			if (!loaded) {
+				s->jh = std::make_unique<ssx::JHModel>(ssx::jh_optimize(*s->color, jh_res ? jh_res : 64u));
+				if (!path.empty()) ssx::jh_save(*s->jh, path);
+			}
+		} else if (uplift != SSX_UPLIFT_OURS) {
+			throw ssx::HostError{ -3, "unsupported uplift variant" };
+		}
 		ssx::Texture tex;
 		const ssx::Texture* texp = nullptr;
 		if (tex_rgb && tex_w && tex_h) {
@@ -41,7 +57,7 @@ int ssh_scene_create(const char* scene_name, const char* data_dir, int observer,
 			tex = ssx::load_png_rgb8(texture_path);
 			texp = &tex;
 		}
-		s->scene = std::make_unique<ssx::Scene>(*s->color, scene_name, data_dir, texp, light_scale);
+		s->scene = std::make_unique<ssx::Scene>(*s->color, scene_name, data_dir, texp, light_scale, s->jh.get());
 		*out = s.release();
 		return SSX_OK;
 	} catch (const ssx::HostError& e) {
@@ -50,6 +66,12 @@ int ssh_scene_create(const char* scene_name, const char* data_dir, int observer,
 		g_error = e.what();
 		return SSX_ERR_DATA;
 	}
+}
+
+int ssh_scene_create(const char* scene_name, const char* data_dir, int observer,
+                     const uint8_t* tex_rgb, uint32_t tex_w, uint32_t tex_h, const char* texture_path,
+                     float light_scale, ssh_scene** out) {
+	return ssh_scene_create_ex(scene_name, data_dir, observer, tex_rgb, tex_w, tex_h, texture_path, light_scale, SSX_UPLIFT_OURS, nullptr, 0, out);
 }
 
 void ssh_scene_destroy(ssh_scene* scene) { delete scene; }

@@ -88,7 +88,18 @@ Renderer::Renderer(const Options& opts) : options(opts), framebuffer(opts.res), 
 		tex = load_png_rgb8(path);
 		texp = &tex;
 	}
-	scene = std::make_unique<Scene>(*color, options.scene_name, options.data_dir, texp, options.light_scale);
+	if (options.uplift == SSX_UPLIFT_JH) {
+		const std::string path = options.jh_coeff_path.empty() ? options.data_dir + "/jakob-and-hanika-2019-srgb.coeff" : options.jh_coeff_path;
+		try { jh = std::make_unique<JHModel>(jh_load(path)); }
+		catch (const HostError&) { // the authors' table is not in the repository: fit our own once and keep it
+			std::fprintf(stderr, "Fitting Jakob-Hanika coefficients (\"%s\" not found) ...\n", path.c_str());
+			jh = std::make_unique<JHModel>(jh_optimize(*color, 64));
+			try { jh_save(*jh, path); } catch (const HostError&) {}
+		}
+	} else if (options.uplift != SSX_UPLIFT_OURS) {
+		throw HostError{ -3, "unsupported uplift variant" };
+	}
+	scene = std::make_unique<Scene>(*color, options.scene_name, options.data_dir, texp, options.light_scale, jh.get());
 
 	api_ = std::make_unique<Api>(options.hip_library.empty() ? default_hip_library() : options.hip_library);
 	const int n = options.gpus < 1 ? 1 : options.gpus;

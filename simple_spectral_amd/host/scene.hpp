@@ -5,6 +5,7 @@
 #pragma once
 #include "../../include/ssx.h"
 #include "color.hpp"
+#include "jh2019.hpp"
 
 #include <cstdint>
 #include <memory>
@@ -29,7 +30,10 @@ class Scene {
 public:
 	// name: "cornell" | "cornell-srgb" | "plane-srgb" (src/renderer.cpp:17-38; anything else -> -3).
 	// texture: decoded image for the -srgb scenes; light_scale: `lightsc` of src/scene.cpp:291-293.
-	Scene(const ColorData& color, const std::string& name, const std::string& data_dir, const Texture* texture, float light_scale);
+	// jh: Jakob-Hanika model to uplift texels with (RENDER_MODE_SPECTRAL_JH), or nullptr for the
+	// basis uplift (RENDER_MODE_SPECTRAL_OURS, the reference's default).
+	Scene(const ColorData& color, const std::string& name, const std::string& data_dir, const Texture* texture, float light_scale,
+	      const JHModel* jh = nullptr);
 
 	const ssx_scene_desc& desc() const { return desc_; }
 	Camera camera;
@@ -54,6 +58,7 @@ private:
 	std::vector<Texture> textures_;
 	std::vector<ssx_texture> texture_descs_;
 	uint32_t zero_emission_ = 0;
+	const JHModel* jh_ = nullptr;
 	ssx_scene_desc desc_{};
 };
 

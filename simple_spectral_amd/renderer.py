@@ -41,6 +41,9 @@ class Options:
     seed: int = 0
     texture: Optional[str] = None        # PNG path; default per scene below
     light_scale: float = 30.0            # lightsc (src/scene.cpp:291-293)
+    uplift: str = "ours"                 # RENDER_MODE_SPECTRAL_ALGNUM: "ours" (1) | "jh" (3, Jakob-Hanika 2019)
+    jh_res: int = 64                     # resolution of the fitted JH model when no coefficient file exists
+    jh_coeff_path: Optional[str] = None  # data/jakob-and-hanika-2019-srgb.coeff in the reference (missing blob)
     device: int = 0
     tile_first: int = 0
     tile_stride: int = 1
@@ -62,7 +65,8 @@ def default_texture(data_dir):
 class Scene:
     """Host-prepared scene + colour tables (libssx_host.so)."""
 
-    def __init__(self, name, observer=1931, texture=None, light_scale=30.0, data_dir=DEFAULT_DATA_DIR):
+    def __init__(self, name, observer=1931, texture=None, light_scale=30.0, data_dir=DEFAULT_DATA_DIR,
+                 uplift="ours", jh_res=64, jh_coeff_path=None):
         lib = _capi.host_lib()
         self._lib = lib
         self._h = C.c_void_p()
@@ -76,8 +80,12 @@ class Scene:
                 if tex_path and not os.path.isabs(tex_path) and not os.path.exists(tex_path):
                     tex_path = os.path.join(data_dir, "scenes", tex_path)
         tp, tw, th = (self._tex.ctypes.data, self._tex.shape[1], self._tex.shape[0]) if self._tex is not None else (None, 0, 0)
-        rc = lib.ssh_scene_create(name.encode(), data_dir.encode(), observer, tp, tw, th,
-                                  tex_path.encode() if tex_path else None, C.c_float(light_scale), C.byref(self._h))
+        if uplift not in ("ours", "jh"):
+            raise SsxError(_capi.SSX_ERR_SCENE, "unsupported uplift %r (ours | jh)" % (uplift,))
+        rc = lib.ssh_scene_create_ex(name.encode(), data_dir.encode(), observer, tp, tw, th,
+                                     tex_path.encode() if tex_path else None, C.c_float(light_scale),
+                                     _capi.SSX_UPLIFT_JH if uplift == "jh" else _capi.SSX_UPLIFT_OURS,
+                                     jh_coeff_path.encode() if jh_coeff_path else None, jh_res, C.byref(self._h))
         if rc != 0:
             raise SsxError(rc, lib.ssh_last_error().decode())
         self.name = name
@@ -85,6 +93,15 @@ class Scene:
     @property
     def desc(self):
         return self._lib.ssh_scene_desc(self._h)
+
+    def jh_model(self):
+        """(res, scale[res], data[3*res^3*3]) of the Jakob-Hanika model in use, or None."""
+        d = self.desc.contents
+        if d.uplift != _capi.SSX_UPLIFT_JH:
+            return None
+        res = int(d.jh_res)
+        return (res, np.ctypeslib.as_array(d.jh_scale, shape=(res,)).copy(),
+                np.ctypeslib.as_array(d.jh_data, shape=(3 * res ** 3 * 3,)).copy())
 
     def xyza_to_srgba(self, xyza):
         xyza = np.ascontiguousarray(xyza, dtype=np.float32)
@@ -119,7 +136,8 @@ class Renderer:
 
     def __init__(self, options: Options):
         self.options = options
-        self.scene = Scene(options.scene_name, options.observer, options.texture, options.light_scale, options.data_dir)
+        self.scene = Scene(options.scene_name, options.observer, options.texture, options.light_scale, options.data_dir,
+                           options.uplift, options.jh_res, options.jh_coeff_path)
         self._lib = _capi.hip_lib()
         self._ctx = C.c_void_p()
         rc = self._lib.ssx_create(options.device, C.byref(self._ctx))

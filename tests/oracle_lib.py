@@ -89,6 +89,10 @@ def load(variant=""):
     lib.orc_color_create.restype = vp
     lib.orc_color_create.argtypes = [C.c_char_p, C.c_int]
     lib.orc_color_destroy.argtypes = [vp]
+    lib.orc_color_set_jh.argtypes = [vp, C.c_int, vp, vp]
+    lib.orc_jh_fetch.argtypes = [vp, f32p, f32p]
+    lib.orc_jh_eval_precise.restype = C.c_float
+    lib.orc_jh_eval_precise.argtypes = [f32p, C.c_float]
     lib.orc_scene_create.restype = vp
     lib.orc_scene_create.argtypes = [vp, C.c_char_p, C.c_char_p, vp, C.c_int, C.c_int, C.c_float]
     lib.orc_scene_destroy.argtypes = [vp]
@@ -161,11 +165,17 @@ class Oracle:
     """Colour tables + one scene, with render helpers.  observer: 1931 | 2006."""
 
     def __init__(self, scene="cornell-srgb", observer=1931, texture="test-img.png", light_scale=30.0,
-                 variant="", data_dir=DATA_DIR):
+                 variant="", data_dir=DATA_DIR, jh=None):
+        """jh: (res, scale, data) Jakob-Hanika model -> RENDER_MODE_SPECTRAL_JH; None -> "ours"."""
         self.lib = load(variant)
         self.color = self.lib.orc_color_create(data_dir.encode(), observer)
         if not self.color:
             raise RuntimeError(self.lib.orc_last_error().decode())
+        if jh is not None:
+            res, scale, data = jh
+            scale = np.ascontiguousarray(scale, dtype=np.float32); data = np.ascontiguousarray(data, dtype=np.float32)
+            if self.lib.orc_color_set_jh(self.color, int(res), scale.ctypes.data, data.ctypes.data) != 0:
+                raise RuntimeError(self.lib.orc_last_error().decode())
         tex = None
         if texture is not None and scene != "cornell":
             tex = texture if isinstance(texture, np.ndarray) else load_texture(

@@ -167,3 +167,29 @@ def test_error_codes():
     bad = _capi.SsxSceneDesc(); bad.struct_size = 12
     assert lib.ssx_upload_scene(ctx, C.byref(bad)) == _capi.SSX_ERR_ARG
     lib.ssx_destroy(ctx)
+
+
+def same_or_both_nan(a, b):
+    """Bit equality, except that NaN matches NaN of any payload (black texels make the reference's
+    Jakob-Hanika path divide by zero, rgb2spec.c:88-91, so both sides hold NaN there)."""
+    return ((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))).all()
+
+
+@pytest.mark.parametrize("scene", ["cornell-srgb", "plane-srgb"])
+def test_jakob_hanika_uplift_bit_exact(scene):
+    """BASELINE configs[2] names the Jakob-Hanika uplift (RENDER_MODE_SPECTRAL_ALGNUM 3): texels go
+    through rgb2spec_fetch / rgb2spec_eval_precise instead of the basis spectra."""
+    r = Renderer(Options(scene_name=scene, res=(48, 40), spp=5, seed=4, texture="test-img.png", uplift="jh", jh_res=16))
+    r.render_start(); r.render_wait()
+    ref = ol.Oracle(scene, texture="test-img.png", jh=r.scene.jh_model()).render(48, 40, 5, seed=4)
+    assert same_or_both_nan(r.xyza, ref)
+    assert np.isfinite(ref).mean() > 0.9
+    ours = ol.Oracle(scene, texture="test-img.png").render(48, 40, 5, seed=4)
+    assert not np.array_equal(bits(ours), bits(ref))        # the variant really changes textured pixels
+
+
+def test_jakob_hanika_lizard_texture_config1_shape():
+    r = Renderer(Options(scene_name="cornell-srgb", res=(128, 128), spp=16, texture="crystal-lizard-512.png", uplift="jh", jh_res=32))
+    r.render_start(); r.render_wait()
+    ref = ol.Oracle("cornell-srgb", texture="crystal-lizard-512.png", jh=r.scene.jh_model()).render(128, 128, 16)
+    assert same_or_both_nan(r.xyza, ref)

@@ -133,3 +133,33 @@ def test_missing_hip_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(sbuild, "HIP_LIB", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU or PyTorch fallback"):
         _capi.hip_lib()
+
+
+def test_jakob_hanika_model_host_vs_oracle_and_round_trip(tmp_path):
+    """RENDER_MODE_SPECTRAL_JH (config 3): the table is fitted by the build's own optimiser (the
+    authors' .coeff blob is missing from the reference); fetch/eval must equal the oracle's
+    restatement of rgb2spec.c bit for bit, and the uplift must round-trip colours."""
+    path = str(tmp_path / "m.coeff")
+    s = Scene("cornell-srgb", texture="test-img.png", uplift="jh", jh_res=16, jh_coeff_path=path)
+    res, scale, data = s.jh_model()
+    assert res == 16 and os.path.getsize(path) == 8 + 4 * 16 + 4 * 3 * 16 ** 3 * 3 and open(path, "rb").read(4) == b"SPEC"
+    s2 = Scene("cornell-srgb", texture="test-img.png", uplift="jh", jh_coeff_path=path)   # loads the file
+    assert np.array_equal(s2.jh_model()[2], data)
+    o = ol.Oracle("cornell-srgb", texture="test-img.png", jh=(res, scale, data))
+    rs = np.random.RandomState(5)
+    worst = 0.0
+    xb, yb, zb = (o.spectrum(n)[0].astype(np.float64) for n in ("xbar", "ybar", "zbar"))
+    d65 = o.spectrum("D65_rad")[0].astype(np.float64)[16:]          # 380..780 of the 300..780 table
+    m = np.array([o.lib.orc_color_matrix(o.color, b"xyz_to_lrgb")[i] for i in range(9)], dtype=np.float64).reshape(3, 3).T
+    for _ in range(300):
+        rgb = rs.uniform(0.03, 0.97, 3).astype(np.float32)
+        co = (C.c_float * 3)()
+        o.lib.orc_jh_fetch(o.color, (C.c_float * 3)(*rgb), co)
+        spec = np.array([o.lib.orc_jh_eval_precise(co, np.float32(380 + 5 * k)) for k in range(81)], dtype=np.float64)
+        assert spec.min() >= 0.0 and spec.max() <= 1.0
+        xyz = np.array([(spec * d65 * b).sum() * 5.0 for b in (xb, yb, zb)])
+        worst = max(worst, np.abs(m @ xyz - rgb).max())
+    assert worst < 0.05          # res 16 is coarse; res 64 reaches ~1e-3 (DESIGN.md)
+    with pytest.raises(SsxError) as e:
+        Scene("cornell-srgb", texture="test-img.png", uplift="jh", observer=2006)
+    assert e.value.code == -3    # src/stdafx.hpp:107-109
