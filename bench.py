@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel PER GPU")
     ap.add_argument("--observer", type=int, default=1931)
+    ap.add_argument("--uplift", default="ours", choices=["ours", "jh"])
+    ap.add_argument("--batch", type=int, default=0, help="spp per pipelined batch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -92,23 +94,41 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: simple_spectral_amd has no CPU path")
+    # SSX_BENCH_TEST_ONE_GPU=1: plumbing test of the N>1 path on a 1-GPU box (all ranks share
+    # device 0 and the reduce goes through gloo on host copies); never set by the driver.
+    test_one_gpu = os.environ.get("SSX_BENCH_TEST_ONE_GPU") == "1"
+    if test_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if test_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     W = H = args.res
     spp_total = args.spp * world
     texture = "crystal-lizard-512.png"
     r = Renderer(Options(scene_name=args.scene, res=(W, H), spp=spp_total, texture=texture, device=local_rank,
-                         tile_first=rank, tile_stride=world, seed=0, observer=args.observer))
+                         tile_first=rank, tile_stride=world, seed=0, observer=args.observer, uplift=args.uplift,
+                         spp_per_launch=args.batch))
     out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
+
+    def reduce_to_rank0():
+        # the one exchange step of the path: sum of the per-rank framebuffers (RCCL over xGMI)
+        if test_one_gpu:
+            h = out.cpu()
+            dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
+            out.copy_(h)
+        else:
+            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
 
     def step():
         r.render_device(out.data_ptr(), stream.cuda_stream)
         if world > 1:
-            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+            reduce_to_rank0()
 
     def fence():
         if world > 1:
@@ -128,14 +148,14 @@ def main():
         r.render_device(out.data_ptr(), stream.cuda_stream)
         ev[k][1].record(stream)
         if world > 1:
-            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+            reduce_to_rank0()
     fence()
     elapsed = time.perf_counter() - t0
     pipeline_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
     stage_ms = {k: v / max(args.steps, 1) for k, v in r.get_timing().items()}
     kernel_ms = stage_ms["path"]  # the dominant kernel (ssx_render_kernel), mean per launch
     if world > 1:
-        tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cpu" if test_one_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(tt[0]), float(tt[1])
 
@@ -153,7 +173,7 @@ def main():
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s %dx%d spp=%d/GPU (total spp %d) CIE%d hero-wavelength megakernel" % (args.scene, W, H, args.spp, spp_total, args.observer),
+            "config": {"workload": "%s %dx%d spp=%d/GPU (total spp %d) CIE%d uplift=%s hero-wavelength megakernel" % (args.scene, W, H, args.spp, spp_total, args.observer, args.uplift),
                        "parallelism": "tile-split x%d + RCCL reduce" % world if world > 1 else "single GPU",
                        "texture": texture, "seed": 0},
             "roofline": {"bound": "valu", "achieved": round(achieved_tflops, 3), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",

@@ -49,11 +49,16 @@ struct ssx_ctx {
 	int worker_rc = 0;
 	ssx_render_params cur{};
 
-	// optional per-kernel timing (ssx_set_timing): events on the launch stream around each stage
+	// resolve/accumulate of one batch run on aux_stream while the next batch's generate/path
+	// kernels run on the caller's stream (the former is HBM-bound, the latter VALU-bound)
+	hipStream_t aux_stream = nullptr;
+	hipEvent_t ev_start = nullptr, ev_front[2] = {}, ev_back[2] = {};
+
+	// optional per-kernel timing (ssx_set_timing): events around each stage of each batch
 	bool timing = false;
-	hipEvent_t ev[5] = {};
+	std::vector<hipEvent_t> ev_pool;   // 6 per batch: gen0, gen1=path0, path1 | res0, res1=acc0, acc1
+	size_t ev_used = 0;
 	float stage_ms[4] = { 0, 0, 0, 0 };
-	bool ev_pending = false;
 
 	std::string error;
 };
@@ -244,73 +249,134 @@ int ensure_samples(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t n_k) {
 	return SSX_OK;
 }
 
-// adds the stage durations of the last recorded launch to ctx->stage_ms
+// adds the stage durations of the recorded batches to ctx->stage_ms
 int collect_timing(ssx_ctx* ctx) {
-	if (!ctx->ev_pending) return SSX_OK;
-	SSX_HIP(ctx, hipEventSynchronize(ctx->ev[4]));
-	for (int k = 0; k < 4; ++k) {
-		float ms = 0;
-		SSX_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]));
-		ctx->stage_ms[k] += ms;
+	for (size_t b = 0; b + 6 <= ctx->ev_used; b += 6) {
+		hipEvent_t* e = &ctx->ev_pool[b];
+		SSX_HIP(ctx, hipEventSynchronize(e[2]));
+		SSX_HIP(ctx, hipEventSynchronize(e[5]));
+		const int pairs[4][2] = { { 0, 1 }, { 1, 2 }, { 3, 4 }, { 4, 5 } };
+		for (int k = 0; k < 4; ++k) {
+			float ms = 0;
+			SSX_HIP(ctx, hipEventElapsedTime(&ms, e[pairs[k][0]], e[pairs[k][1]]));
+			ctx->stage_ms[k] += ms;
+		}
 	}
-	ctx->ev_pending = false;
+	ctx->ev_used = 0;
 	return SSX_OK;
 }
 
-// samples [k0,k1) of every owned pixel: generate -> path megakernel -> resolve (fold + XYZ) -> ordered f64 accumulation
-int launch_range(ssx_ctx* ctx, LaunchPlan& pl, uint32_t k0, uint32_t k1, hipStream_t stream) {
-	SsxKernelArgs& a = pl.args;
-	if (a.my_tiles == 0 || k1 <= k0) return SSX_OK;
+int timing_events(ssx_ctx* ctx, hipEvent_t** out) {
+	if (ctx->ev_used + 6 > 6 * 64) { int r = collect_timing(ctx); if (r) return r; }
+	while (ctx->ev_pool.size() < ctx->ev_used + 6) {
+		hipEvent_t e;
+		SSX_HIP(ctx, hipEventCreate(&e));
+		ctx->ev_pool.push_back(e);
+	}
+	*out = &ctx->ev_pool[ctx->ev_used];
+	ctx->ev_used += 6;
+	return SSX_OK;
+}
+
+// One batch = samples [k0,k1) of every owned pixel, with its records and frames at record offset
+// rec_off of the buffers.  front = generate -> path megakernel; back = resolve (fold + XYZ) ->
+// ordered f64 accumulation.
+struct Batch { SsxKernelArgs a; uint32_t units; uint64_t n_rec; hipEvent_t* tev; };
+
+Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1, uint64_t rec_off) {
+	Batch b{};
+	b.a = pl.args;
+	SsxKernelArgs& a = b.a;
 	const uint32_t n_k = k1 - k0;
 	a.k0 = k0; a.k1 = k1;
-	a.samples = ctx->d_samples;
-	a.frames = ctx->d_frames;
+	a.samples = ctx->d_samples + rec_off;
+	a.frames = ctx->d_frames + rec_off * SSX_MAX_FRAMES;
 	a.n_records = (uint64_t)a.my_tiles * n_k * 64u;
+	uint64_t g = ((uint64_t)n_k * a.my_tiles + kTargetUnits - 1) / kTargetUnits;
+	a.group_spp = (uint32_t)(g < 8 ? 8 : g);
+	if (a.group_spp > n_k) a.group_spp = n_k;
+	a.n_groups = (n_k + a.group_spp - 1) / a.group_spp;
+	b.units = a.my_tiles * a.n_groups;
+	b.n_rec = a.n_records;
+	return b;
+}
+
+int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stream) {
 #ifdef SSX_PROFILE_REGIONS
 	{
 		static uint64_t* d_prof = nullptr;
 		if (!d_prof) { SSX_HIP(ctx, hipMalloc((void**)&d_prof, 16 * sizeof(uint64_t))); }
 		SSX_HIP(ctx, hipMemsetAsync(d_prof, 0, 16 * sizeof(uint64_t), stream));
-		a.prof = d_prof;
+		b.a.prof = d_prof;
 	}
 #endif
-	uint64_t g = ((uint64_t)n_k * a.my_tiles + kTargetUnits - 1) / kTargetUnits;
-	a.group_spp = (uint32_t)(g < 8 ? 8 : g);
-	if (a.group_spp > n_k) a.group_spp = n_k;
-	a.n_groups = (n_k + a.group_spp - 1) / a.group_spp;
-	const uint32_t units = a.my_tiles * a.n_groups;
-	const uint64_t n_rec = (uint64_t)a.my_tiles * n_k * 64u;
-	if (ctx->timing) {
-		if (ctx->ev_pending) { int r = collect_timing(ctx); if (r) return r; }
-		for (hipEvent_t& e : ctx->ev) if (!e) SSX_HIP(ctx, hipEventCreate(&e));
-		SSX_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
-	}
-	hipLaunchKernelGGL(ssx_generate_kernel, dim3((uint32_t)((n_rec + 255u) / 256u)), dim3(256), 0, stream, a);
+	if (ctx->timing) { int r = timing_events(ctx, &b.tev); if (r) return r; SSX_HIP(ctx, hipEventRecord(b.tev[0], stream)); }
+	hipLaunchKernelGGL(ssx_generate_kernel, dim3((uint32_t)((b.n_rec + 255u) / 256u)), dim3(256), 0, stream, b.a);
 	SSX_HIP(ctx, hipGetLastError());
-	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
-	hipLaunchKernelGGL(ssx_render_kernel, dim3((units + 3u) / 4u), dim3(256), pl.lds_bytes, stream, a);
+	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[1], stream));
+	hipLaunchKernelGGL(ssx_render_kernel, dim3((b.units + 3u) / 4u), dim3(256), pl.lds_bytes, stream, b.a);
 	SSX_HIP(ctx, hipGetLastError());
-	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
-	{
-		const uint64_t want = (n_rec + 255u) / 256u;
-		hipLaunchKernelGGL(ssx_resolve_kernel, dim3((uint32_t)(want < 8192u ? want : 8192u)), dim3(256), pl.lds_bytes, stream, a);
-	}
+	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[2], stream));
+	return SSX_OK;
+}
+
+int enqueue_back(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stream) {
+	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[3], stream));
+	const uint64_t want = (b.n_rec + 255u) / 256u;
+	hipLaunchKernelGGL(ssx_resolve_kernel, dim3((uint32_t)(want < 8192u ? want : 8192u)), dim3(256), pl.lds_bytes, stream, b.a);
 	SSX_HIP(ctx, hipGetLastError());
-	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
-	hipLaunchKernelGGL(ssx_accumulate_kernel, dim3((a.my_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, a, ctx->d_accum);
+	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[4], stream));
+	hipLaunchKernelGGL(ssx_accumulate_kernel, dim3((b.a.my_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, b.a, ctx->d_accum);
 	SSX_HIP(ctx, hipGetLastError());
-	if (ctx->timing) { SSX_HIP(ctx, hipEventRecord(ctx->ev[4], stream)); ctx->ev_pending = true; }
+	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[5], stream));
 #ifdef SSX_PROFILE_REGIONS
 	{
 		uint64_t h[16];
 		SSX_HIP(ctx, hipStreamSynchronize(stream));
-		SSX_HIP(ctx, hipMemcpy(h, a.prof, sizeof h, hipMemcpyDeviceToHost));
+		SSX_HIP(ctx, hipMemcpy(h, b.a.prof, sizeof h, hipMemcpyDeviceToHost));
 		static const char* names[12] = { "refill", "trace_primary", "hit+albedo", "sample_light", "trace_shadow", "nee_contrib", "bsdf_sample", "frame_push", "finish/fold", "total_wave_cycles", "wave_iterations", "active_lanes" };
 		fprintf(stderr, "[region profile] ");
 		for (int r = 0; r < 12; ++r) fprintf(stderr, "%s=%llu ", names[r], (unsigned long long)h[r]);
 		fprintf(stderr, "\n");
 	}
 #endif
+	return SSX_OK;
+}
+
+// everything in stream order (used by the asynchronous worker, which synchronises per chunk anyway)
+int launch_range(ssx_ctx* ctx, LaunchPlan& pl, uint32_t k0, uint32_t k1, hipStream_t stream) {
+	if (pl.args.my_tiles == 0 || k1 <= k0) return SSX_OK;
+	Batch b = make_batch(ctx, pl, k0, k1, 0);
+	int rc = enqueue_front(ctx, pl, b, stream);
+	if (rc) return rc;
+	return enqueue_back(ctx, pl, b, stream);
+}
+
+// Samples [0,spp) in batches of `batch` spp, double-buffered: the back half of batch i (HBM-bound)
+// runs on ctx->aux_stream concurrently with the front half of batch i+1 (VALU-bound) on `stream`.
+// Accumulation order is preserved because the back halves execute in batch order on one stream.
+int launch_pipelined(ssx_ctx* ctx, LaunchPlan& pl, uint32_t spp, uint32_t batch, hipStream_t stream) {
+	if (pl.args.my_tiles == 0) return SSX_OK;
+	const uint64_t half = (uint64_t)pl.args.my_tiles * 64u * batch; // records per buffer half
+	if (!ctx->aux_stream) SSX_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+	auto mk = [&](hipEvent_t& e) -> int { if (!e) SSX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); return SSX_OK; };
+	int rc;
+	if ((rc = mk(ctx->ev_start)) || (rc = mk(ctx->ev_front[0])) || (rc = mk(ctx->ev_front[1])) || (rc = mk(ctx->ev_back[0])) || (rc = mk(ctx->ev_back[1]))) return rc;
+	SSX_HIP(ctx, hipEventRecord(ctx->ev_start, stream));          // orders aux after the caller's earlier work (accum memset)
+	SSX_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_start, 0));
+	uint32_t n = 0;
+	for (uint32_t k0 = 0; k0 < spp; k0 += batch, ++n) {
+		const uint32_t k1 = (spp - k0 < batch) ? spp : k0 + batch;
+		const uint32_t h = n & 1u;
+		if (n >= 2) SSX_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_back[h], 0)); // this half's previous tenant is resolved
+		Batch b = make_batch(ctx, pl, k0, k1, h * half);
+		if ((rc = enqueue_front(ctx, pl, b, stream))) return rc;
+		SSX_HIP(ctx, hipEventRecord(ctx->ev_front[h], stream));
+		SSX_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_front[h], 0));
+		if ((rc = enqueue_back(ctx, pl, b, ctx->aux_stream))) return rc;
+		SSX_HIP(ctx, hipEventRecord(ctx->ev_back[h], ctx->aux_stream));
+	}
+	if (n) SSX_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_back[(n - 1) & 1u], 0)); // aux is serial: the last back half ends last
 	return SSX_OK;
 }
 
@@ -400,7 +466,9 @@ void ssx_destroy(ssx_ctx* ctx) {
 	if (ctx->d_samples) (void)hipFree(ctx->d_samples);
 	if (ctx->d_frames) (void)hipFree(ctx->d_frames);
 	if (ctx->d_out) (void)hipFree(ctx->d_out);
-	for (hipEvent_t e : ctx->ev) if (e) (void)hipEventDestroy(e);
+	for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+	for (hipEvent_t e : { ctx->ev_start, ctx->ev_front[0], ctx->ev_front[1], ctx->ev_back[0], ctx->ev_back[1] }) if (e) (void)hipEventDestroy(e);
+	if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -455,13 +523,18 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	if ((rc = ensure_buffers(ctx, pixels, false))) return rc;
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, pixels * 4 * sizeof(double), stream));
 	LaunchPlan pl = make_plan(ctx, p);
-	uint32_t chunk = p->spp_per_launch ? p->spp_per_launch : p->spp;
-	if (chunk > pl.max_spp_per_launch) chunk = pl.max_spp_per_launch;
-	if ((rc = ensure_samples(ctx, pl, chunk < p->spp ? chunk : p->spp))) return rc;
-	for (uint32_t k0 = 0; k0 < p->spp; k0 += chunk) {
-		uint32_t k1 = (p->spp - k0 < chunk) ? p->spp : k0 + chunk;
-		if ((rc = launch_range(ctx, pl, k0, k1, stream))) return rc;
+	// One batch when the whole render fits the buffer budget (measured best: the path kernel fills
+	// every SIMD's register file, so a concurrently enqueued resolve kernel only runs in its tail
+	// anyway); otherwise double-buffered batches of half the budget each.
+	uint32_t batch = p->spp_per_launch ? p->spp_per_launch : p->spp;
+	if (batch > p->spp) batch = p->spp;
+	if (batch > pl.max_spp_per_launch) batch = pl.max_spp_per_launch;
+	if (batch < p->spp) {
+		const uint32_t cap = pl.max_spp_per_launch / 2u ? pl.max_spp_per_launch / 2u : 1u;
+		if (batch > cap) batch = cap;
 	}
+	if ((rc = ensure_samples(ctx, pl, batch * (batch < p->spp ? 2u : 1u)))) return rc;
+	if ((rc = launch_pipelined(ctx, pl, p->spp, batch, stream))) return rc;
 	return launch_finalize(ctx, p, (float*)d_xyza_out, stream);
 }
 
@@ -512,7 +585,7 @@ int ssx_set_timing(ssx_ctx* ctx, int enable) {
 	if (!ctx) return SSX_ERR_ARG;
 	ctx->timing = enable != 0;
 	for (float& m : ctx->stage_ms) m = 0;
-	ctx->ev_pending = false;
+	ctx->ev_used = 0;
 	return SSX_OK;
 }
 
