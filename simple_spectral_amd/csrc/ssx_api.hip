@@ -8,6 +8,8 @@
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -109,6 +111,18 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	h.spec_basis_r = s->spec_basis_r; h.spec_basis_g = s->spec_basis_g; h.spec_basis_b = s->spec_basis_b;
 	h.n_textures = s->n_textures;
 	{
+		// R bounds every coordinate a ray origin or vertex can take: vertices and the camera (paths start at
+		// the camera and continue from points on the quads), with 1 % slack for the rounding of hit points
+		float R = 0.0f;
+		for (int k = 0; k < 3; ++k) R = std::max(R, std::fabs(s->cam_pos[k]));
+		for (uint32_t q = 0; q < s->n_quads; ++q) {
+			const ssx_vertex* vs[4] = { &s->quads[q].v00, &s->quads[q].v10, &s->quads[q].v11, &s->quads[q].v01 };
+			for (const ssx_vertex* v : vs) for (int k = 0; k < 3; ++k) R = std::max(R, std::fabs(v->pos[k]));
+		}
+		R *= 1.01f;
+		h.pass1_tol = 1024.0f * 5.9604644775390625e-8f * R * R;
+	}
+	{
 		const ssx_spectrum &r = s->spectra[s->spec_basis_r], &g = s->spectra[s->spec_basis_g], &b = s->spectra[s->spec_basis_b];
 		h.basis_one_grid = (r.n == g.n && r.n == b.n && r.low == g.low && r.low == b.low && r.delta_recip == g.delta_recip && r.delta_recip == b.delta_recip) ? 1u : 0u;
 	}
@@ -142,7 +156,7 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 			uint32_t kz = p >> 1, kx = (kz + 1) % 3, ky = (kz + 2) % 3;
 			if (p & 1u) { uint32_t t = kx; kx = ky; ky = t; }
 			float* dst = perm + q * SSX_PERM_WORDS_PER_QUAD + p * 12u;
-			for (int v = 0; v < 4; ++v) { dst[3 * v + 0] = vs[v]->pos[kx]; dst[3 * v + 1] = vs[v]->pos[ky]; dst[3 * v + 2] = vs[v]->pos[kz]; }
+			for (int v = 0; v < 4; ++v) { dst[2 * v + 0] = vs[v]->pos[kx]; dst[2 * v + 1] = vs[v]->pos[ky]; dst[8 + v] = vs[v]->pos[kz]; } // x0 y0 .. x3 y3 | z0..z3
 		}
 		for (int v = 0; v < 4; ++v) {
 			memcpy(bq[q].pos[v], vs[v]->pos, 12);

@@ -10,7 +10,8 @@
 #define SSX_BLOB_MAX_BYTES (48u * 1024u)
 
 // Permuted vertex table: for quad q and axis permutation p (0..5) the 12 floats
-//   v00[kx] v00[ky] v00[kz]  v10[kx] v10[ky] v10[kz]  v11[kx] ...  v01[kz]
+//   v00[kx] v00[ky]  v10[kx] v10[ky]  v11[kx] v11[ky]  v01[kx] v01[ky] | v00[kz] v10[kz] v11[kz] v01[kz]
+// ((x,y) pairs land in aligned register pairs for the packed-f32 pass-1 arithmetic)
 // so a lane reads its ray's shear-space ordering with three 16-byte LDS loads instead of
 // selecting components per vertex.  p = 2*kz_case + swapped, with (kx,ky,kz) as chosen by the
 // reference's axis rule (src/geometry.cpp:17-32).  The six 48-byte copies of one quad sit in
@@ -51,7 +52,8 @@ struct SsxBlobHeader {
 	uint32_t basis_one_grid; // the three basis tables share (low, delta_recip, n)
 	// Jakob-Hanika uplift (uplift == 3): scale[jh_res] in the blob, coefficient table in HBM
 	uint32_t uplift, jh_res, off_jh_scale, jh_data_lo, jh_data_hi;
-	uint32_t pad[3];
+	float pass1_tol;  // tolerance of the conservative edge-function filter: 1024 * 2^-24 * R^2
+	uint32_t pad[2];
 };
 static_assert(sizeof(SsxBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 
