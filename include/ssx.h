@@ -118,6 +118,9 @@ typedef struct ssx_render_params {
 	uint32_t tile_first;      /* this device renders tiles t with t % tile_stride == tile_first ... */
 	uint32_t tile_stride;     /* ... (1 = whole image); other pixels are written as 0 */
 	uint32_t spp_per_launch;  /* progress/cancel granularity; 0 = library default */
+	uint32_t no_explicit_light_sampling; /* 0 = EXPLICIT_LIGHT_SAMPLING defined (src/stdafx.hpp:44, the
+	                             reference's default); 1 = the integrator it compiles without it */
+	uint32_t reserved;
 	uint64_t seed;            /* seeding contract below */
 } ssx_render_params;
 

@@ -25,7 +25,9 @@ int ssh_scene_create(const char* scene_name, const char* data_dir, int observer,
 /* As ssh_scene_create, plus the uplift variant (SSX_UPLIFT_OURS | SSX_UPLIFT_JH).  For JH the model is
  * loaded from jh_coeff_path when that file exists ("SPEC" format of rgb2spec_load), otherwise
  * fitted by the library's own optimiser at resolution jh_res (and written to jh_coeff_path when one
- * is given).  JH requires the CIE 1931 observer (src/stdafx.hpp:107-109). */
+ * is given).  JH requires the CIE 1931 observer (src/stdafx.hpp:107-109).  Bit 8 (0x100) of `uplift`
+ * builds the scene for the integrator without EXPLICIT_LIGHT_SAMPLING (plane-srgb's textured quad
+ * becomes a MaterialMirror, src/scene.cpp:346-355). */
 int ssh_scene_create_ex(const char* scene_name, const char* data_dir, int observer,
                         const uint8_t* tex_rgb, uint32_t tex_w, uint32_t tex_h, const char* texture_path,
                         float light_scale, uint32_t uplift, const char* jh_coeff_path, uint32_t jh_res,

@@ -150,11 +150,16 @@ float orc_jh_eval_precise(const float coeff[3], float lambda);          /* rgb2s
 orc_scene* orc_scene_create(const orc_color*, const char* name, const char* data_dir,
                             const uint8_t* tex_rgb, int tex_w, int tex_h, float light_scale);
 void orc_scene_destroy(orc_scene*);
+/* test hook: change a material's kind (ORC_MTL_LAMBERTIAN / ORC_MTL_MIRROR), e.g. to build the
+ * reference's non-ELS plane scene material (scene.cpp:346-355) or any mirror surface */
+int orc_scene_set_material_kind(orc_scene*, int material, int kind);
+int orc_scene_quad_material(const orc_scene*, int quad);
 
 /* The build's seeding contract: one PCG32 stream per (seed, pixel index j*W+i, sample k). */
 void orc_seed_sample(uint64_t seed, uint64_t pixel, uint64_t k, orc_rng* out);
 
-/* Renderer::_render_sample (renderer.cpp:104-277): out = X,Y,Z,alpha. */
+/* Renderer::_render_sample (renderer.cpp:104-277): out = X,Y,Z,alpha.  `indirect_only` is a flag
+ * word: bit 0 = Options::indirect_only, bit 1 = integrator compiled WITHOUT EXPLICIT_LIGHT_SAMPLING. */
 void orc_render_sample(const orc_color*, const orc_scene*, orc_rng*, size_t i, size_t j,
                        size_t W, size_t H, int indirect_only, float out_xyza[4], orc_stats*);
 

@@ -14,6 +14,7 @@ typedef struct {
 	orc_rng* rng;
 	float lambda_0;
 	int indirect_only;
+	int els; /* EXPLICIT_LIGHT_SAMPLING (stdafx.hpp:44) */
 	int hit_anything;
 	orc_stats* st;
 	unsigned interactions;
@@ -29,8 +30,8 @@ static orc_hero radiance_L(path_ctx* c, const orc_ray* ray, int last_was_delta, 
 		c->hit_anything = 1;
 		const orc_material* mtl = &c->sc->materials[c->sc->prims[hitrec.prim].material];
 
-		/* Emission (:166-175) */
-		if (last_was_delta && (!c->indirect_only || depth > 0u)) {
+		/* Emission (:166-175); the condition exists only #ifdef EXPLICIT_LIGHT_SAMPLING */
+		if (!c->els || (last_was_delta && (!c->indirect_only || depth > 0u))) {
 			float em[4];
 			orc_spectrum_hero(&mtl->emission, c->lambda_0, c->cd->lambda_step, em); /* material.hpp:101-103 */
 			if (c->st) c->st->spectrum_lookups++;
@@ -42,7 +43,7 @@ static orc_hero radiance_L(path_ctx* c, const orc_ray* ray, int last_was_delta, 
 			orc_v3 hit_pos = v3_add(ray->orig, v3_scale(hitrec.dist, ray->dir)); /* Ray::at, stdafx.hpp:220 */
 
 			/* Direct lighting (:182-219) */
-			if (!c->indirect_only || depth > 0u) {
+			if (c->els && (!c->indirect_only || depth > 0u)) { /* whole block #ifdef EXPLICIT_LIGHT_SAMPLING */
 				orc_v3 shad_ray_dir; int light; float shad_pdf;
 				orc_scene_get_rand_toward_light(c->sc, c->rng, hit_pos, &shad_ray_dir, &light, &shad_pdf);
 				float n_dot_l = v3_dot(shad_ray_dir, hitrec.normal);
@@ -129,7 +130,8 @@ void orc_render_sample(const orc_color* cd, const orc_scene* sc, orc_rng* rng, s
 
 	float lambda_0 = cd->lambda_min + orc_rand_1f(rng) * cd->lambda_step; /* :138 */
 
-	path_ctx c = { cd, sc, rng, lambda_0, indirect_only, 0, st, 0 };
+	/* `indirect_only` carries two flags: bit 0 = Options::indirect_only, bit 1 = build without ELS */
+	path_ctx c = { cd, sc, rng, lambda_0, indirect_only & 1, !(indirect_only & 2), 0, st, 0 };
 	orc_ray ray_camera = { sc->camera.pos, camera_ray_dir };
 	orc_hero rad = radiance_L(&c, &ray_camera, 1, 0u, -1);
 

@@ -446,3 +446,10 @@ int orc_scene_counts(const orc_scene* sc, int* n_prims, int* n_lights, int* n_ma
 	if (n_materials) *n_materials = sc->n_materials;
 	return 0;
 }
+
+int orc_scene_set_material_kind(orc_scene* sc, int material, int kind) {
+	if (material < 0 || material >= sc->n_materials) return -2;
+	sc->materials[material].kind = kind;
+	return 0;
+}
+int orc_scene_quad_material(const orc_scene* sc, int quad) { return (quad >= 0 && quad < sc->n_prims) ? sc->prims[quad].material : -1; }

@@ -51,7 +51,8 @@ class SsxSceneDesc(C.Structure):
 class SsxRenderParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32),
                 ("indirect_only", C.c_uint32), ("tile_first", C.c_uint32), ("tile_stride", C.c_uint32),
-                ("spp_per_launch", C.c_uint32), ("seed", C.c_uint64)]
+                ("spp_per_launch", C.c_uint32), ("no_explicit_light_sampling", C.c_uint32), ("reserved", C.c_uint32),
+                ("seed", C.c_uint64)]
 
 
 SSX_UPLIFT_OURS, SSX_UPLIFT_JH = 1, 3

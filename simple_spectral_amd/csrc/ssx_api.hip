@@ -226,7 +226,7 @@ int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
 
 // Every launch writes its samples to [tile slot][k][64] float4 (16 B per sample) and the ordered
 // accumulate pass consumes them; the buffer bounds how many samples per pixel one launch may cover.
-constexpr size_t kSampleBufferBudget = (size_t)32 << 30; // bytes: 32 B record + 8 x 48 B frames per sample in flight (288 GB HBM)
+constexpr size_t kSampleBufferBudget = (size_t)32 << 30; // bytes: 32 B record + 9 x 48 B frames per sample in flight (288 GB HBM)
 constexpr size_t kBytesPerSampleInFlight = sizeof(SsxSampleRecord) + SSX_MAX_FRAMES * sizeof(SsxFrame);
 constexpr uint32_t kTargetUnits = 16384;               // wave work units wanted per launch (~8 per SIMD)
 
@@ -241,6 +241,7 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	a.n_tiles = a.tiles_x * ((p->height + 7u) / 8u);
 	a.tile_first = p->tile_first; a.tile_stride = p->tile_stride;
 	a.indirect_only = p->indirect_only ? 1u : 0u;
+	a.no_els = p->no_explicit_light_sampling ? 1u : 0u;
 	a.seed = p->seed;
 	a.my_tiles = a.n_tiles > p->tile_first ? (a.n_tiles - p->tile_first + p->tile_stride - 1u) / p->tile_stride : 0u;
 	pl.lds_bytes = (size_t)ctx->blob_words * 4;

@@ -73,7 +73,7 @@ static_assert(sizeof(SsxSampleRecord) == 32, "layout");
 // Layout [depth][record]; written by the path kernel, read once by ssx_resolve_kernel.
 struct SsxFrame { float4 direct; float4 f_s; float2 np; float2 pad; };
 static_assert(sizeof(SsxFrame) == 48, "layout");
-#define SSX_MAX_FRAMES 8u  // depths 0..MAX_DEPTH-3 can continue (see path_step)
+#define SSX_MAX_FRAMES 9u  // depths 0..MAX_DEPTH-2 can continue (MAX_DEPTH-3 with explicit light sampling)
 
 struct SsxKernelArgs {
 	const uint32_t* blob;   // device copy of the scene blob
@@ -83,6 +83,7 @@ struct SsxKernelArgs {
 	uint32_t tile_first, tile_stride;
 	uint32_t k0, k1;        // sample range of this launch
 	uint32_t indirect_only;
+	uint32_t no_els;        // 1: integrator without EXPLICIT_LIGHT_SAMPLING
 	uint32_t my_tiles;      // tiles this device owns
 	uint32_t group_spp;     // samples per pixel in one wave's work unit
 	uint32_t n_groups;      // ceil((k1-k0)/group_spp)

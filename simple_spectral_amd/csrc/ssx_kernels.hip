@@ -629,12 +629,21 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 	float direct[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
 	// emission: only the camera ray has last_was_delta (:169-172, :247).  A material whose emission
 	// table is all zeros (MaterialBase's default) would add exactly +0, so its lookup is skipped.
-	if (p.depth == 0u && !a.indirect_only && M.is_emissive != 0u) {
+	// Without EXPLICIT_LIGHT_SAMPLING (a.no_els; a compile-time switch in the reference,
+	// stdafx.hpp:44) every hit adds its emission unconditionally (:166-175).
+	const bool els = a.no_els == 0u;
+	if ((els ? (p.depth == 0u && !a.indirect_only) : true) && M.is_emissive != 0u) {
 		Hero em = spectrum_hero(L, M.emission, p.lambda_0, h.lambda_step);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) direct[k] += em.v[k];
 	}
-	// depth+1 < MAX_DEPTH always holds here: a ray at depth MAX_DEPTH-1 is never started (below)
+	// :178 `if (depth+1u<MAX_DEPTH)`: with ELS a ray at depth MAX_DEPTH-1 is never started (below);
+	// without it that ray exists (its hit may emit) and ends here
+	if (p.depth + 1u >= SSX_MAX_DEPTH_) {
+#pragma unroll
+		for (int k = 0; k < 4; ++k) rad[k] = direct[k];
+		return false;
+	}
 	V3 hit_pos = add(p.orig, scl(hit.dist, p.dir)); // Ray::at
 	// hitrec.st (geometry.cpp:91-95) is read only by textured albedo
 	float st_x = 0.0f, st_y = 0.0f;
@@ -655,7 +664,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 
 	// direct lighting (:182-219)
 #ifndef SSX_ABL_NONEE
-	if (!a.indirect_only || p.depth > 0u) {
+	if (els && (!a.indirect_only || p.depth > 0u)) {
 		V3 sdir; uint32_t light; float spdf;
 		sample_light(L, p.rng, hit_pos, sdir, light, spdf);
 		float n_dot_l = dot3(sdir, N);
@@ -708,7 +717,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 	// is exactly 0 and the parent adds ((0*n)*f)/p.
 	// In that case direct + ((0*n_dot_l)*f_s)/pdf == direct exactly: n_dot_l, f_s (finite table
 	// values / pi) and pdf (in (EPS/pi, 1/pi], or 1 for a mirror) are finite and pdf > 0.
-	if (!cont || p.depth + 2u >= SSX_MAX_DEPTH_) {
+	if (!cont || (els && p.depth + 2u >= SSX_MAX_DEPTH_)) {
 #pragma unroll
 		for (int k = 0; k < 4; ++k) rad[k] = direct[k];
 		return false;

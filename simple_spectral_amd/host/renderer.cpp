@@ -70,9 +70,11 @@ bool file_exists(const std::string& p) { return std::ifstream(p).good(); }
 
 Renderer::Renderer(const Options& opts) : options(opts), framebuffer(opts.res), xyza(4 * opts.res[0] * opts.res[1], 0.0f) {
 	// Scene selection and its warnings (src/renderer.cpp:17-38, EXPLICIT_LIGHT_SAMPLING build)
-	if (options.scene_name == "plane-srgb")
-		std::fprintf(stderr, "Warning: Plane converges much faster without explicit light sampling!  (See \"stdafx.hpp\" to disable.)\n");
-	else if (options.scene_name != "cornell" && options.scene_name != "cornell-srgb") {
+	if (options.scene_name == "plane-srgb") {
+		if (options.explicit_light_sampling) std::fprintf(stderr, "Warning: Plane converges much faster without explicit light sampling!  (See \"stdafx.hpp\" to disable.)\n");
+	} else if (options.scene_name == "cornell" || options.scene_name == "cornell-srgb") {
+		if (!options.explicit_light_sampling) std::fprintf(stderr, "Warning: Cornell converges much faster with explicit light sampling!  (See \"stdafx.hpp\" to enable.)\n");
+	} else {
 		std::fprintf(stderr, "Unrecognized scene \"%s\"!  (Supported scenes: \"cornell\", \"cornell-srgb\", \"plane-srgb\")\n", options.scene_name.c_str());
 		throw HostError{ -3, "Unrecognized scene" };
 	}
@@ -99,7 +101,7 @@ Renderer::Renderer(const Options& opts) : options(opts), framebuffer(opts.res), 
 	} else if (options.uplift != SSX_UPLIFT_OURS) {
 		throw HostError{ -3, "unsupported uplift variant" };
 	}
-	scene = std::make_unique<Scene>(*color, options.scene_name, options.data_dir, texp, options.light_scale, jh.get());
+	scene = std::make_unique<Scene>(*color, options.scene_name, options.data_dir, texp, options.light_scale, jh.get(), options.explicit_light_sampling);
 
 	api_ = std::make_unique<Api>(options.hip_library.empty() ? default_hip_library() : options.hip_library);
 	const int n = options.gpus < 1 ? 1 : options.gpus;
@@ -125,6 +127,7 @@ void Renderer::render_start() {
 		p.width = static_cast<uint32_t>(options.res[0]); p.height = static_cast<uint32_t>(options.res[1]);
 		p.spp = static_cast<uint32_t>(options.spp);
 		p.indirect_only = options.indirect_only ? 1u : 0u;
+		p.no_explicit_light_sampling = options.explicit_light_sampling ? 0u : 1u;
 		p.tile_first = static_cast<uint32_t>(d); p.tile_stride = static_cast<uint32_t>(ctxs_.size());
 		p.spp_per_launch = 0;
 		p.seed = options.seed;

@@ -43,6 +43,7 @@ public:
 		int gpus = 1;                // devices 0..gpus-1, 8x8 tiles dealt round-robin
 		std::string texture_path;    // default: data/scenes/crystal-lizard-4096.png, else the 512 version
 		float light_scale = 30.0f;   // lightsc (src/scene.cpp:291-293)
+		bool explicit_light_sampling = true; // EXPLICIT_LIGHT_SAMPLING (src/stdafx.hpp:44)
 		int uplift = 1;              // RENDER_MODE_SPECTRAL_ALGNUM: 1 = basis (ours), 3 = Jakob-Hanika 2019
 		std::string jh_coeff_path;   // default data/jakob-and-hanika-2019-srgb.coeff (src/util/color.cpp:144); fitted and written when absent
 		std::string data_dir = "data"; // CWD-relative like the reference's paths

@@ -202,7 +202,9 @@ void Scene::build_plane_srgb(const Texture* tex) {
 	const uint32_t d65 = add_spectrum(color_.D65_rad);
 	const uint32_t m_light = add_material(SSX_MTL_LAMBERTIAN, SSX_ALBEDO_CONSTANT, black, d65);
 	textures_.push_back(*tex);
-	const uint32_t m_tex = add_material(SSX_MTL_LAMBERTIAN, SSX_ALBEDO_TEXTURE, 0, zero_emission_); // ELS build: Lambertian
+	// Lambertian with explicit light sampling, Mirror without (both converge to the same image; the
+	// mirror is faster because the ray direction is not random: src/scene.cpp:346-355)
+	const uint32_t m_tex = add_material(els_ ? SSX_MTL_LAMBERTIAN : SSX_MTL_MIRROR, SSX_ALBEDO_TEXTURE, 0, zero_emission_);
 
 	const float plane[4][3] = { { -1, -1, 0 }, { 1, -1, 0 }, { 1, 1, 0 }, { -1, 1, 0 } };
 	const float plane_st[4][2] = { { 0, 0 }, { 1, 0 }, { 1, 1 }, { 0, 1 } };
@@ -249,8 +251,8 @@ void Scene::finish() {
 }
 
 Scene::Scene(const ColorData& color, const std::string& scene_name, const std::string& data_dir, const Texture* texture, float light_scale,
-             const JHModel* jh)
-	: name(scene_name), color_(color), jh_(jh) {
+             const JHModel* jh, bool explicit_light_sampling)
+	: name(scene_name), color_(color), jh_(jh), els_(explicit_light_sampling) {
 	if (jh_ && color_.observer != 1931) throw HostError{ -3, "Only our algorithm currently implements support for the newest CIE standard observer!" }; // stdafx.hpp:107-109
 	// MaterialBase's default emission: constant 0 over the rendered band (src/material.hpp:95-96)
 	zero_emission_ = add_spectrum(Spectrum(0.0f, color_.lambda_min, color_.lambda_max));

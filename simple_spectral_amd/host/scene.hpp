@@ -33,7 +33,7 @@ public:
 	// jh: Jakob-Hanika model to uplift texels with (RENDER_MODE_SPECTRAL_JH), or nullptr for the
 	// basis uplift (RENDER_MODE_SPECTRAL_OURS, the reference's default).
 	Scene(const ColorData& color, const std::string& name, const std::string& data_dir, const Texture* texture, float light_scale,
-	      const JHModel* jh = nullptr);
+	      const JHModel* jh = nullptr, bool explicit_light_sampling = true);
 
 	const ssx_scene_desc& desc() const { return desc_; }
 	Camera camera;
@@ -59,6 +59,7 @@ private:
 	std::vector<ssx_texture> texture_descs_;
 	uint32_t zero_emission_ = 0;
 	const JHModel* jh_ = nullptr;
+	bool els_ = true;
 	ssx_scene_desc desc_{};
 };
 

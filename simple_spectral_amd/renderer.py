@@ -41,6 +41,8 @@ class Options:
     seed: int = 0
     texture: Optional[str] = None        # PNG path; default per scene below
     light_scale: float = 30.0            # lightsc (src/scene.cpp:291-293)
+    explicit_light_sampling: bool = True  # EXPLICIT_LIGHT_SAMPLING (src/stdafx.hpp:44); False also makes
+    #                                       plane-srgb's textured quad a mirror (src/scene.cpp:346-355)
     uplift: str = "ours"                 # RENDER_MODE_SPECTRAL_ALGNUM: "ours" (1) | "jh" (3, Jakob-Hanika 2019)
     jh_res: int = 64                     # resolution of the fitted JH model when no coefficient file exists
     jh_coeff_path: Optional[str] = None  # data/jakob-and-hanika-2019-srgb.coeff in the reference (missing blob)
@@ -66,7 +68,7 @@ class Scene:
     """Host-prepared scene + colour tables (libssx_host.so)."""
 
     def __init__(self, name, observer=1931, texture=None, light_scale=30.0, data_dir=DEFAULT_DATA_DIR,
-                 uplift="ours", jh_res=64, jh_coeff_path=None):
+                 uplift="ours", jh_res=64, jh_coeff_path=None, explicit_light_sampling=True):
         lib = _capi.host_lib()
         self._lib = lib
         self._h = C.c_void_p()
@@ -84,7 +86,7 @@ class Scene:
             raise SsxError(_capi.SSX_ERR_SCENE, "unsupported uplift %r (ours | jh)" % (uplift,))
         rc = lib.ssh_scene_create_ex(name.encode(), data_dir.encode(), observer, tp, tw, th,
                                      tex_path.encode() if tex_path else None, C.c_float(light_scale),
-                                     _capi.SSX_UPLIFT_JH if uplift == "jh" else _capi.SSX_UPLIFT_OURS,
+                                     (_capi.SSX_UPLIFT_JH if uplift == "jh" else _capi.SSX_UPLIFT_OURS) | (0 if explicit_light_sampling else 0x100),
                                      jh_coeff_path.encode() if jh_coeff_path else None, jh_res, C.byref(self._h))
         if rc != 0:
             raise SsxError(rc, lib.ssh_last_error().decode())
@@ -137,7 +139,7 @@ class Renderer:
     def __init__(self, options: Options):
         self.options = options
         self.scene = Scene(options.scene_name, options.observer, options.texture, options.light_scale, options.data_dir,
-                           options.uplift, options.jh_res, options.jh_coeff_path)
+                           options.uplift, options.jh_res, options.jh_coeff_path, options.explicit_light_sampling)
         self._lib = _capi.hip_lib()
         self._ctx = C.c_void_p()
         rc = self._lib.ssx_create(options.device, C.byref(self._ctx))
@@ -159,6 +161,7 @@ class Renderer:
         p.width, p.height = o.res
         p.spp = o.spp
         p.indirect_only = int(o.indirect_only)
+        p.no_explicit_light_sampling = int(not o.explicit_light_sampling)
         p.tile_first, p.tile_stride = o.tile_first, o.tile_stride
         p.spp_per_launch = o.spp_per_launch
         p.seed = o.seed

@@ -96,6 +96,8 @@ def load(variant=""):
     lib.orc_scene_create.restype = vp
     lib.orc_scene_create.argtypes = [vp, C.c_char_p, C.c_char_p, vp, C.c_int, C.c_int, C.c_float]
     lib.orc_scene_destroy.argtypes = [vp]
+    lib.orc_scene_set_material_kind.argtypes = [vp, C.c_int, C.c_int]
+    lib.orc_scene_quad_material.argtypes = [vp, C.c_int]
     lib.orc_seed_sample.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(Rng)]
     lib.orc_render_sample.argtypes = [vp, vp, C.POINTER(Rng), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
                                       C.c_int, f32p, C.POINTER(Stats)]
@@ -202,11 +204,11 @@ class Oracle:
         except Exception:
             pass
 
-    def render(self, W, H, spp, seed=0, rect=None, indirect_only=False, nthreads=0, stats=False):
+    def render(self, W, H, spp, seed=0, rect=None, indirect_only=False, nthreads=0, stats=False, els=True):
         out = np.zeros((H, W, 4), dtype=np.float32)
         i0, j0, i1, j1 = rect if rect else (0, 0, W, H)
         st = Stats() if stats else None
-        rc = self.lib.orc_render(self.color, self.scene, seed, W, H, i0, j0, i1, j1, spp, int(indirect_only),
+        rc = self.lib.orc_render(self.color, self.scene, seed, W, H, i0, j0, i1, j1, spp, int(indirect_only) | (0 if els else 2),
                                  nthreads, out.ctypes.data, C.byref(st) if stats else None)
         assert rc == 0
         return (out, st) if stats else out

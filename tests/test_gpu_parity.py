@@ -193,3 +193,46 @@ def test_jakob_hanika_lizard_texture_config1_shape():
     r.render_start(); r.render_wait()
     ref = ol.Oracle("cornell-srgb", texture="crystal-lizard-512.png", jh=r.scene.jh_model()).render(128, 128, 16)
     assert same_or_both_nan(r.xyza, ref)
+
+
+def test_mirror_material_bit_exact():
+    """MaterialMirror (src/material.cpp:146-167): delta BSDF, evaluate -> 0, sample -> reflect with
+    pdf = +inf (then n_dot_l = pdf = 1, src/renderer.cpp:236-243).  No built-in scene selects it in
+    the explicit-light-sampling build, so the textured quad of plane-srgb and the blocks of the
+    Cornell box are switched to mirrors through the scene description on both sides."""
+    import ctypes as C
+    for scene, pick in (("plane-srgb", lambda q: q == 0), ("cornell-srgb", lambda q: q >= 9)):
+        r = Renderer(Options(scene_name=scene, res=(40, 32), spp=6, seed=8, texture="test-img.png"))
+        d = r.scene.desc.contents
+        mats = (_capi.SsxMaterial * d.n_materials)(*[d.materials[i] for i in range(d.n_materials)])
+        o = ol.Oracle(scene, texture="test-img.png")
+        changed = set()
+        for q in range(d.n_quads):
+            if pick(q):
+                m = d.quads[q].material
+                mats[m].kind = 1  # SSX_MTL_MIRROR
+                changed.add(m)
+                assert o.lib.orc_scene_set_material_kind(o.scene, o.lib.orc_scene_quad_material(o.scene, q), 1) == 0
+        d2 = _capi.SsxSceneDesc.from_buffer_copy(d)
+        d2.materials = C.cast(mats, C.POINTER(_capi.SsxMaterial))
+        r._check(r._lib.ssx_upload_scene(r._ctx, C.byref(d2)))
+        r.render_start(); r.render_wait()
+        ref = o.render(40, 32, 6, seed=8)
+        assert np.array_equal(bits(r.xyza), bits(ref)), scene
+        base = ol.Oracle(scene, texture="test-img.png").render(40, 32, 6, seed=8)
+        assert not np.array_equal(bits(base), bits(ref)) and changed
+
+
+@pytest.mark.parametrize("scene", ["plane-srgb", "cornell-srgb"])
+def test_without_explicit_light_sampling_bit_exact(scene):
+    """The integrator the reference compiles without EXPLICIT_LIGHT_SAMPLING (src/stdafx.hpp:44):
+    emission at every hit, no next-event estimation, rays down to depth MAX_DEPTH-1; plane-srgb's
+    textured quad is then a MaterialMirror (src/scene.cpp:346-355)."""
+    r = Renderer(Options(scene_name=scene, res=(40, 32), spp=6, seed=3, texture="test-img.png", explicit_light_sampling=False))
+    r.render_start(); r.render_wait()
+    o = ol.Oracle(scene, texture="test-img.png")
+    if scene == "plane-srgb":
+        assert o.lib.orc_scene_set_material_kind(o.scene, o.lib.orc_scene_quad_material(o.scene, 0), 1) == 0
+    ref = o.render(40, 32, 6, seed=3, els=False)
+    assert np.array_equal(bits(r.xyza), bits(ref))
+    assert not np.array_equal(bits(o.render(40, 32, 6, seed=3)), bits(ref))
