@@ -613,6 +613,14 @@ int ssx_get_timing(ssx_ctx* ctx, float stage_ms[4]) {
 	return SSX_OK;
 }
 
+#ifdef SSX_PROFILE_CANDS
+int ssx_cand_stats(unsigned long long out[4], int reset) {
+	if (reset) { unsigned long long z[4] = { 0, 0, 0, 0 }; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cand_stats), z, sizeof z); }
+	(void)hipDeviceSynchronize();
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cand_stats), 4 * sizeof(unsigned long long));
+}
+#endif
+
 int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* scratch_bytes, int* max_blocks_per_cu) {
 	if (!ctx) return SSX_ERR_ARG;
 	SSX_HIP(ctx, hipSetDevice(ctx->device));

@@ -49,6 +49,10 @@
 #define SSX_MAX_DEPTH_ 10u       // stdafx.hpp:47
 #define SSX_PI_F 3.14159265358979323846f
 
+#ifdef SSX_PROFILE_CANDS
+__device__ unsigned long long g_cand_stats[4]; // traces, lanes, candidates, wave loop trips
+#endif
+
 namespace {
 
 struct V3 { float x, y, z; };
@@ -393,6 +397,19 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 	hit.tri = -1;
 	hit.dist = __builtin_inff();
 	hit.U = hit.V = hit.W = hit.det_recip = 0.0f;
+#ifdef SSX_PROFILE_CANDS
+	{ // pass-2 statistics: lanes with a ray, candidates over lanes, wave-level loop trips (max over lanes)
+		const uint64_t act = __ballot(1);
+		uint32_t mine = (uint32_t)__popcll(cand), mx = mine, sum = mine;
+		for (int o = 32; o > 0; o >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); sum += (uint32_t)__shfl_xor((int)sum, o); }
+		if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(act)) {
+			atomicAdd((unsigned long long*)&g_cand_stats[0], 1ull);
+			atomicAdd((unsigned long long*)&g_cand_stats[1], (unsigned long long)__popcll(act));
+			atomicAdd((unsigned long long*)&g_cand_stats[2], (unsigned long long)sum);
+			atomicAdd((unsigned long long*)&g_cand_stats[3], (unsigned long long)mx);
+		}
+	}
+#endif
 	while (cand) {
 		uint32_t bit = (uint32_t)__builtin_ctzll(cand);
 		cand &= cand - 1ull;
