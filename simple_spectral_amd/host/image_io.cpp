@@ -35,66 +35,113 @@ void write_chunk(std::vector<uint8_t>& out, const char type[4], const std::vecto
 
 } // namespace
 
-// Non-interlaced PNG, bit depth 8 (grey, grey+alpha, RGB, RGBA, palette) or 16 (high byte kept).
+// PNG -> RGB8, every standard variant: colour types 0/2/3/4/6, bit depths 1/2/4/8/16, Adam7
+// interlacing; alpha and tRNS do not affect RGB.  Conversion rules are those of
+// lodepng::decode(..., LCT_RGB) (src/material.cpp:11-14): sub-byte grey scaled by 255/(2^d-1),
+// 16-bit samples keep their high byte, palette indices past PLTE give black.  Checked against the
+// reference's lodepng itself in tests/test_ref_pins.py.
 Texture load_png_rgb8(const std::string& path) {
+	const std::string fail = "Could not load texture \"" + path + "\"";
 	std::ifstream f(path, std::ios::binary);
-	if (!f.good()) throw HostError{ -1, "Could not load texture \"" + path + "\"" };
+	if (!f.good()) throw HostError{ -1, fail };
 	std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
 	static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n' };
-	if (file.size() < 8 || std::memcmp(file.data(), sig, 8) != 0) throw HostError{ -1, "Could not load texture \"" + path + "\"" };
+	if (file.size() < 8 || std::memcmp(file.data(), sig, 8) != 0) throw HostError{ -1, fail + " (not a PNG)" };
 
-	uint32_t w = 0, h = 0; int depth = 0, ctype = -1, interlace = 0;
+	uint32_t w = 0, h = 0; int depth = 0, ctype = -1, interlace = 0; bool have_ihdr = false, have_iend = false;
 	std::vector<uint8_t> idat, palette;
 	for (size_t pos = 8; pos + 12 <= file.size();) {
 		const uint32_t len = be32(&file[pos]);
 		const char* type = reinterpret_cast<const char*>(&file[pos + 4]);
 		const uint8_t* data = &file[pos + 8];
-		if (pos + 12 + len > file.size()) break;
-		if (!std::memcmp(type, "IHDR", 4) && len >= 13) { w = be32(data); h = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12]; }
+		if ((uint64_t)pos + 12 + len > file.size()) throw HostError{ -1, fail + " (truncated chunk)" };
+		if ((uint32_t)crc32(0L, &file[pos + 4], (uInt)(len + 4)) != be32(data + len)) throw HostError{ -1, fail + " (chunk CRC mismatch)" };
+		if (!std::memcmp(type, "IHDR", 4) && len == 13) {
+			w = be32(data); h = be32(data + 4); depth = data[8]; ctype = data[9]; interlace = data[12]; have_ihdr = true;
+			if (data[10] != 0 || data[11] != 0) throw HostError{ -1, fail + " (unknown compression/filter method)" };
+		}
 		else if (!std::memcmp(type, "PLTE", 4)) palette.assign(data, data + len);
 		else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), data, data + len);
-		else if (!std::memcmp(type, "IEND", 4)) break;
+		else if (!std::memcmp(type, "IEND", 4)) { have_iend = true; break; }
 		pos += 12 + len;
 	}
+	(void)have_iend;
 	const int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-	if (!w || !h || !channels || interlace || (depth != 8 && depth != 16) || (ctype == 3 && depth != 8))
-		throw HostError{ -1, "Could not load texture \"" + path + "\" (unsupported PNG variant)" };
-	const size_t bpp = (size_t)channels * (depth / 8), stride = bpp * w;
-	std::vector<uint8_t> raw((stride + 1) * h);
+	const bool depth_ok = ctype == 0 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+	                    : ctype == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8)
+	                    : (depth == 8 || depth == 16);
+	if (!have_ihdr || !w || !h || !channels || !depth_ok || interlace > 1 || (ctype == 3 && palette.empty()))
+		throw HostError{ -1, fail + " (invalid or unsupported PNG header)" };
+
+	const size_t bits = (size_t)channels * depth;       // bits per pixel
+	const size_t bpp = bits >= 8 ? bits / 8 : 1;         // filter distance in bytes
+	auto line_bytes = [&](uint32_t pw) { return ((size_t)pw * bits + 7) / 8; };
+	// pass geometry: {x0, y0, dx, dy}; one pass when not interlaced
+	static const uint32_t adam7[7][4] = { {0,0,8,8}, {4,0,8,8}, {0,4,4,8}, {2,0,4,4}, {0,2,2,4}, {1,0,2,2}, {0,1,1,2} };
+	static const uint32_t whole[1][4] = { {0,0,1,1} };
+	const uint32_t (*passes)[4] = interlace ? adam7 : whole;
+	const int n_passes = interlace ? 7 : 1;
+	size_t raw_size = 0;
+	for (int p = 0; p < n_passes; ++p) {
+		const uint32_t pw = (w + passes[p][2] - 1 - passes[p][0]) / passes[p][2], ph = (h + passes[p][3] - 1 - passes[p][1]) / passes[p][3];
+		if (pw && ph) raw_size += (line_bytes(pw) + 1) * ph;
+	}
+	std::vector<uint8_t> raw(raw_size);
 	uLongf raw_len = (uLongf)raw.size();
 	if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size())
-		throw HostError{ -1, "Could not load texture \"" + path + "\" (bad zlib stream)" };
+		throw HostError{ -1, fail + " (bad zlib stream)" };
 
-	std::vector<uint8_t> img(stride * h);
-	for (uint32_t y = 0; y < h; ++y) {
-		const uint8_t filter = raw[(stride + 1) * y];
-		const uint8_t* src = &raw[(stride + 1) * y + 1];
-		uint8_t* dst = &img[stride * y];
-		const uint8_t* up = y ? &img[stride * (y - 1)] : nullptr;
-		for (size_t x = 0; x < stride; ++x) {
-			const int a = x >= bpp ? dst[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
-			int v = src[x];
-			switch (filter) {
-				case 1: v += a; break;
-				case 2: v += b; break;
-				case 3: v += (a + b) / 2; break;
-				case 4: v += paeth(a, b, c); break;
-				default: break;
-			}
-			dst[x] = (uint8_t)v;
-		}
-	}
 	Texture t;
 	t.width = w; t.height = h;
-	t.rgb.resize((size_t)3 * w * h);
-	const size_t step = depth / 8;
-	for (size_t p = 0; p < (size_t)w * h; ++p) {
-		const uint8_t* px = &img[p * bpp];
-		uint8_t r, g, b;
-		if (ctype == 3) { const size_t k = (size_t)px[0] * 3; r = k + 2 < palette.size() ? palette[k] : 0; g = k + 2 < palette.size() ? palette[k + 1] : 0; b = k + 2 < palette.size() ? palette[k + 2] : 0; }
-		else if (channels <= 2) { r = g = b = px[0]; }
-		else { r = px[0]; g = px[step]; b = px[2 * step]; }
-		t.rgb[3 * p] = r; t.rgb[3 * p + 1] = g; t.rgb[3 * p + 2] = b;
+	t.rgb.assign((size_t)3 * w * h, 0);
+	const uint32_t highest = (1u << (depth < 16 ? depth : 8)) - 1u;
+	size_t cursor = 0;
+	std::vector<uint8_t> prev, cur;
+	for (int p = 0; p < n_passes; ++p) {
+		const uint32_t x0 = passes[p][0], y0 = passes[p][1], dx = passes[p][2], dy = passes[p][3];
+		const uint32_t pw = (w + dx - 1 - x0) / dx, ph = (h + dy - 1 - y0) / dy;
+		if (!pw || !ph) continue;
+		const size_t lb = line_bytes(pw);
+		prev.assign(lb, 0); cur.assign(lb, 0);
+		for (uint32_t y = 0; y < ph; ++y) {
+			const uint8_t filter = raw[cursor];
+			const uint8_t* src = &raw[cursor + 1];
+			cursor += lb + 1;
+			if (filter > 4) throw HostError{ -1, fail + " (bad filter type)" };
+			for (size_t x = 0; x < lb; ++x) {
+				const int a = x >= bpp ? cur[x - bpp] : 0, b = prev[x], c = x >= bpp ? prev[x - bpp] : 0;
+				int v = src[x];
+				switch (filter) {
+					case 1: v += a; break;
+					case 2: v += b; break;
+					case 3: v += (a + b) / 2; break;
+					case 4: v += paeth(a, b, c); break;
+					default: break;
+				}
+				cur[x] = (uint8_t)v;
+			}
+			uint8_t* row = &t.rgb[(size_t)3 * w * (y0 + (size_t)y * dy)];
+			for (uint32_t x = 0; x < pw; ++x) {
+				uint8_t* out = row + (size_t)3 * (x0 + (size_t)x * dx);
+				uint32_t s0;
+				if (depth < 8) { // one sample per pixel, packed most significant bits first
+					const size_t bit = (size_t)x * depth;
+					s0 = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & highest;
+				} else s0 = cur[(size_t)x * bpp];
+				if (ctype == 3) {
+					const size_t k = (size_t)s0 * 3;
+					const bool in = k + 2 < palette.size();
+					out[0] = in ? palette[k] : 0; out[1] = in ? palette[k + 1] : 0; out[2] = in ? palette[k + 2] : 0;
+				} else if (channels <= 2) {
+					out[0] = out[1] = out[2] = depth < 8 ? (uint8_t)((s0 * 255u) / highest) : (uint8_t)s0;
+				} else {
+					const size_t step = depth / 8;
+					const uint8_t* px = &cur[(size_t)x * bpp];
+					out[0] = px[0]; out[1] = px[step]; out[2] = px[2 * step];
+				}
+			}
+			prev.swap(cur);
+		}
 	}
 	return t;
 }
