@@ -78,7 +78,19 @@ typedef struct ssx_texture { uint32_t width, height; const uint8_t* rgb; } ssx_t
 
 /* RENDER_MODE_SPECTRAL_ALGNUM (src/stdafx.hpp:63-73): how a texel's linear RGB becomes a
  * reflectance spectrum (Color::lrgb_to_specrefl, src/util/color.cpp:167-232). */
-enum { SSX_UPLIFT_OURS = 1, SSX_UPLIFT_JH = 3 };
+enum { SSX_UPLIFT_OURS = 1, SSX_UPLIFT_MENG = 2, SSX_UPLIFT_JH = 3 };
+
+/* Meng et al. 2015 grid (RENDER_MODE_SPECTRAL_MENG): the tables the reference compiles in from
+ * src/meng-et-al.-2015/spectra_xyz_5nm_380_780_0.97.h, here passed as data (this library ships no
+ * copy of them; see simple_spectral_amd/meng.py for the file format and converter). */
+typedef struct ssx_meng_grid {
+	uint32_t grid_w, grid_h;       /* spectrum_grid_width/height (:2-3) */
+	uint32_t n_points, n_samples;  /* data points; spectrum_num_samples (:9) */
+	float sample_min, sample_max;  /* spectrum_sample_min/max (:6-7) */
+	float xy_to_uv[6];             /* spectrum_mat_xy_to_uv (:23-27) */
+	const int32_t* cells;          /* grid_w*grid_h x {inside, num_points, idx[6]} (spectrum_grid_cell_t, :58-63) */
+	const float* points;           /* n_points x {xystar[2], uv[2], spectrum[n_samples]} (spectrum_data_point_t) */
+} ssx_meng_grid;
 
 /* Everything the kernel reads: the flattened Scene (src/scene.hpp:16-66) + Color::data tables
  * (src/util/color.hpp:22-68). */
@@ -106,6 +118,9 @@ typedef struct ssx_scene_desc {
 	uint32_t jh_res;
 	const float* jh_scale;
 	const float* jh_data;
+	/* SSX_UPLIFT_MENG: the grid (copied at upload); NULL otherwise.  Callers built against the
+	 * struct without this field (smaller struct_size) keep working. */
+	const ssx_meng_grid* meng;
 } ssx_scene_desc;
 
 /* One render = Renderer::render_start..render_wait (src/renderer.cpp:396-430) for this device's

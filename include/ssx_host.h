@@ -22,7 +22,10 @@ typedef struct ssh_scene ssh_scene;
 int ssh_scene_create(const char* scene_name, const char* data_dir, int observer,
                      const uint8_t* tex_rgb, uint32_t tex_w, uint32_t tex_h, const char* texture_path,
                      float light_scale, ssh_scene** out);
-/* As ssh_scene_create, plus the uplift variant (SSX_UPLIFT_OURS | SSX_UPLIFT_JH).  For JH the model is
+/* As ssh_scene_create, plus the uplift variant (SSX_UPLIFT_OURS | SSX_UPLIFT_MENG | SSX_UPLIFT_JH).
+ * For MENG, jh_coeff_path names the grid file ("SSXMENG1", simple_spectral_amd/host/meng2015.hpp;
+ * -1 when missing) and ssh_xyza_to_srgba applies the Meng output transform (src/util/color.cpp:
+ * 243-254); like JH it requires the CIE 1931 observer.  For JH the model is
  * loaded from jh_coeff_path when that file exists ("SPEC" format of rgb2spec_load), otherwise
  * fitted by the library's own optimiser at resolution jh_res (and written to jh_coeff_path when one
  * is given).  JH requires the CIE 1931 observer (src/stdafx.hpp:107-109).  Bit 8 (0x100) of `uplift`

@@ -125,6 +125,13 @@ typedef struct {
 	int jh_res;
 	float* jh_scale;
 	float* jh_data;
+	/* RENDER_MODE_SPECTRAL_MENG: the grid of meng-et-al.-2015/spectra_xyz_5nm_380_780_0.97.h as
+	 * data (never copied into this repo: read out of oracle/_ref/libref_meng.so or a user's file);
+	 * meng_points == NULL -> not Meng */
+	int meng_grid_w, meng_grid_h, meng_n_points, meng_n_samples;
+	float meng_sample_min, meng_sample_max, meng_xy_to_uv[6];
+	int32_t* meng_cells;   /* grid_w*grid_h x {inside, num_points, idx[6]} (spectrum_grid_cell_t) */
+	float* meng_points;    /* n_points x {xystar[2], uv[2], spectrum[n_samples]} (spectrum_data_point_t) */
 } orc_color;
 
 /* counters for the survey's per-sample work statistics */
@@ -144,6 +151,11 @@ void orc_color_destroy(orc_color*);
 int orc_color_set_jh(orc_color*, int res, const float* scale, const float* data);
 void orc_jh_fetch(const orc_color*, const float rgb[3], float out[3]);  /* rgb2spec.c:77-118 */
 float orc_jh_eval_precise(const float coeff[3], float lambda);          /* rgb2spec.c:129-133 */
+/* switch the uplift to Meng et al. 2015 with the given grid (copied); points == NULL switches back.
+ * Also switches ciexyz_to_srgb to the Meng variant (color.cpp:243-254). */
+int orc_color_set_meng(orc_color*, int grid_w, int grid_h, int n_points, int n_samples, float sample_min,
+                       float sample_max, const float xy_to_uv[6], const int32_t* cells, const float* points);
+float orc_meng_xyz_to_p(const orc_color*, float lambda, const float xyz[3]); /* spectrum_grid.h:13-134 */
 
 /* Scene::get_new_* (scene.cpp:32-415).  name in {cornell, cornell-srgb, plane-srgb}.
  * tex_rgb/tex_w/tex_h: decoded RGB8 texture for the -srgb scenes (rows top-to-bottom). */

@@ -3,6 +3,7 @@
  * roundf, floorf) exactly where the reference calls std::pow/exp/round/floor on float. */
 #include "oracle_internal.h"
 
+#include <float.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -332,6 +333,7 @@ void orc_color_destroy(orc_color* cd) {
 	orc_spectrum_free(&cd->D65_orig); orc_spectrum_free(&cd->D65_rad);
 	orc_spectrum_free(&cd->basis_r); orc_spectrum_free(&cd->basis_g); orc_spectrum_free(&cd->basis_b);
 	free(cd->jh_scale); free(cd->jh_data);
+	free(cd->meng_cells); free(cd->meng_points);
 	free(cd);
 }
 
@@ -403,9 +405,87 @@ float orc_jh_eval_precise(const float coeff[3], float lambda) {
 	return (.5f * x) * y + .5f;
 }
 
+/* ---- Meng et al. 2015 (reference src/meng-et-al.-2015/spectrum_grid.h; tables passed in as data) ---- */
+int orc_color_set_meng(orc_color* cd, int grid_w, int grid_h, int n_points, int n_samples, float sample_min,
+                       float sample_max, const float xy_to_uv[6], const int32_t* cells, const float* points) {
+	free(cd->meng_cells); free(cd->meng_points);
+	cd->meng_cells = NULL; cd->meng_points = NULL;
+	if (!points) return 0;
+	if (cd->observer != 1931) { orc_set_error("%s", "Meng needs the CIE 1931 observer (stdafx.hpp:107-109)"); return -3; }
+	if (grid_w <= 0 || grid_h <= 0 || n_points <= 0 || n_samples < 2 || !cells) { orc_set_error("%s", "bad Meng grid"); return -1; }
+	size_t nc = (size_t)grid_w * grid_h * 8, np_ = (size_t)n_points * (4 + (size_t)n_samples);
+	cd->meng_cells = (int32_t*)malloc(sizeof(int32_t) * nc);
+	cd->meng_points = (float*)malloc(sizeof(float) * np_);
+	memcpy(cd->meng_cells, cells, sizeof(int32_t) * nc);
+	memcpy(cd->meng_points, points, sizeof(float) * np_);
+	cd->meng_grid_w = grid_w; cd->meng_grid_h = grid_h; cd->meng_n_points = n_points; cd->meng_n_samples = n_samples;
+	cd->meng_sample_min = sample_min; cd->meng_sample_max = sample_max;
+	memcpy(cd->meng_xy_to_uv, xy_to_uv, sizeof(float) * 6);
+	return 0;
+}
+/* spectrum_grid.h:13-134, expression by expression */
+float orc_meng_xyz_to_p(const orc_color* cd, float lambda, const float xyz[3]) {
+	const int ns = cd->meng_n_samples, stride = 4 + ns;
+	const float* pts = cd->meng_points;
+	float uv[2];
+	/* :19 `1.0/(x+y+z)`: float sum, double division, rounded to float */
+	const float norm = (float)(1.0 / (double)((xyz[0] + xyz[1]) + xyz[2]));
+	if (!(norm < FLT_MAX)) return 0.0f;                                        /* :20-23 */
+	const float x = xyz[0] * norm, y = xyz[1] * norm;                          /* :25-26 */
+	const float* m = cd->meng_xy_to_uv;                                        /* :30, spectra_...h:34-38 */
+	uv[0] = (m[0] * x + m[1] * y) + m[2];
+	uv[1] = (m[3] * x + m[4] * y) + m[5];
+	if (uv[0] < 0.0f || uv[0] >= (float)cd->meng_grid_w || uv[1] < 0.0f || uv[1] >= (float)cd->meng_grid_h) return 0.f; /* :32-36 */
+	const int uvi0 = (int)uv[0], uvi1 = (int)uv[1];                            /* :38 */
+	const int32_t* cell = cd->meng_cells + 8 * (uvi0 + cd->meng_grid_w * uvi1); /* :42-46 */
+	const int inside = cell[0], num = cell[1];
+	const int32_t* idx = cell + 2;
+	float p[6] = { 0, 0, 0, 0, 0, 0 };
+	/* :55-56 */
+	const float sb = (lambda - cd->meng_sample_min) / (cd->meng_sample_max - cd->meng_sample_min) * (float)(ns - 1);
+	const int sb0 = (int)sb;                                                   /* :60 */
+	const int sb1 = (int)(sb + 1 < (float)ns ? sb + 1 : (float)(ns - 1));      /* :61: float ?: int -> float -> int */
+	const float sbf = sb - (float)sb0;                                         /* :62 */
+	for (int i = 0; i < num; ++i) {                                            /* :63-70 */
+		const float* spectrum = pts + (size_t)stride * idx[i] + 4;
+		p[i] = spectrum[sb0] * (1.0f - sbf) + spectrum[sb1] * sbf;
+	}
+	float interpolated_p = 0.0f;
+	if (inside) {                                                              /* :74-88 */
+		const float u = uv[0] - (float)uvi0, v = uv[1] - (float)uvi1;
+		interpolated_p = ((p[0] * (1.0f - u) * (1.0f - v) + p[2] * (1.0f - u) * v) + p[3] * u * v) + p[1] * u * (1.0f - v);
+	} else if (num > 0) {                                                      /* :89-131 (num == 0: loop body never runs) */
+		const float* P0 = pts + (size_t)stride * idx[0];
+		const float* P1 = pts + (size_t)stride * idx[1];
+		const float ex = uv[0] - P0[2], ey = uv[1] - P0[3];
+		float e0x = P1[2] - P0[2], e0y = P1[3] - P0[3];
+		float uu = e0x * ey - ex * e0y;
+		for (int i = 0; i < num - 1; i++) {
+			const float* Pn = (i == num - 2) ? P1 : pts + (size_t)stride * idx[i + 2];
+			const float e1x = Pn[2] - P0[2], e1y = Pn[3] - P0[3];
+			const float vv = ex * e1y - e1x * ey;
+			const float area = e0x * e1y - e1x * e0y;
+			const float u = uu / area, v = vv / area;
+			const float w = 1.0f - u - v;
+			if (u < 0.0 || v < 0.0 || w < 0.0) { uu = -vv; e0x = e1x; e0y = e1y; continue; }
+			interpolated_p = (p[0] * w + p[i + 1] * v) + p[(i == num - 2) ? 1 : (i + 2)] * u;
+			break;
+		}
+	}
+	return interpolated_p / norm;                                              /* :133 */
+}
+
 /* color.cpp:167-173 (ours): r*basis.r[l0] + g*basis.g[l0] + b*basis.b[l0] (scalar*vec4, left to right);
  * color.cpp:203-232 (JH): fetch the coefficients, evaluate at lambda_0 + i*LAMBDA_STEP */
 void orc_lrgb_to_specrefl(const orc_color* cd, const float lrgb[3], float lambda_0, float out[4]) {
+	if (cd->meng_points) { /* color.cpp:175-201: (transpose(mat3(..)) * 100.0f) * lrgb, then spectrum_xyz_to_p per wavelength */
+		static const float rows[9] = { 0.41231515f, 0.3576f, 0.1805f,  0.2126f, 0.7152f, 0.0722f,  0.01932727f, 0.1192f, 0.95063333f };
+		float xyz_rel[3];
+		for (int r = 0; r < 3; ++r)
+			xyz_rel[r] = ((rows[3 * r] * 100.0f) * lrgb[0] + (rows[3 * r + 1] * 100.0f) * lrgb[1]) + (rows[3 * r + 2] * 100.0f) * lrgb[2];
+		for (size_t i = 0; i < ORC_NWAVE; ++i) out[i] = orc_meng_xyz_to_p(cd, lambda_0 + (float)i * cd->lambda_step, xyz_rel);
+		return;
+	}
 	if (cd->jh_res > 0) {
 		float coeffs[3];
 		orc_jh_fetch(cd, lrgb, coeffs);
@@ -436,6 +516,13 @@ void orc_specradflux_to_ciexyz_hero(const orc_color* cd, const float flux[4], fl
 void orc_xyza_to_srgba(const orc_color* cd, const float* xyza, float* srgba, size_t n) {
 	for (size_t p = 0; p < n; ++p) {
 		float lrgb[3];
+		if (cd->meng_points) { /* color.cpp:243-254: xyz / D65_rad_XYZ.y, then Meng's inverse matrix */
+			static const float rows[9] = { 3.24156456f, -1.53766524f, -0.49870224f,  -0.96920119f, 1.87588535f, 0.04155324f,
+			                               0.05562416f, -0.20395525f, 1.05685902f };
+			float rel[3];
+			for (int c = 0; c < 3; ++c) rel[c] = xyza[4 * p + c] / cd->D65_rad_XYZ[1];
+			for (int r = 0; r < 3; ++r) lrgb[r] = (rows[3 * r] * rel[0] + rows[3 * r + 1] * rel[1]) + rows[3 * r + 2] * rel[2];
+		} else
 		orc_mat3_mul_vec3(cd->matr_xyz_to_lrgb, xyza + 4 * p, lrgb);
 		orc_lrgb_to_srgb(lrgb, srgba + 4 * p);
 		srgba[4 * p + 3] = xyza[4 * p + 3];

@@ -29,6 +29,12 @@ class SsxTexture(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("rgb", C.POINTER(C.c_uint8))]
 
 
+class SsxMengGrid(C.Structure):
+    _fields_ = [("grid_w", C.c_uint32), ("grid_h", C.c_uint32), ("n_points", C.c_uint32), ("n_samples", C.c_uint32),
+                ("sample_min", C.c_float), ("sample_max", C.c_float), ("xy_to_uv", C.c_float * 6),
+                ("cells", C.POINTER(C.c_int32)), ("points", C.POINTER(C.c_float))]
+
+
 class SsxSceneDesc(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("reserved", C.c_uint32),
@@ -45,6 +51,7 @@ class SsxSceneDesc(C.Structure):
         ("srgb_to_linear", C.c_float * 256),
         ("uplift", C.c_uint32), ("jh_res", C.c_uint32),
         ("jh_scale", C.POINTER(C.c_float)), ("jh_data", C.POINTER(C.c_float)),
+        ("meng", C.POINTER(SsxMengGrid)),
     ]
 
 
@@ -55,7 +62,7 @@ class SsxRenderParams(C.Structure):
                 ("seed", C.c_uint64)]
 
 
-SSX_UPLIFT_OURS, SSX_UPLIFT_JH = 1, 3
+SSX_UPLIFT_OURS, SSX_UPLIFT_MENG, SSX_UPLIFT_JH = 1, 2, 3
 SSX_OK, SSX_ERR_DATA, SSX_ERR_ARG, SSX_ERR_SCENE, SSX_ERR_DEVICE, SSX_ERR_STATE = 0, -1, -2, -3, -10, -11
 
 # every symbol include/ssx.h and include/ssx_host.h declare (tests check the libraries export them)

@@ -16,7 +16,7 @@ HIP_SRC = [os.path.join(PKG, "csrc", f) for f in ("ssx_api.hip",)]
 HIP_DEPS = [os.path.join(PKG, "csrc", f) for f in ("ssx_api.hip", "ssx_kernels.hip", "ssx_blob.h")] + [
     os.path.join(ROOT, "include", f) for f in ("ssx.h", "ssx_fmath.h")]
 HOST_SRC = [os.path.join(PKG, "host", f) for f in
-            ("spectrum.cpp", "color.cpp", "jh2019.cpp", "scene.cpp", "image_io.cpp", "renderer.cpp", "host_api.cpp")]
+            ("spectrum.cpp", "color.cpp", "jh2019.cpp", "meng2015.cpp", "scene.cpp", "image_io.cpp", "renderer.cpp", "host_api.cpp")]
 HOST_DEPS = HOST_SRC + [os.path.join(PKG, "host", f) for f in
                         ("spectrum.hpp", "color.hpp", "jh2019.hpp", "scene.hpp", "image_io.hpp", "renderer.hpp")] + [
     os.path.join(ROOT, "include", f) for f in ("ssx.h", "ssx_host.h")]

@@ -139,6 +139,8 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	if (s->uplift == SSX_UPLIFT_JH) {
 		h.jh_res = s->jh_res;
 		h.off_jh_scale = off;  off = align4(off + s->jh_res);
+	}
+	if (s->uplift == SSX_UPLIFT_JH || s->uplift == SSX_UPLIFT_MENG) { // the uplift's table in HBM (JH coefficients / Meng grid)
 		h.jh_data_lo = (uint32_t)(uintptr_t)d_jh; h.jh_data_hi = (uint32_t)((uint64_t)(uintptr_t)d_jh >> 32);
 	}
 	h.total_words = off;
@@ -490,6 +492,13 @@ void ssx_destroy(ssx_ctx* ctx) {
 
 int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 	if (!ctx) return SSX_ERR_ARG;
+	ssx_scene_desc local;
+	if (s && s->struct_size == offsetof(ssx_scene_desc, meng)) { // caller built before the Meng field existed
+		memcpy(&local, s, offsetof(ssx_scene_desc, meng));
+		local.meng = nullptr;
+		local.struct_size = sizeof(ssx_scene_desc);
+		s = &local;
+	}
 	if (!s || s->struct_size != sizeof(ssx_scene_desc)) return fail(ctx, SSX_ERR_ARG, "ssx_scene_desc.struct_size mismatch");
 	if (ctx->rendering.load()) return fail(ctx, SSX_ERR_STATE, "render in progress");
 	SSX_HIP(ctx, hipSetDevice(ctx->device));
@@ -506,8 +515,34 @@ int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 		ctx->d_textures.push_back(d);
 		SSX_HIP(ctx, hipMemcpy(d, t.rgb, bytes, hipMemcpyHostToDevice));
 	}
-	if (s->uplift != SSX_UPLIFT_OURS && s->uplift != SSX_UPLIFT_JH) return fail(ctx, SSX_ERR_SCENE, "unsupported uplift variant (1 = basis, 3 = Jakob-Hanika)");
+	if (s->uplift != SSX_UPLIFT_OURS && s->uplift != SSX_UPLIFT_JH && s->uplift != SSX_UPLIFT_MENG)
+		return fail(ctx, SSX_ERR_SCENE, "unsupported uplift variant (1 = basis, 2 = Meng et al., 3 = Jakob-Hanika)");
 	if (ctx->d_jh_data) { (void)hipFree(ctx->d_jh_data); ctx->d_jh_data = nullptr; }
+	if (s->uplift == SSX_UPLIFT_MENG) {
+		// device table: 16 header words, cells, points (layout documented at meng_uplift in ssx_kernels.hip)
+		const ssx_meng_grid* g = s->meng;
+		if (!g || !g->cells || !g->points || g->grid_w == 0 || g->grid_h == 0 || g->grid_w > 4096 || g->grid_h > 4096 ||
+		    g->n_points == 0 || g->n_points > (1u << 20) || g->n_samples < 2 || g->n_samples > 4096 || !(g->sample_max > g->sample_min))
+			return fail(ctx, SSX_ERR_DATA, "Meng grid missing or invalid");
+		const size_t n_cells = (size_t)g->grid_w * g->grid_h;
+		for (size_t c = 0; c < n_cells; ++c) {
+			const int32_t* cell = g->cells + 8 * c;
+			const int32_t inside = cell[0], num = cell[1];
+			// what spectrum_xyz_to_p can read without leaving the tables (spectrum_grid.h:47-131)
+			const bool shape_ok = inside ? (num == 4) : (num == 0 || (num >= 3 && num <= 6));
+			if (!shape_ok) return fail(ctx, SSX_ERR_DATA, "Meng grid: cell with an unusable point count");
+			for (int32_t k = 0; k < num; ++k) if (cell[2 + k] < 0 || (uint32_t)cell[2 + k] >= g->n_points) return fail(ctx, SSX_ERR_DATA, "Meng grid: point index out of range");
+		}
+		const size_t words = 16 + n_cells * 8 + (size_t)g->n_points * (4 + (size_t)g->n_samples);
+		std::vector<uint32_t> tab(words, 0u);
+		tab[0] = g->grid_w; tab[1] = g->grid_h; tab[2] = g->n_points; tab[3] = g->n_samples;
+		memcpy(&tab[4], &g->sample_min, 4); memcpy(&tab[5], &g->sample_max, 4);
+		memcpy(&tab[6], g->xy_to_uv, 24);
+		memcpy(&tab[16], g->cells, n_cells * 32);
+		memcpy(&tab[16 + n_cells * 8], g->points, (size_t)g->n_points * (4 + (size_t)g->n_samples) * 4);
+		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_jh_data, words * 4));
+		SSX_HIP(ctx, hipMemcpy(ctx->d_jh_data, tab.data(), words * 4, hipMemcpyHostToDevice));
+	}
 	if (s->uplift == SSX_UPLIFT_JH) {
 		// rgb2spec_load returns NULL for a missing table and the reference then crashes (color.cpp:144,220)
 		if (!s->jh_scale || !s->jh_data || s->jh_res < 2 || s->jh_res > 256) return fail(ctx, SSX_ERR_DATA, "Jakob-Hanika model missing or invalid");

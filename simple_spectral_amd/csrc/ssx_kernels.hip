@@ -223,6 +223,101 @@ __device__ __forceinline__ Hero jh_uplift(const Lds& L, float r, float g, float 
 	return out;
 }
 
+// Meng et al. 2015 uplift: util/color.cpp:175-201 -> meng-et-al.-2015/spectrum_grid.h:13-134.
+// The grid lives in HBM behind the header's table pointer as words
+//   [0..3] grid_w, grid_h, n_points, n_samples  [4..5] sample_min, sample_max  [6..11] xy->uv  [12..15] 0
+//   cells: grid_w*grid_h x {inside, num_points, idx[6]}    points: n_points x {xystar[2], uv[2], spectrum[n_samples]}
+// (69 KB: L2-resident).  spectrum_xyz_to_p is evaluated once per hero wavelength by the
+// reference; everything but the spectral bin is wavelength-independent, so the cell lookup and the
+// triangle-fan search run once and only the per-point interpolation runs four times -- same
+// expressions, same operation order, same results.
+__device__ __forceinline__ Hero meng_uplift(const Lds& L, float r, float g, float b, float lambda_0) {
+	const SsxBlobHeader& h = L.hdr();
+	const uint32_t* tab = reinterpret_cast<const uint32_t*>(((uint64_t)h.jh_data_hi << 32) | (uint64_t)h.jh_data_lo);
+	const int gw = (int)tab[0], gh = (int)tab[1], ns = (int)tab[3];
+	const float smin = __uint_as_float(tab[4]), smax = __uint_as_float(tab[5]);
+	const float* m = reinterpret_cast<const float*>(tab + 6);
+	const int32_t* cells = reinterpret_cast<const int32_t*>(tab + 16);
+	const float* pts = reinterpret_cast<const float*>(tab + 16 + gw * gh * 8);
+	const int stride = 4 + ns;
+	Hero out;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) out.v[k] = 0.0f;
+	// xyz_rel = (transpose(mat3(...)) * 100.0f) * lrgb  (color.cpp:189-193; GLM mat*scalar then mat*vec)
+	const float X = ((0.41231515f * 100.0f) * r + (0.3576f * 100.0f) * g) + (0.1805f * 100.0f) * b;
+	const float Y = ((0.2126f * 100.0f) * r + (0.7152f * 100.0f) * g) + (0.0722f * 100.0f) * b;
+	const float Z = ((0.01932727f * 100.0f) * r + (0.1192f * 100.0f) * g) + (0.95063333f * 100.0f) * b;
+	const float norm = (float)(1.0 / (double)((X + Y) + Z));                 // :19 double division
+	if (!(norm < 3.402823466e+38f)) return out;                              // :20-23
+	const float x = X * norm, y = Y * norm;
+	const float u0 = (m[0] * x + m[1] * y) + m[2], v0 = (m[3] * x + m[4] * y) + m[5];
+	if (u0 < 0.0f || u0 >= (float)gw || v0 < 0.0f || v0 >= (float)gh) return out; // :32-36
+	const int ui = (int)u0, vi = (int)v0;
+	const int32_t* cell = cells + 8 * (ui + gw * vi);
+	const int inside = cell[0], num = cell[1];
+	// the (up to four) data points that contribute and their weights, in the order the reference sums them
+	int pa = 0, pb = 0, pc = 0, pd = 0;
+	float wa = 0.0f, wb = 0.0f, wc = 0.0f, wd = 0.0f;
+	bool found = false;
+	if (inside) {                                                            // :74-88
+		const float u = u0 - (float)ui, v = v0 - (float)vi;
+		pa = cell[2]; pb = cell[4]; pc = cell[5]; pd = cell[3];                // p[0], p[2], p[3], p[1]
+		found = true;
+		// weights are applied as p*(f1)*(f2): keep both factors
+		wa = u; wb = v;                                                        // (decoded below)
+	} else if (num > 0) {                                                    // :89-131
+		const float* P0 = pts + stride * cell[2];
+		const float* P1 = pts + stride * cell[3];
+		const float p0u = P0[2], p0v = P0[3];
+		const float ex = u0 - p0u, ey = v0 - p0v;
+		float e0x = P1[2] - p0u, e0y = P1[3] - p0v;
+		float uu = e0x * ey - ex * e0y;
+		for (int i = 0; i < num - 1; ++i) {
+			const int third = (i == num - 2) ? 1 : (i + 2);
+			const float* Pn = pts + stride * cell[2 + third];
+			const float e1x = Pn[2] - p0u, e1y = Pn[3] - p0v;
+			const float vv = ex * e1y - e1x * ey;
+			const float area = e0x * e1y - e1x * e0y;
+			const float u = uu / area, v = vv / area;
+			const float w = 1.0f - u - v;
+			if (u < 0.0f || v < 0.0f || w < 0.0f) { uu = -vv; e0x = e1x; e0y = e1y; continue; }
+			pa = cell[2]; pb = cell[2 + i + 1]; pc = cell[2 + third];
+			wa = w; wb = v; wc = u;
+			found = true;
+			break;
+		}
+	}
+	if (!found) { // interpolated_p stays 0: 0/norm == +0 for the finite positive norm that got here
+		return out;
+	}
+	const float* Sa = pts + stride * pa + 4;
+	const float* Sb = pts + stride * pb + 4;
+	const float* Sc = pts + stride * pc + 4;
+	const float* Sd = pts + stride * pd + 4;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const float lambda = lambda_0 + (float)k * h.lambda_step;              // color.cpp:197
+		const float sb = (lambda - smin) / (smax - smin) * (float)(ns - 1);    // :55-56
+		const int sb0 = (int)sb;
+		const int sb1 = (int)((sb + 1.0f < (float)ns) ? sb + 1.0f : (float)(ns - 1)); // :61
+		const float sbf = sb - (float)sb0;
+		const float qa = Sa[sb0] * (1.0f - sbf) + Sa[sb1] * sbf;               // :69
+		const float qb = Sb[sb0] * (1.0f - sbf) + Sb[sb1] * sbf;
+		const float qc = Sc[sb0] * (1.0f - sbf) + Sc[sb1] * sbf;
+		float ip;
+		if (inside) {
+			const float qd = Sd[sb0] * (1.0f - sbf) + Sd[sb1] * sbf;
+			const float u = wa, v = wb;
+			// p[0]*(1-u)*(1-v) + p[2]*(1-u)*v + p[3]*u*v + p[1]*u*(1-v)   (:86-88)
+			ip = ((qa * (1.0f - u) * (1.0f - v) + qb * (1.0f - u) * v) + qc * u * v) + qd * u * (1.0f - v);
+		} else {
+			ip = (qa * wa + qb * wb) + qc * wc;                                  // :128
+		}
+		out.v[k] = ip / norm;                                                  // :133
+	}
+	return out;
+}
+
 // material.cpp:45-97 + util/color.cpp:167-173 ("ours" basis uplift)
 __device__ __forceinline__ Hero texture_sample(const Lds& L, uint32_t tex_index, float st_x, float st_y, float lambda_0) {
 	const SsxBlobTexture t = L.texture(tex_index);
@@ -237,6 +332,7 @@ __device__ __forceinline__ Hero texture_sample(const Lds& L, uint32_t tex_index,
 	float r = L.lut(px[0]), g = L.lut(px[1]), b = L.lut(px[2]);
 	const SsxBlobHeader& h = L.hdr();
 	if (h.uplift == 3u) return jh_uplift(L, r, g, b, lambda_0); // RENDER_MODE_SPECTRAL_JH (wave-uniform)
+	if (h.uplift == 2u) return meng_uplift(L, r, g, b, lambda_0); // RENDER_MODE_SPECTRAL_MENG
 	Hero br, bg, bb;
 	const SsxBlobSpectrum sr = L.spectrum(h.spec_basis_r), sg = L.spectrum(h.spec_basis_g), sb = L.spectrum(h.spec_basis_b);
 	if (h.basis_one_grid) { // wave-uniform: r, g, b tables have the same (low, delta_recip, n)

@@ -21,10 +21,13 @@ public:
 	float D65_orig_XYZ[3], D65_rad_XYZ[3];
 	Spectrum basis_r, basis_g, basis_b;
 	Mat3 matr_lrgb_to_xyz, matr_xyz_to_lrgb;
+	// RENDER_MODE_SPECTRAL_MENG swaps the output transform for the authors' matrix applied to
+	// xyz / D65_rad_XYZ.y (color.cpp:243-254); set by whoever selects that uplift.
+	bool meng_output_transform = false;
 
 	void specradflux_to_ciexyz(const Spectrum& flux, float xyz[3]) const; // color.hpp:106-111
 	void ciexyz_to_lrgb(const float xyz[3], float lrgb[3]) const;         // color.hpp:150-152
-	void ciexyz_to_srgb(const float xyz[3], float srgb[3]) const;         // color.cpp:238-242
+	void ciexyz_to_srgb(const float xyz[3], float srgb[3]) const;         // color.cpp:238-254
 	void round_trip_lrgb(const float lrgb_in[3], float lrgb_out[3]) const; // color.cpp:260-289
 };
 

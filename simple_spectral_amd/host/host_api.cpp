@@ -12,6 +12,7 @@
 struct ssh_scene {
 	std::unique_ptr<ssx::ColorData> color;
 	std::unique_ptr<ssx::JHModel> jh;
+	std::unique_ptr<ssx::MengGrid> meng;
 	std::unique_ptr<ssx::Scene> scene;
 };
 
@@ -46,6 +47,10 @@ int ssh_scene_create_ex(const char* scene_name, const char* data_dir, int observ
 				s->jh = std::make_unique<ssx::JHModel>(ssx::jh_optimize(*s->color, jh_res ? jh_res : 64u));
 				if (!path.empty()) ssx::jh_save(*s->jh, path);
 			}
+		} else if (uplift == SSX_UPLIFT_MENG) { // jh_coeff_path names the grid file (meng2015.hpp)
+			if (observer != 1931) throw ssx::HostError{ -3, "Only our algorithm currently implements support for the newest CIE standard observer!" };
+			s->meng = std::make_unique<ssx::MengGrid>(ssx::meng_load(jh_coeff_path ? jh_coeff_path : ""));
+			s->color->meng_output_transform = true;
 		} else if (uplift != SSX_UPLIFT_OURS) {
 			throw ssx::HostError{ -3, "unsupported uplift variant" };
 		}
@@ -59,7 +64,7 @@ int ssh_scene_create_ex(const char* scene_name, const char* data_dir, int observ
 			tex = ssx::load_png_rgb8(texture_path);
 			texp = &tex;
 		}
-		s->scene = std::make_unique<ssx::Scene>(*s->color, scene_name, data_dir, texp, light_scale, s->jh.get(), els);
+		s->scene = std::make_unique<ssx::Scene>(*s->color, scene_name, data_dir, texp, light_scale, s->jh.get(), els, s->meng.get());
 		*out = s.release();
 		return SSX_OK;
 	} catch (const ssx::HostError& e) {

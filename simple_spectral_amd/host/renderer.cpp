@@ -98,10 +98,13 @@ Renderer::Renderer(const Options& opts) : options(opts), framebuffer(opts.res), 
 			jh = std::make_unique<JHModel>(jh_optimize(*color, 64));
 			try { jh_save(*jh, path); } catch (const HostError&) {}
 		}
+	} else if (options.uplift == SSX_UPLIFT_MENG) {
+		meng = std::make_unique<MengGrid>(meng_load(options.meng_grid_path.empty() ? options.data_dir + "/meng-et-al-2015-grid.bin" : options.meng_grid_path));
+		color->meng_output_transform = true;
 	} else if (options.uplift != SSX_UPLIFT_OURS) {
 		throw HostError{ -3, "unsupported uplift variant" };
 	}
-	scene = std::make_unique<Scene>(*color, options.scene_name, options.data_dir, texp, options.light_scale, jh.get(), options.explicit_light_sampling);
+	scene = std::make_unique<Scene>(*color, options.scene_name, options.data_dir, texp, options.light_scale, jh.get(), options.explicit_light_sampling, meng.get());
 
 	api_ = std::make_unique<Api>(options.hip_library.empty() ? default_hip_library() : options.hip_library);
 	const int n = options.gpus < 1 ? 1 : options.gpus;

@@ -245,15 +245,17 @@ void Scene::finish() {
 	desc_.lights = lights_.data(); desc_.n_lights = static_cast<uint32_t>(lights_.size());
 	desc_.textures = texture_descs_.data(); desc_.n_textures = static_cast<uint32_t>(texture_descs_.size());
 	// texel decode table: (u8 * (1/255)) -> srgb_to_lrgb, as sRGB_ReflectanceTexture::sample does per texel
-	desc_.uplift = jh_ ? SSX_UPLIFT_JH : SSX_UPLIFT_OURS;
+	desc_.uplift = meng_ ? SSX_UPLIFT_MENG : (jh_ ? SSX_UPLIFT_JH : SSX_UPLIFT_OURS);
 	if (jh_) { desc_.jh_res = jh_->res; desc_.jh_scale = jh_->scale.data(); desc_.jh_data = jh_->data.data(); }
+	if (meng_) { meng_desc_ = meng_->desc(); desc_.meng = &meng_desc_; }
 	for (int u = 0; u < 256; ++u) desc_.srgb_to_linear[u] = srgb_to_lrgb(static_cast<float>(static_cast<uint8_t>(u)) * (1.0f / 255.0f));
 }
 
 Scene::Scene(const ColorData& color, const std::string& scene_name, const std::string& data_dir, const Texture* texture, float light_scale,
-             const JHModel* jh, bool explicit_light_sampling)
-	: name(scene_name), color_(color), jh_(jh), els_(explicit_light_sampling) {
-	if (jh_ && color_.observer != 1931) throw HostError{ -3, "Only our algorithm currently implements support for the newest CIE standard observer!" }; // stdafx.hpp:107-109
+             const JHModel* jh, bool explicit_light_sampling, const MengGrid* meng)
+	: name(scene_name), color_(color), jh_(jh), meng_(meng), els_(explicit_light_sampling) {
+	if (jh_ && meng_) throw HostError{ -3, "one uplift at a time" };
+	if ((jh_ || meng_) && color_.observer != 1931) throw HostError{ -3, "Only our algorithm currently implements support for the newest CIE standard observer!" }; // stdafx.hpp:107-109
 	// MaterialBase's default emission: constant 0 over the rendered band (src/material.hpp:95-96)
 	zero_emission_ = add_spectrum(Spectrum(0.0f, color_.lambda_min, color_.lambda_max));
 	if (name == "cornell") build_cornell(data_dir);

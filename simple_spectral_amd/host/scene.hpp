@@ -6,6 +6,7 @@
 #include "../../include/ssx.h"
 #include "color.hpp"
 #include "jh2019.hpp"
+#include "meng2015.hpp"
 
 #include <cstdint>
 #include <memory>
@@ -31,9 +32,10 @@ public:
 	// name: "cornell" | "cornell-srgb" | "plane-srgb" (src/renderer.cpp:17-38; anything else -> -3).
 	// texture: decoded image for the -srgb scenes; light_scale: `lightsc` of src/scene.cpp:291-293.
 	// jh: Jakob-Hanika model to uplift texels with (RENDER_MODE_SPECTRAL_JH), or nullptr for the
-	// basis uplift (RENDER_MODE_SPECTRAL_OURS, the reference's default).
+	// basis uplift (RENDER_MODE_SPECTRAL_OURS, the reference's default).  meng: the Meng et al. grid
+	// (RENDER_MODE_SPECTRAL_MENG); at most one of jh / meng.
 	Scene(const ColorData& color, const std::string& name, const std::string& data_dir, const Texture* texture, float light_scale,
-	      const JHModel* jh = nullptr, bool explicit_light_sampling = true);
+	      const JHModel* jh = nullptr, bool explicit_light_sampling = true, const MengGrid* meng = nullptr);
 
 	const ssx_scene_desc& desc() const { return desc_; }
 	Camera camera;
@@ -59,6 +61,8 @@ private:
 	std::vector<ssx_texture> texture_descs_;
 	uint32_t zero_emission_ = 0;
 	const JHModel* jh_ = nullptr;
+	const MengGrid* meng_ = nullptr;
+	ssx_meng_grid meng_desc_{};
 	bool els_ = true;
 	ssx_scene_desc desc_{};
 };

@@ -43,7 +43,8 @@ class Options:
     light_scale: float = 30.0            # lightsc (src/scene.cpp:291-293)
     explicit_light_sampling: bool = True  # EXPLICIT_LIGHT_SAMPLING (src/stdafx.hpp:44); False also makes
     #                                       plane-srgb's textured quad a mirror (src/scene.cpp:346-355)
-    uplift: str = "ours"                 # RENDER_MODE_SPECTRAL_ALGNUM: "ours" (1) | "jh" (3, Jakob-Hanika 2019)
+    uplift: str = "ours"                 # RENDER_MODE_SPECTRAL_ALGNUM: "ours" (1) | "meng" (2, Meng et al. 2015) | "jh" (3, Jakob-Hanika 2019)
+    meng_grid_path: Optional[str] = None  # "SSXMENG1" file converted from the authors' header (simple_spectral_amd/meng.py)
     jh_res: int = 64                     # resolution of the fitted JH model when no coefficient file exists
     jh_coeff_path: Optional[str] = None  # data/jakob-and-hanika-2019-srgb.coeff in the reference (missing blob)
     device: int = 0
@@ -68,7 +69,7 @@ class Scene:
     """Host-prepared scene + colour tables (libssx_host.so)."""
 
     def __init__(self, name, observer=1931, texture=None, light_scale=30.0, data_dir=DEFAULT_DATA_DIR,
-                 uplift="ours", jh_res=64, jh_coeff_path=None, explicit_light_sampling=True):
+                 uplift="ours", jh_res=64, jh_coeff_path=None, explicit_light_sampling=True, meng_grid_path=None):
         lib = _capi.host_lib()
         self._lib = lib
         self._h = C.c_void_p()
@@ -82,12 +83,14 @@ class Scene:
                 if tex_path and not os.path.isabs(tex_path) and not os.path.exists(tex_path):
                     tex_path = os.path.join(data_dir, "scenes", tex_path)
         tp, tw, th = (self._tex.ctypes.data, self._tex.shape[1], self._tex.shape[0]) if self._tex is not None else (None, 0, 0)
-        if uplift not in ("ours", "jh"):
-            raise SsxError(_capi.SSX_ERR_SCENE, "unsupported uplift %r (ours | jh)" % (uplift,))
+        if uplift not in ("ours", "meng", "jh"):
+            raise SsxError(_capi.SSX_ERR_SCENE, "unsupported uplift %r (ours | meng | jh)" % (uplift,))
+        code = {"ours": _capi.SSX_UPLIFT_OURS, "meng": _capi.SSX_UPLIFT_MENG, "jh": _capi.SSX_UPLIFT_JH}[uplift]
+        table_path = (meng_grid_path or os.path.join(data_dir, "meng-et-al-2015-grid.bin")) if uplift == "meng" else jh_coeff_path
         rc = lib.ssh_scene_create_ex(name.encode(), data_dir.encode(), observer, tp, tw, th,
                                      tex_path.encode() if tex_path else None, C.c_float(light_scale),
-                                     (_capi.SSX_UPLIFT_JH if uplift == "jh" else _capi.SSX_UPLIFT_OURS) | (0 if explicit_light_sampling else 0x100),
-                                     jh_coeff_path.encode() if jh_coeff_path else None, jh_res, C.byref(self._h))
+                                     code | (0 if explicit_light_sampling else 0x100),
+                                     table_path.encode() if table_path else None, jh_res, C.byref(self._h))
         if rc != 0:
             raise SsxError(rc, lib.ssh_last_error().decode())
         self.name = name
@@ -139,7 +142,7 @@ class Renderer:
     def __init__(self, options: Options):
         self.options = options
         self.scene = Scene(options.scene_name, options.observer, options.texture, options.light_scale, options.data_dir,
-                           options.uplift, options.jh_res, options.jh_coeff_path, options.explicit_light_sampling)
+                           options.uplift, options.jh_res, options.jh_coeff_path, options.explicit_light_sampling, options.meng_grid_path)
         self._lib = _capi.hip_lib()
         self._ctx = C.c_void_p()
         rc = self._lib.ssx_create(options.device, C.byref(self._ctx))

@@ -93,6 +93,9 @@ def load(variant=""):
     lib.orc_jh_fetch.argtypes = [vp, f32p, f32p]
     lib.orc_jh_eval_precise.restype = C.c_float
     lib.orc_jh_eval_precise.argtypes = [f32p, C.c_float]
+    lib.orc_color_set_meng.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp, vp]
+    lib.orc_meng_xyz_to_p.restype = C.c_float
+    lib.orc_meng_xyz_to_p.argtypes = [vp, C.c_float, f32p]
     lib.orc_scene_create.restype = vp
     lib.orc_scene_create.argtypes = [vp, C.c_char_p, C.c_char_p, vp, C.c_int, C.c_int, C.c_float]
     lib.orc_scene_destroy.argtypes = [vp]
@@ -167,8 +170,10 @@ class Oracle:
     """Colour tables + one scene, with render helpers.  observer: 1931 | 2006."""
 
     def __init__(self, scene="cornell-srgb", observer=1931, texture="test-img.png", light_scale=30.0,
-                 variant="", data_dir=DATA_DIR, jh=None):
-        """jh: (res, scale, data) Jakob-Hanika model -> RENDER_MODE_SPECTRAL_JH; None -> "ours"."""
+                 variant="", data_dir=DATA_DIR, jh=None, meng=None):
+        """jh: (res, scale, data) Jakob-Hanika model -> RENDER_MODE_SPECTRAL_JH; meng: grid dict as
+        returned by ref_lib.meng_table() / simple_spectral_amd.meng.load_table -> RENDER_MODE_SPECTRAL_MENG;
+        neither -> "ours"."""
         self.lib = load(variant)
         self.color = self.lib.orc_color_create(data_dir.encode(), observer)
         if not self.color:
@@ -177,6 +182,13 @@ class Oracle:
             res, scale, data = jh
             scale = np.ascontiguousarray(scale, dtype=np.float32); data = np.ascontiguousarray(data, dtype=np.float32)
             if self.lib.orc_color_set_jh(self.color, int(res), scale.ctypes.data, data.ctypes.data) != 0:
+                raise RuntimeError(self.lib.orc_last_error().decode())
+        if meng is not None:
+            cells = np.ascontiguousarray(meng["cells"], dtype=np.int32); points = np.ascontiguousarray(meng["points"], dtype=np.float32)
+            m = np.ascontiguousarray(meng["xy_to_uv"], dtype=np.float32)
+            if self.lib.orc_color_set_meng(self.color, meng["grid_w"], meng["grid_h"], meng["n_points"], meng["n_samples"],
+                                           C.c_float(meng["sample_min"]), C.c_float(meng["sample_max"]), m.ctypes.data,
+                                           cells.ctypes.data, points.ctypes.data) != 0:
                 raise RuntimeError(self.lib.orc_last_error().decode())
         tex = None
         if texture is not None and scene != "cornell":

@@ -236,3 +236,46 @@ def test_without_explicit_light_sampling_bit_exact(scene):
     ref = o.render(40, 32, 6, seed=3, els=False)
     assert np.array_equal(bits(r.xyza), bits(ref))
     assert not np.array_equal(bits(o.render(40, 32, 6, seed=3)), bits(ref))
+
+
+@pytest.fixture(scope="module")
+def meng_grid(tmp_path_factory):
+    """The Meng et al. grid, read out of the reference's own header through oracle/_ref/libref_meng.so
+    (built in place by `make -C oracle ref`; the .so travels to the GPU box, the header does not)."""
+    import ref_lib
+    from simple_spectral_amd import meng
+    if ref_lib.meng() is None:
+        pytest.skip("oracle/_ref/libref_meng.so not built (needs /root/reference at build time)")
+    table = ref_lib.meng_table()
+    path = str(tmp_path_factory.mktemp("meng") / "grid.bin")
+    meng.save_table(path, table)
+    return table, path
+
+
+@pytest.mark.parametrize("scene,texture,W,H,spp", [("cornell-srgb", "test-img.png", 48, 40, 5), ("plane-srgb", "test-img.png", 48, 40, 5),
+                                                   ("cornell-srgb", "crystal-lizard-512.png", 128, 128, 8)])
+def test_meng_uplift_bit_exact(meng_grid, scene, texture, W, H, spp):
+    """RENDER_MODE_SPECTRAL_ALGNUM 2 (src/util/color.cpp:175-201): texels go through Meng et al.'s
+    spectrum_xyz_to_p.  The oracle's restatement of it is itself pinned bit for bit against the
+    reference's function (tests/test_ref_pins.py), so this is HIP == reference code for the uplift."""
+    table, path = meng_grid
+    r = Renderer(Options(scene_name=scene, res=(W, H), spp=spp, seed=4, texture=texture, uplift="meng", meng_grid_path=path))
+    r.render_start(); r.render_wait()
+    orc = ol.Oracle(scene, texture=texture, meng=table)
+    ref = orc.render(W, H, spp, seed=4)
+    assert np.array_equal(bits(r.xyza), bits(ref))
+    assert np.isfinite(ref).all()
+    ours = ol.Oracle(scene, texture=texture).render(W, H, spp, seed=4)
+    assert not np.array_equal(bits(ours), bits(ref))        # the variant really changes textured pixels
+    # output transform of the variant (color.cpp:243-254), host vs oracle
+    assert np.array_equal(bits(r.framebuffer), bits(orc.to_srgba(ref)))
+
+
+def test_meng_grid_errors(meng_grid, tmp_path):
+    table, path = meng_grid
+    with pytest.raises(SsxError) as e:
+        Renderer(Options(scene_name="cornell-srgb", texture="test-img.png", uplift="meng", meng_grid_path=str(tmp_path / "missing.bin")))
+    assert e.value.code == _capi.SSX_ERR_DATA
+    with pytest.raises(SsxError) as e:
+        Renderer(Options(scene_name="cornell-srgb", texture="test-img.png", uplift="meng", meng_grid_path=path, observer=2006))
+    assert e.value.code == _capi.SSX_ERR_SCENE                # stdafx.hpp:107-109

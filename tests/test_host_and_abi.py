@@ -36,12 +36,12 @@ def test_libraries_export_every_declared_symbol():
 def test_struct_layouts_match_the_headers():
     # sizes the C compiler reports for the ABI structs (guards the ctypes mirrors)
     import subprocess, tempfile
-    src = '#include "ssx.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",sizeof(ssx_spectrum),sizeof(ssx_quad),sizeof(ssx_material),sizeof(ssx_texture),sizeof(ssx_scene_desc),sizeof(ssx_render_params));return 0;}'
+    src = '#include "ssx.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",sizeof(ssx_spectrum),sizeof(ssx_quad),sizeof(ssx_material),sizeof(ssx_texture),sizeof(ssx_scene_desc),sizeof(ssx_render_params),sizeof(ssx_meng_grid));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "t.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
         sizes = list(map(int, subprocess.check_output([os.path.join(d, "t")]).split()))
-    mine = [C.sizeof(x) for x in (_capi.SsxSpectrum, _capi.SsxQuad, _capi.SsxMaterial, _capi.SsxTexture, _capi.SsxSceneDesc, _capi.SsxRenderParams)]
+    mine = [C.sizeof(x) for x in (_capi.SsxSpectrum, _capi.SsxQuad, _capi.SsxMaterial, _capi.SsxTexture, _capi.SsxSceneDesc, _capi.SsxRenderParams, _capi.SsxMengGrid)]
     assert sizes == mine
 
 

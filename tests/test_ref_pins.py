@@ -240,3 +240,104 @@ def test_png_writer_round_trips_through_lodepng_and_back(png_ref, tmp_path):
     assert png_ref.lodepng().ref_png_encode_rgba8(theirs.encode(), expect.ctypes.data, W, H) == 0
     rc, got = host_decode(theirs)
     assert rc == 0 and np.array_equal(got, expect[..., :3])
+
+
+# ------------------------------------------------------------------------------------------------
+# Meng et al. 2015: oracle restatement against the reference's own spectrum_xyz_to_p
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def meng_setup():
+    lib = ref_lib.meng()
+    if lib is None:
+        pytest.skip("oracle/_ref/libref_meng.so not built (needs /root/reference)")
+    table = ref_lib.meng_table()
+    orc = ol.Oracle("cornell-srgb", texture="test-img.png", meng=table)
+    return lib, table, orc
+
+
+def test_meng_grid_shape(meng_setup):
+    _, t, _ = meng_setup
+    assert (t["grid_w"], t["grid_h"], t["n_samples"]) == (12, 14, 81)         # spectra_xyz_5nm_380_780_0.97.h:2-9
+    assert (t["sample_min"], t["sample_max"]) == (380.0, 780.0)
+    assert t["cells"][:, 1].max() <= 6 and t["cells"][:, 2:].max() < t["n_points"]
+
+
+def test_meng_xyz_to_p_bit_identical_to_reference(meng_setup):
+    lib, t, orc = meng_setup
+    rng = np.random.default_rng(5)
+    fp = C.POINTER(C.c_float)
+    M = np.array([[0.41231515, 0.3576, 0.1805], [0.2126, 0.7152, 0.0722], [0.01932727, 0.1192, 0.95063333]], np.float32) * np.float32(100)
+    xyzs = [(M @ rng.random(3, dtype=np.float32)).astype(np.float32) for _ in range(30000)]          # in-gamut colours
+    xyzs += [rng.random(3, dtype=np.float32) * np.float32(100) for _ in range(30000)]                # anything, incl. outside the grid
+    xyzs += [np.array(v, np.float32) for v in ([0, 0, 0], [1, 1, 1], [100, 0, 0], [0, 100, 0], [0, 0, 100], [1e-30, 1e-30, 1e-30],
+                                               [1e-40, 0, 0], [95.047, 100.0, 108.883])]
+    lams = [380.0, 780.0, 555.5, 400.0, 779.999]
+    n_nonzero = 0; n_fan = 0
+    for k, xyz in enumerate(xyzs):
+        for lam in (lams if k % 50 == 0 else (float(rng.uniform(380, 780)),)):
+            a = lib.ref_meng_xyz_to_p(C.c_float(lam), xyz.ctypes.data_as(fp))
+            b = orc.lib.orc_meng_xyz_to_p(orc.color, C.c_float(lam), xyz.ctypes.data_as(fp))
+            assert struct.pack("f", a) == struct.pack("f", b), (xyz, lam, a, b)
+            n_nonzero += a != 0.0
+    assert n_nonzero > 40000          # both the bilinear cells and the boundary fans were exercised
+
+
+def test_meng_lrgb_to_specrefl_uses_reference_function(meng_setup):
+    """color.cpp:175-201: the oracle's per-texel uplift = reference spectrum_xyz_to_p at the 4 hero wavelengths."""
+    lib, t, orc = meng_setup
+    fp = C.POINTER(C.c_float)
+    rng = np.random.default_rng(6)
+    orc.lib.orc_lrgb_to_specrefl.argtypes = [C.c_void_p, fp, C.c_float, fp]
+    rows = np.array([[0.41231515, 0.3576, 0.1805], [0.2126, 0.7152, 0.0722], [0.01932727, 0.1192, 0.95063333]], np.float32)
+    for _ in range(2000):
+        lrgb = rng.random(3, dtype=np.float32)
+        lam0 = np.float32(rng.uniform(380, 480))
+        out = np.zeros(4, np.float32)
+        orc.lib.orc_lrgb_to_specrefl(orc.color, lrgb.ctypes.data_as(fp), C.c_float(lam0), out.ctypes.data_as(fp))
+        m100 = rows * np.float32(100.0)
+        xyz = ((m100[:, 0] * lrgb[0] + m100[:, 1] * lrgb[1]) + m100[:, 2] * lrgb[2]).astype(np.float32)
+        for i in range(4):
+            lam = np.float32(lam0 + np.float32(i) * np.float32(100.0))
+            ref = lib.ref_meng_xyz_to_p(C.c_float(lam), xyz.ctypes.data_as(fp))
+            assert struct.pack("f", ref) == struct.pack("f", out[i])
+
+
+def test_meng_header_converter_file_format_and_host_scene(meng_setup, tmp_path):
+    """simple_spectral_amd/meng.py parses the authors' header as text; its result must equal the
+    tables as the C compiler sees them (libref_meng.so), survive the SSXMENG1 file, and load in the
+    host library; the host's Meng output transform (color.cpp:243-254) equals the oracle's."""
+    from simple_spectral_amd import meng
+    from simple_spectral_amd.renderer import SsxError
+    _, t_ref, orc = meng_setup
+    header = "/root/reference/src/meng-et-al.-2015/spectra_xyz_5nm_380_780_0.97.h"
+    if os.path.exists(header):
+        t_txt = meng.table_from_header(header)
+        for k in ("grid_w", "grid_h", "n_points", "n_samples", "sample_min", "sample_max"):
+            assert t_txt[k] == t_ref[k], k
+        assert np.array_equal(t_txt["cells"], t_ref["cells"])
+        assert np.array_equal(bits(t_txt["points"]), bits(t_ref["points"]))
+        assert np.array_equal(bits(t_txt["xy_to_uv"]), bits(t_ref["xy_to_uv"]))
+    path = str(tmp_path / "grid.bin")
+    meng.save_table(path, t_ref)
+    back = meng.load_table(path)
+    assert np.array_equal(bits(back["points"]), bits(t_ref["points"])) and np.array_equal(back["cells"], t_ref["cells"])
+    s = Scene("cornell-srgb", texture="test-img.png", uplift="meng", meng_grid_path=path)
+    d = s.desc.contents
+    g = d.meng.contents
+    assert d.uplift == _capi.SSX_UPLIFT_MENG and (g.grid_w, g.grid_h, g.n_points, g.n_samples) == (12, 14, 186, 81)
+    assert np.array_equal(np.ctypeslib.as_array(g.points, shape=(186 * 85,)), t_ref["points"].reshape(-1))
+    xyza = np.random.default_rng(1).random((4096, 4)).astype(np.float32) * np.float32(0.5)
+    assert np.array_equal(bits(s.xyza_to_srgba(xyza)), bits(orc.to_srgba(xyza)))
+    plain = Scene("cornell-srgb", texture="test-img.png")
+    assert not np.array_equal(bits(s.xyza_to_srgba(xyza)), bits(plain.xyza_to_srgba(xyza)))
+    # error behaviour: missing file -> -1 (data), truncated file -> -1, wrong observer -> -3 (stdafx.hpp:107-109)
+    with pytest.raises(SsxError) as e:
+        Scene("cornell-srgb", texture="test-img.png", uplift="meng", meng_grid_path=str(tmp_path / "nope.bin"))
+    assert e.value.code == -1
+    open(str(tmp_path / "cut.bin"), "wb").write(open(path, "rb").read()[:5000])
+    with pytest.raises(SsxError) as e:
+        Scene("cornell-srgb", texture="test-img.png", uplift="meng", meng_grid_path=str(tmp_path / "cut.bin"))
+    assert e.value.code == -1
+    with pytest.raises(SsxError) as e:
+        Scene("cornell-srgb", texture="test-img.png", uplift="meng", meng_grid_path=path, observer=2006)
+    assert e.value.code == -3
