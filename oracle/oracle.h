@@ -18,7 +18,10 @@
  * vectors; the libstdc++ distributions against vectors generated from the real libstdc++ in
  * this image (tests/golden/gen_stdlib_vectors.cpp); the colour pipeline against the reference's
  * single known-answer (src/main.cpp:242-245: max sRGB round-trip error 1.851469e-5) and its
- * assert D65[560nm]==100 (src/util/color.cpp:115).  The integrator itself (intersection,
+ * assert D65[560nm]==100 (src/util/color.cpp:115); the Jakob-Hanika fetch/eval and the Meng et
+ * al. spectrum_xyz_to_p restatements bit for bit against the reference's OWN code, the two
+ * self-contained C sources it vendors, compiled in place into oracle/_ref/ (Makefile target
+ * `ref`; tests/test_ref_pins.py).  The integrator itself (intersection,
  * light sampling, recursion) has no reference-held vector: PARITY UNPINNED for those, checked
  * only against the survey's recorded constants and per-sample work statistics.
  */

@@ -53,3 +53,31 @@ def test_cli_renders_the_same_image_as_the_oracle(cli, tmp_path):
     pfm = str(tmp_path / "o.pfm")
     r = run(cli, "-s=plane-srgb", "-w=16", "-h=16", "-spp=2", "-o=" + pfm, "--texture=data/scenes/test-img.png", "-io")
     assert r.returncode == 0 and "Plane converges much faster" in r.stderr and os.path.getsize(pfm) == len("PF\n16 16\n-1.0\n") + 16 * 16 * 12
+
+
+def test_cli_meng_without_grid_file_fails_like_a_missing_data_file(cli, tmp_path):
+    r = run(cli, "-s=cornell-srgb", "-w=8", "-h=8", "-spp=1", "-o=" + str(tmp_path / "x.png"), "--texture=data/scenes/test-img.png",
+            "--uplift=meng", "--meng-grid=" + str(tmp_path / "missing.bin"))
+    assert r.returncode == 255 and "Could not open Meng grid" in r.stderr
+    r = run(cli, "-s=cornell-srgb", "-w=8", "-h=8", "-spp=1", "-o=" + str(tmp_path / "x.png"), "--uplift=nope")
+    assert r.returncode == 255 and "Invalid value for --uplift" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_meng_uplift_matches_the_oracle(cli, tmp_path):
+    import ref_lib
+    from simple_spectral_amd import meng
+    from PIL import Image
+    if ref_lib.meng() is None:
+        pytest.skip("oracle/_ref/libref_meng.so not built")
+    table = ref_lib.meng_table()
+    grid = str(tmp_path / "grid.bin")
+    meng.save_table(grid, table)
+    out = str(tmp_path / "m.png")
+    r = run(cli, "-s=cornell-srgb", "-w=32", "-h=24", "-spp=4", "-o=" + out, "--texture=data/scenes/test-img.png", "--seed=3",
+            "--uplift=meng", "--meng-grid=" + grid)
+    assert r.returncode == 0, r.stderr
+    o = ol.Oracle("cornell-srgb", texture="test-img.png", meng=table)
+    srgba = o.to_srgba(o.render(32, 24, 4, seed=3))
+    want = np.floor(np.clip(np.float32(255.0) * srgba, 0, 255) + np.float32(0.5)).astype(np.uint8)[::-1]
+    assert np.array_equal(np.asarray(Image.open(out)), want)
