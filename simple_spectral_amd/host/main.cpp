@@ -7,6 +7,7 @@
 #include "renderer.hpp"
 
 #include <chrono>
+#include <csignal>
 #include <cstdio>
 #include <string>
 #include <thread>
@@ -112,6 +113,13 @@ void parse_arguments(int argc, char* argv[], ssx::Renderer::Options* o) {
 
 } // namespace
 
+namespace {
+// The reference aborts a render by closing its window (src/main.cpp:318-327: render_stop, then the
+// last worker saves what exists).  Without a window the same path hangs off Ctrl-C.
+volatile std::sig_atomic_t g_abort = 0;
+void on_sigint(int) { g_abort = 1; }
+} // namespace
+
 int main(int argc, char* argv[]) {
 	ssx::Renderer::Options options;
 	try {
@@ -122,8 +130,11 @@ int main(int argc, char* argv[]) {
 	}
 	try {
 		ssx::Renderer renderer(options);
+		std::signal(SIGINT, on_sigint);
 		renderer.render_start();
+		bool stop_sent = false;
 		while (renderer.is_rendering()) { // the reference prints from its workers every 10 ms (src/renderer.cpp:352-358)
+			if (g_abort && !stop_sent) { renderer.render_stop(); stop_sent = true; std::fprintf(stderr, "\nAborting: saving the partial render ...\n"); }
 			renderer.print_progress();
 			std::this_thread::sleep_for(std::chrono::milliseconds(10));
 		}

@@ -81,3 +81,21 @@ def test_cli_meng_uplift_matches_the_oracle(cli, tmp_path):
     srgba = o.to_srgba(o.render(32, 24, 4, seed=3))
     want = np.floor(np.clip(np.float32(255.0) * srgba, 0, 255) + np.float32(0.5)).astype(np.uint8)[::-1]
     assert np.array_equal(np.asarray(Image.open(out)), want)
+
+
+@pytest.mark.gpu
+def test_cli_abort_saves_the_partial_render(cli, tmp_path):
+    """The reference's abort path (window close -> render_stop -> the last worker saves what exists,
+    src/main.cpp:318-327, src/renderer.cpp:388-394) hangs off Ctrl-C here."""
+    import signal
+    import time
+    out = str(tmp_path / "partial.pfm")
+    p = subprocess.Popen([cli, "-s=cornell", "-w=2048", "-h=2048", "-spp=4096", "-o=" + out], cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(4.0)                       # context + scene upload + a few of the ~50 ms launches (the whole render takes >10 s)
+    p.send_signal(signal.SIGINT)
+    so, se = p.communicate(timeout=120)
+    assert p.returncode == 0, se
+    assert "Aborting: saving the partial render" in se and "Render completed in" in so
+    data = np.fromfile(out, dtype="<f4", offset=len("PF\n2048 2048\n-1.0\n")).reshape(2048, 2048, 3)
+    assert np.isfinite(data).all() and data.max() > 0.0
