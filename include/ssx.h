@@ -79,6 +79,13 @@ typedef struct ssx_texture { uint32_t width, height; const uint8_t* rgb; } ssx_t
 /* RENDER_MODE_SPECTRAL_ALGNUM (src/stdafx.hpp:63-73): how a texel's linear RGB becomes a
  * reflectance spectrum (Color::lrgb_to_specrefl, src/util/color.cpp:167-232). */
 enum { SSX_UPLIFT_OURS = 1, SSX_UPLIFT_MENG = 2, SSX_UPLIFT_JH = 3 };
+/* `uplift` value for the reference's other build mode, RENDER_MODE_RGB (src/stdafx.hpp:91-93): no
+ * spectra at all -- the integrator carries linear RGB, texels are used as they are (src/material.cpp:
+ * 61-63), no wavelength is drawn (src/renderer.cpp:134-143), pixels are the plain mean of the
+ * samples (:300-304) and the image returned is linear RGB + alpha, not XYZ.  The scene then encodes
+ * every "spectrum" as the 4-sample table {r,g,b,0} with low = 0, delta_recip = 1, and lambda_min = 0,
+ * lambda_step = 1 (the three components ride in the first three hero slots). */
+enum { SSX_MODE_RGB = 0 };
 
 /* Meng et al. 2015 grid (RENDER_MODE_SPECTRAL_MENG): the tables the reference compiles in from
  * src/meng-et-al.-2015/spectra_xyz_5nm_380_780_0.97.h, here passed as data (this library ships no

@@ -22,7 +22,9 @@ typedef struct ssh_scene ssh_scene;
 int ssh_scene_create(const char* scene_name, const char* data_dir, int observer,
                      const uint8_t* tex_rgb, uint32_t tex_w, uint32_t tex_h, const char* texture_path,
                      float light_scale, ssh_scene** out);
-/* As ssh_scene_create, plus the uplift variant (SSX_UPLIFT_OURS | SSX_UPLIFT_MENG | SSX_UPLIFT_JH).
+/* Bit 9 (0x200) of `uplift`: RENDER_MODE_RGB (SSX_MODE_RGB in ssx.h; the low byte is then ignored):
+ * the scene carries linear-RGB triples, ssh_xyza_to_srgba applies only the sRGB transfer function.
+ * As ssh_scene_create, plus the uplift variant (SSX_UPLIFT_OURS | SSX_UPLIFT_MENG | SSX_UPLIFT_JH).
  * For MENG, jh_coeff_path names the grid file ("SSXMENG1", simple_spectral_amd/host/meng2015.hpp;
  * -1 when missing) and ssh_xyza_to_srgba applies the Meng output transform (src/util/color.cpp:
  * 243-254); like JH it requires the CIE 1931 observer.  For JH the model is

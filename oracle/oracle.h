@@ -84,6 +84,8 @@ typedef struct {
 	orc_spectrum emission;
 	orc_spectrum albedo;
 	orc_texture* texture;
+	/* RENDER_MODE_RGB (stdafx.hpp:91-93): emission / constant albedo are lRGB triples instead */
+	float rgb_emission[3], rgb_albedo[3];
 } orc_material;
 
 typedef struct {
@@ -110,6 +112,7 @@ typedef struct {
 	orc_quad* prims;          int n_prims;
 	int* lights;              int n_lights; /* indices into prims */
 	orc_texture* textures;    int n_textures;
+	int rgb_mode;             /* built under RENDER_MODE_RGB (copied from the orc_color at creation) */
 } orc_scene;
 
 typedef struct { int prim; orc_v3 normal; orc_v2 st; float dist; } orc_hit; /* stdafx.hpp:224-232 */
@@ -133,6 +136,8 @@ typedef struct {
 	 * meng_points == NULL -> not Meng */
 	int meng_grid_w, meng_grid_h, meng_n_points, meng_n_samples;
 	float meng_sample_min, meng_sample_max, meng_xy_to_uv[6];
+	/* RENDER_MODE_RGB: no spectra anywhere; the integrator carries lRGB (set before orc_scene_create) */
+	int rgb_mode;
 	int32_t* meng_cells;   /* grid_w*grid_h x {inside, num_points, idx[6]} (spectrum_grid_cell_t) */
 	float* meng_points;    /* n_points x {xystar[2], uv[2], spectrum[n_samples]} (spectrum_data_point_t) */
 } orc_color;
@@ -154,6 +159,9 @@ void orc_color_destroy(orc_color*);
 int orc_color_set_jh(orc_color*, int res, const float* scale, const float* data);
 void orc_jh_fetch(const orc_color*, const float rgb[3], float out[3]);  /* rgb2spec.c:77-118 */
 float orc_jh_eval_precise(const float coeff[3], float lambda);          /* rgb2spec.c:129-133 */
+/* RENDER_MODE_RGB on/off; affects scenes created afterwards, orc_render_* and orc_xyza_to_srgba
+ * (then lRGB+A in, sRGB+A out: renderer.cpp:300-307) */
+void orc_color_set_rgb_mode(orc_color*, int on);
 /* switch the uplift to Meng et al. 2015 with the given grid (copied); points == NULL switches back.
  * Also switches ciexyz_to_srgb to the Meng variant (color.cpp:243-254). */
 int orc_color_set_meng(orc_color*, int grid_w, int grid_h, int n_points, int n_samples, float sample_min,
@@ -169,6 +177,8 @@ void orc_scene_destroy(orc_scene*);
  * reference's non-ELS plane scene material (scene.cpp:346-355) or any mirror surface */
 int orc_scene_set_material_kind(orc_scene*, int material, int kind);
 int orc_scene_quad_material(const orc_scene*, int quad);
+/* RGB-mode introspection: out = {emission r,g,b, constant albedo r,g,b}; returns albedo_mode */
+int orc_scene_material_rgb(const orc_scene*, int material, float out[6]);
 
 /* The build's seeding contract: one PCG32 stream per (seed, pixel index j*W+i, sample k). */
 void orc_seed_sample(uint64_t seed, uint64_t pixel, uint64_t k, orc_rng* out);

@@ -405,6 +405,8 @@ float orc_jh_eval_precise(const float coeff[3], float lambda) {
 	return (.5f * x) * y + .5f;
 }
 
+void orc_color_set_rgb_mode(orc_color* cd, int on) { cd->rgb_mode = on ? 1 : 0; }
+
 /* ---- Meng et al. 2015 (reference src/meng-et-al.-2015/spectrum_grid.h; tables passed in as data) ---- */
 int orc_color_set_meng(orc_color* cd, int grid_w, int grid_h, int n_points, int n_samples, float sample_min,
                        float sample_max, const float xy_to_uv[6], const int32_t* cells, const float* points) {
@@ -516,6 +518,11 @@ void orc_specradflux_to_ciexyz_hero(const orc_color* cd, const float flux[4], fl
 void orc_xyza_to_srgba(const orc_color* cd, const float* xyza, float* srgba, size_t n) {
 	for (size_t p = 0; p < n; ++p) {
 		float lrgb[3];
+		if (cd->rgb_mode) { /* renderer.cpp:306: Color::lrgb_to_srgb(lRGB_F32(avg)) -- the input already is lRGB */
+			orc_lrgb_to_srgb(xyza + 4 * p, srgba + 4 * p);
+			srgba[4 * p + 3] = xyza[4 * p + 3];
+			continue;
+		}
 		if (cd->meng_points) { /* color.cpp:243-254: xyz / D65_rad_XYZ.y, then Meng's inverse matrix */
 			static const float rows[9] = { 3.24156456f, -1.53766524f, -0.49870224f,  -0.96920119f, 1.87588535f, 0.04155324f,
 			                               0.05562416f, -0.20395525f, 1.05685902f };

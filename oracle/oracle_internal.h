@@ -26,6 +26,7 @@ void orc_mat3_mul_vec3(const float* m, const float v[3], float o[3]);
 /* scene / materials / samplers used by the integrator */
 void orc_scene_get_rand_toward_light(const orc_scene* sc, orc_rng* rng, orc_v3 from, orc_v3* dir, int* light, float* pdf);
 void orc_texture_sample(const orc_color* cd, const orc_texture* tex, orc_v2 st, float lambda_0, float out[4], orc_stats* stt);
+void orc_material_emission(const orc_color* cd, const orc_material* m, float lambda_0, float out[4]);
 void orc_material_albedo(const orc_color* cd, const orc_scene* sc, const orc_material* m, orc_v2 st, float lambda_0, float out[4], orc_stats* stt);
 orc_v3 orc_reflect(orc_v3 vec, orc_v3 normal);
 

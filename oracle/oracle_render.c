@@ -33,7 +33,7 @@ static orc_hero radiance_L(path_ctx* c, const orc_ray* ray, int last_was_delta, 
 		/* Emission (:166-175); the condition exists only #ifdef EXPLICIT_LIGHT_SAMPLING */
 		if (!c->els || (last_was_delta && (!c->indirect_only || depth > 0u))) {
 			float em[4];
-			orc_spectrum_hero(&mtl->emission, c->lambda_0, c->cd->lambda_step, em); /* material.hpp:101-103 */
+			orc_material_emission(c->cd, mtl, c->lambda_0, em); /* material.hpp:101-103 */
 			if (c->st) c->st->spectrum_lookups++;
 			for (int i = 0; i < 4; ++i) radiance.v[i] += em[i];
 		}
@@ -54,7 +54,7 @@ static orc_hero radiance_L(path_ctx* c, const orc_ray* ray, int last_was_delta, 
 					if (hitrec_shad.prim == light) {
 						const orc_material* lm = &c->sc->materials[c->sc->prims[hitrec_shad.prim].material];
 						float emitted[4], f_s[4];
-						orc_spectrum_hero(&lm->emission, c->lambda_0, c->cd->lambda_step, emitted);
+						orc_material_emission(c->cd, lm, c->lambda_0, emitted);
 						if (c->st) c->st->spectrum_lookups++;
 						/* evaluate_bsdf (material.cpp:120-129 Lambertian, :146-153 Mirror) */
 						if (mtl->kind == ORC_MTL_LAMBERTIAN) {
@@ -128,7 +128,8 @@ void orc_render_sample(const orc_color* cd, const orc_scene* sc, orc_rng* rng, s
 		camera_ray_dir = v3_make((float)(dx * inv), (float)(dy * inv), (float)(dz * inv));
 	}
 
-	float lambda_0 = cd->lambda_min + orc_rand_1f(rng) * cd->lambda_step; /* :138 */
+	/* :138, #ifdef RENDER_MODE_SPECTRAL only: the RGB build draws no wavelength */
+	float lambda_0 = cd->rgb_mode ? 0.0f : cd->lambda_min + orc_rand_1f(rng) * cd->lambda_step;
 
 	/* `indirect_only` carries two flags: bit 0 = Options::indirect_only, bit 1 = build without ELS */
 	path_ctx c = { cd, sc, rng, lambda_0, indirect_only & 1, !(indirect_only & 2), 0, st, 0 };
@@ -137,6 +138,8 @@ void orc_render_sample(const orc_color* cd, const orc_scene* sc, orc_rng* rng, s
 
 	/* FLAT_FIELD_CORRECTION: flux = radiance (:262-263) */
 	float xyz[3];
+	if (cd->rgb_mode) { xyz[0] = rad.v[0]; xyz[1] = rad.v[1]; xyz[2] = rad.v[2]; } /* :274-276 lRGB_A_F32(pixel_flux_est, hit) */
+	else
 	orc_specradflux_to_ciexyz_hero(cd, rad.v, lambda_0, xyz);
 	out_xyza[0] = xyz[0]; out_xyza[1] = xyz[1]; out_xyza[2] = xyz[2];
 	out_xyza[3] = c.hit_anything ? 1.0f : 0.0f;
@@ -158,8 +161,10 @@ static void render_pixel(const orc_color* cd, const orc_scene* sc, uint64_t seed
 		orc_seed_sample(seed, (uint64_t)(j * W + i), (uint64_t)k, &rng);
 		float s[4];
 		orc_render_sample(cd, sc, &rng, i, j, W, H, indirect_only, s, st);
-		for (int c = 0; c < 4; ++c) avg[c] += (double)(s[c] * 0.001f);
+		if (cd->rgb_mode) for (int c = 0; c < 4; ++c) avg[c] += (double)s[c];            /* :301-303 */
+		else for (int c = 0; c < 4; ++c) avg[c] += (double)(s[c] * 0.001f);              /* :292-294 */
 	}
+	if (cd->rgb_mode) { for (int c = 0; c < 4; ++c) out[c] = (float)(avg[c] / (double)spp); return; } /* :304 avg /= double(spp) */
 	double sc_ = 1000.0 / (double)spp;
 	for (int c = 0; c < 4; ++c) out[c] = (float)(avg[c] * sc_);
 }

@@ -140,6 +140,7 @@ void orc_texture_sample(const orc_color* cd, const orc_texture* tex, orc_v2 st, 
 	float srgb[3] = { (float)px[0] * (1.0f / 255.0f), (float)px[1] * (1.0f / 255.0f), (float)px[2] * (1.0f / 255.0f) };
 	float lrgb[3];
 	orc_srgb_to_lrgb(srgb, lrgb);
+	if (cd->rgb_mode) { out[0] = lrgb[0]; out[1] = lrgb[1]; out[2] = lrgb[2]; out[3] = 0.0f; return; } /* material.cpp:61-63 */
 	orc_lrgb_to_specrefl(cd, lrgb, lambda_0, out);
 	if (stt) stt->spectrum_lookups += 3;
 }
@@ -148,6 +149,7 @@ void orc_texture_sample(const orc_color* cd, const orc_texture* tex, orc_v2 st, 
 void orc_material_albedo(const orc_color* cd, const orc_scene* sc, const orc_material* m, orc_v2 st, float lambda_0, float out[4], orc_stats* stt) {
 	(void)sc;
 	if (m->albedo_mode == ORC_ALBEDO_CONSTANT) {
+		if (cd->rgb_mode) { out[0] = m->rgb_albedo[0]; out[1] = m->rgb_albedo[1]; out[2] = m->rgb_albedo[2]; out[3] = 0.0f; return; } /* material.cpp:125,138 */
 		orc_spectrum_hero(&m->albedo, lambda_0, cd->lambda_step, out);
 		if (stt) stt->spectrum_lookups++;
 	} else {
@@ -156,7 +158,15 @@ void orc_material_albedo(const orc_color* cd, const orc_scene* sc, const orc_mat
 }
 
 /* material.cpp:100-106 */
-static int material_is_emissive(const orc_material* m) { return orc_spectrum_integrate(&m->emission) > 0.0f; }
+static int material_is_emissive(int rgb_mode, const orc_material* m) {
+	if (rgb_mode) return m->rgb_emission[0] > 0.0f || m->rgb_emission[1] > 0.0f || m->rgb_emission[2] > 0.0f;
+	return orc_spectrum_integrate(&m->emission) > 0.0f;
+}
+/* material.hpp:101-103 emission[lambda_0], or the lRGB triple in RGB mode */
+void orc_material_emission(const orc_color* cd, const orc_material* m, float lambda_0, float out[4]) {
+	if (cd->rgb_mode) { out[0] = m->rgb_emission[0]; out[1] = m->rgb_emission[1]; out[2] = m->rgb_emission[2]; out[3] = 0.0f; return; }
+	orc_spectrum_hero(&m->emission, lambda_0, cd->lambda_step, out);
+}
 
 /* ------------------------------------------------------------------- camera ---- */
 /* GLM scalar paths; matrices column-major m[c*4+r]. */
@@ -247,7 +257,7 @@ static void scene_add_quad(orc_scene* sc, int material, orc_vertex v00, orc_vert
 	tri_make(&q->tri0, v00, v10, v11);
 	tri_make(&q->tri1, v00, v11, v01);
 	q->material = material;
-	q->is_light = material_is_emissive(&sc->materials[material]); /* geometry.cpp:7-9 */
+	q->is_light = material_is_emissive(sc->rgb_mode, &sc->materials[material]); /* geometry.cpp:7-9 */
 }
 static int scene_add_material(orc_scene* sc) {
 	sc->materials = (orc_material*)realloc(sc->materials, sizeof(orc_material) * (size_t)(sc->n_materials + 1));
@@ -262,6 +272,7 @@ static int scene_new_lambertian_const(orc_scene* sc, const orc_color* cd, const 
 	orc_spectrum_init_const(&m->emission, 0.0f, cd->lambda_min, cd->lambda_max);
 	if (albedo_or_null) orc_spectrum_copy(&m->albedo, albedo_or_null);
 	else orc_spectrum_init_const(&m->albedo, albedo_const, cd->lambda_min, cd->lambda_max);
+	for (int k = 0; k < 3; ++k) { m->rgb_emission[k] = 0.0f; m->rgb_albedo[k] = albedo_const; } /* RGB_Reflectance(x) */
 	return id;
 }
 static int scene_new_textured(orc_scene* sc, const orc_color* cd, int kind, const uint8_t* rgb, int w, int h) {
@@ -274,6 +285,7 @@ static int scene_new_textured(orc_scene* sc, const orc_color* cd, int kind, cons
 	orc_material* m = &sc->materials[id];
 	m->kind = kind; m->albedo_mode = ORC_ALBEDO_TEXTURE;
 	orc_spectrum_init_const(&m->emission, 0.0f, cd->lambda_min, cd->lambda_max);
+	for (int k = 0; k < 3; ++k) { m->rgb_emission[k] = 0.0f; m->rgb_albedo[k] = 0.0f; }
 	m->texture = NULL; /* fixed up after all reallocs, see scene_finish */
 	return id;
 }
@@ -309,11 +321,15 @@ static int build_cornell(orc_scene* sc, const orc_color* cd, const char* data_di
 	orc_spectrum_init(&green, cols[1], nrows, 400, 700);
 	orc_spectrum_init(&red, cols[2], nrows, 400, 700);
 	orc_free_spectral_data(cols, 3);
-	scene_new_lambertian_const(sc, cd, &white, 0); /* white-back */
-	scene_new_lambertian_const(sc, cd, &white, 0); /* white-blocks (copy) */
-	scene_new_lambertian_const(sc, cd, &white, 0); /* white-floorceil (copy) */
-	scene_new_lambertian_const(sc, cd, &green, 0);
-	scene_new_lambertian_const(sc, cd, &red, 0);
+	scene_new_lambertian_const(sc, cd, &white, 1.0f); /* white-back; RGB: (1,1,1) (scene.cpp:70-71) */
+	scene_new_lambertian_const(sc, cd, &white, 1.0f); /* white-blocks (copy) */
+	scene_new_lambertian_const(sc, cd, &white, 1.0f); /* white-floorceil (copy) */
+	int g_ = scene_new_lambertian_const(sc, cd, &green, 0);
+	int r_ = scene_new_lambertian_const(sc, cd, &red, 0);
+	{ /* RGB: "Set heuristically" green and pure red (scene.cpp:77-81) */
+		const float g3[3] = { 0.07f, 0.38f, 0.07f }, r3[3] = { 1, 0, 0 };
+		memcpy(sc->materials[g_].rgb_albedo, g3, sizeof g3); memcpy(sc->materials[r_].rgb_albedo, r3, sizeof r3);
+	}
 	orc_spectrum_free(&white); orc_spectrum_free(&green); orc_spectrum_free(&red);
 
 	snprintf(path, sizeof path, "%s/scenes/cornell/light.csv", data_dir);
@@ -326,6 +342,7 @@ static int build_cornell(orc_scene* sc, const orc_color* cd, const char* data_di
 	orc_spectrum_free(&sc->materials[light].emission);
 	orc_spectrum_scale(&sc->materials[light].emission, &raw, 200.0f);
 	orc_spectrum_free(&raw);
+	for (int k = 0; k < 3; ++k) sc->materials[light].rgb_emission[k] = 1.0f * 200.0f; /* RGB_Radiance(1,1,1) * 200.0f (scene.cpp:106) */
 
 	/* Floor */
 	scene_add_quad(sc, MTL_WHITE_FLOORCEIL, vtx(552.8f, 0.0f, 0.0f, 1, 0), vtx(0.0f, 0.0f, 0.0f, 0, 0),
@@ -383,6 +400,7 @@ static int build_cornell_srgb(orc_scene* sc, const orc_color* cd, const char* da
 	}
 	orc_spectrum_free(&sc->materials[MTL_LIGHT].emission);
 	orc_spectrum_scale(&sc->materials[MTL_LIGHT].emission, &cd->D65_rad, lightsc);
+	for (int k = 0; k < 3; ++k) sc->materials[MTL_LIGHT].rgb_emission[k] = 1.0f * lightsc; /* scene.cpp:314 */
 	return 0;
 }
 
@@ -399,6 +417,7 @@ static int build_plane_srgb(orc_scene* sc, const orc_color* cd, const uint8_t* r
 	int mtl_light = scene_new_lambertian_const(sc, cd, NULL, 0.0f);
 	orc_spectrum_free(&sc->materials[mtl_light].emission);
 	orc_spectrum_copy(&sc->materials[mtl_light].emission, &cd->D65_rad);
+	for (int k = 0; k < 3; ++k) sc->materials[mtl_light].rgb_emission[k] = 1.0f; /* scene.cpp:341 */
 	int mtl_tex = scene_new_textured(sc, cd, ORC_MTL_LAMBERTIAN, rgb, w, h); /* EXPLICIT_LIGHT_SAMPLING build */
 
 	scene_add_quad(sc, mtl_tex, vtx(-1, -1, 0, 0, 0), vtx(1, -1, 0, 1, 0), vtx(1, 1, 0, 1, 1), vtx(-1, 1, 0, 0, 1));
@@ -419,9 +438,17 @@ static int build_plane_srgb(orc_scene* sc, const orc_color* cd, const uint8_t* r
 	return 0;
 }
 
+int orc_scene_material_rgb(const orc_scene* sc, int material, float out[6]) {
+	if (material < 0 || material >= sc->n_materials) return -1;
+	memcpy(out, sc->materials[material].rgb_emission, 12);
+	memcpy(out + 3, sc->materials[material].rgb_albedo, 12);
+	return sc->materials[material].albedo_mode;
+}
+
 orc_scene* orc_scene_create(const orc_color* cd, const char* name, const char* data_dir,
                             const uint8_t* tex_rgb, int tex_w, int tex_h, float light_scale) {
 	orc_scene* sc = (orc_scene*)calloc(1, sizeof *sc);
+	sc->rgb_mode = cd->rgb_mode;
 	int rc;
 	if (!strcmp(name, "cornell")) rc = build_cornell(sc, cd, data_dir);
 	else if (!strcmp(name, "cornell-srgb")) rc = build_cornell_srgb(sc, cd, data_dir, tex_rgb, tex_w, tex_h, light_scale);

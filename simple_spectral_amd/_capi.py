@@ -62,7 +62,7 @@ class SsxRenderParams(C.Structure):
                 ("seed", C.c_uint64)]
 
 
-SSX_UPLIFT_OURS, SSX_UPLIFT_MENG, SSX_UPLIFT_JH = 1, 2, 3
+SSX_MODE_RGB, SSX_UPLIFT_OURS, SSX_UPLIFT_MENG, SSX_UPLIFT_JH = 0, 1, 2, 3
 SSX_OK, SSX_ERR_DATA, SSX_ERR_ARG, SSX_ERR_SCENE, SSX_ERR_DEVICE, SSX_ERR_STATE = 0, -1, -2, -3, -10, -11
 
 # every symbol include/ssx.h and include/ssx_host.h declare (tests check the libraries export them)

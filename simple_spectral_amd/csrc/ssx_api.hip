@@ -37,6 +37,7 @@ struct ssx_ctx {
 	uint32_t blob_words = 0;
 	std::vector<uint8_t*> d_textures;
 	float* d_jh_data = nullptr;
+	bool rgb_mode = false;     // scene uploaded with uplift == SSX_MODE_RGB
 	double* d_accum = nullptr;  size_t accum_pixels = 0;
 	SsxSampleRecord* d_samples = nullptr; size_t sample_slots = 0; // record capacity of the sample buffer
 	SsxFrame* d_frames = nullptr;
@@ -91,6 +92,14 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 		const ssx_spectrum& sp = s->spectra[i];
 		if (sp.n < 2) return fail(ctx, SSX_ERR_DATA, "Must have at-least two elements in sampled spectrum!"); // spectrum.cpp:17-20
 		if ((uint64_t)sp.offset + sp.n > s->n_samples) return fail(ctx, SSX_ERR_ARG, "spectrum samples out of range");
+	}
+	if (s->uplift == SSX_MODE_RGB) {
+		// the RGB build's "spectra" are triples: every table must be {r,g,b,0} on the grid 0,1,2,3 and the
+		// "wavelengths" 0,1,2,3 (lambda_min 0, step 1), so that lookups return the components exactly
+		if (s->lambda_min != 0.0f || s->lambda_step != 1.0f) return fail(ctx, SSX_ERR_ARG, "RGB mode needs lambda_min = 0, lambda_step = 1");
+		for (uint32_t i = 0; i < s->n_spectra; ++i)
+			if (s->spectra[i].n != 4u || s->spectra[i].low != 0.0f || s->spectra[i].delta_recip != 1.0f || s->samples[s->spectra[i].offset + 3u] != 0.0f)
+				return fail(ctx, SSX_ERR_ARG, "RGB mode needs every spectrum as {r,g,b,0} with low = 0, delta_recip = 1");
 	}
 	for (uint32_t i = 0; i < s->n_materials; ++i) {
 		const ssx_material& m = s->materials[i];
@@ -245,6 +254,7 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	a.indirect_only = p->indirect_only ? 1u : 0u;
 	a.no_els = p->no_explicit_light_sampling ? 1u : 0u;
 	a.seed = p->seed;
+	a.rgb_mode = ctx->rgb_mode ? 1u : 0u;
 	a.my_tiles = a.n_tiles > p->tile_first ? (a.n_tiles - p->tile_first + p->tile_stride - 1u) / p->tile_stride : 0u;
 	pl.lds_bytes = (size_t)ctx->blob_words * 4;
 	size_t per_spp = (size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u * kBytesPerSampleInFlight;
@@ -401,7 +411,7 @@ int launch_finalize(ssx_ctx* ctx, const ssx_render_params* p, float* d_out, hipS
 	uint32_t pixels = p->width * p->height;
 	hipLaunchKernelGGL(ssx_finalize_kernel, dim3((pixels + 255u) / 256u), dim3(256), 0, stream,
 	                   (const double*)ctx->d_accum, (float4*)d_out, p->width, p->height, (p->width + 7u) / 8u,
-	                   p->tile_first, p->tile_stride, p->spp);
+	                   p->tile_first, p->tile_stride, p->spp, ctx->rgb_mode ? 1u : 0u);
 	SSX_HIP(ctx, hipGetLastError());
 	return SSX_OK;
 }
@@ -515,8 +525,9 @@ int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 		ctx->d_textures.push_back(d);
 		SSX_HIP(ctx, hipMemcpy(d, t.rgb, bytes, hipMemcpyHostToDevice));
 	}
-	if (s->uplift != SSX_UPLIFT_OURS && s->uplift != SSX_UPLIFT_JH && s->uplift != SSX_UPLIFT_MENG)
-		return fail(ctx, SSX_ERR_SCENE, "unsupported uplift variant (1 = basis, 2 = Meng et al., 3 = Jakob-Hanika)");
+	if (s->uplift != SSX_MODE_RGB && s->uplift != SSX_UPLIFT_OURS && s->uplift != SSX_UPLIFT_JH && s->uplift != SSX_UPLIFT_MENG)
+		return fail(ctx, SSX_ERR_SCENE, "unsupported uplift variant (0 = RGB mode, 1 = basis, 2 = Meng et al., 3 = Jakob-Hanika)");
+	ctx->rgb_mode = (s->uplift == SSX_MODE_RGB);
 	if (ctx->d_jh_data) { (void)hipFree(ctx->d_jh_data); ctx->d_jh_data = nullptr; }
 	if (s->uplift == SSX_UPLIFT_MENG) {
 		// device table: 16 header words, cells, points (layout documented at meng_uplift in ssx_kernels.hip)

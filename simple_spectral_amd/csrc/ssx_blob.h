@@ -92,4 +92,6 @@ struct SsxKernelArgs {
 	SsxFrame* frames;         // [depth][record]
 	uint64_t n_records;       // my_tiles * (k1-k0) * 64
 	uint64_t* prof;           // region-timing builds only (NULL otherwise)
+	uint32_t rgb_mode;        // 1: RENDER_MODE_RGB (scene uplift == SSX_MODE_RGB): no wavelength draw, no XYZ, plain mean
+	uint32_t pad_;
 };

@@ -331,6 +331,7 @@ __device__ __forceinline__ Hero texture_sample(const Lds& L, uint32_t tex_index,
 	const uint8_t* px = rgb + 3u * ((size_t)j * (size_t)t.w + (size_t)i);
 	float r = L.lut(px[0]), g = L.lut(px[1]), b = L.lut(px[2]);
 	const SsxBlobHeader& h = L.hdr();
+	if (h.uplift == 0u) { Hero o; o.v[0] = r; o.v[1] = g; o.v[2] = b; o.v[3] = 0.0f; return o; } // RENDER_MODE_RGB: material.cpp:61-63
 	if (h.uplift == 3u) return jh_uplift(L, r, g, b, lambda_0); // RENDER_MODE_SPECTRAL_JH (wave-uniform)
 	if (h.uplift == 2u) return meng_uplift(L, r, g, b, lambda_0); // RENDER_MODE_SPECTRAL_MENG
 	Hero br, bg, bb;
@@ -718,8 +719,10 @@ __device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const Ss
 	double px = q[0] / w, py = q[1] / w, pz = q[2] / w;
 	double dx = px - (double)h.cam_pos[0], dy = py - (double)h.cam_pos[1], dz = pz - (double)h.cam_pos[2];
 	double inv = 1.0 / __builtin_sqrt((dx * dx + dy * dy) + dz * dz);
-	rec.a = make_float4((float)(dx * inv), (float)(dy * inv), (float)(dz * inv),
-	                    h.lambda_min + rand_1f(rng) * h.lambda_step); // :138
+	// :138 exists #ifdef RENDER_MODE_SPECTRAL only: the RGB build draws no wavelength (its "spectra" are
+	// 4-sample tables {r,g,b,0} on the grid 0,1,2,3 and lambda_0 = 0, lambda_step = 1 pick them out exactly)
+	const float lambda_0 = a.rgb_mode ? 0.0f : h.lambda_min + rand_1f(rng) * h.lambda_step;
+	rec.a = make_float4((float)(dx * inv), (float)(dy * inv), (float)(dz * inv), lambda_0);
 	rec.b = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), (uint32_t)rng.inc, (uint32_t)(rng.inc >> 32));
 }
 
@@ -999,6 +1002,8 @@ extern "C" __global__ void __launch_bounds__(256) ssx_resolve_kernel(SsxKernelAr
 		}
 		Hero flux; flux.v[0] = rad[0]; flux.v[1] = rad[1]; flux.v[2] = rad[2]; flux.v[3] = rad[3];
 		float xyz[3];
+		if (a.rgb_mode) { xyz[0] = rad[0]; xyz[1] = rad[1]; xyz[2] = rad[2]; } // renderer.cpp:274-276: lRGB_A_F32(pixel_flux_est, hit)
+		else
 		flux_to_xyz(L, flux, __uint_as_float(rec.b.x), xyz);
 		a.samples[r].a = make_float4(xyz[0], xyz[1], xyz[2], rec.b.y ? 1.0f : 0.0f);
 	}
@@ -1018,6 +1023,12 @@ extern "C" __global__ void __launch_bounds__(256) ssx_accumulate_kernel(SsxKerne
 	double* acc_p = accum + 4u * ((size_t)j * a.width + i);
 	double acc[4] = { acc_p[0], acc_p[1], acc_p[2], acc_p[3] };
 	const SsxSampleRecord* s = a.samples + (size_t)slot * n_k * 64u + lane;
+	if (a.rgb_mode) { // renderer.cpp:301-303: avg += _render_sample(...), no pre-scaling
+		for (uint32_t k = 0; k < n_k; ++k) {
+			const float4 v = s[(size_t)k * 64u].a;
+			acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
+		}
+	} else
 	for (uint32_t k = 0; k < n_k; ++k) {
 		const float4 v = s[(size_t)k * 64u].a;
 		acc[0] += (double)(v.x * 0.001f);
@@ -1031,13 +1042,19 @@ extern "C" __global__ void __launch_bounds__(256) ssx_accumulate_kernel(SsxKerne
 // renderer.cpp:296,298: avg *= 1000.0/spp, then the float conversion of CIEXYZ_32F(avg) / avg.a.
 // Pixels of tiles this device does not own are written as 0 (x+0 is exact in the RCCL sum).
 extern "C" __global__ void __launch_bounds__(256) ssx_finalize_kernel(const double* accum, float4* out, uint32_t width, uint32_t height,
-                                                  uint32_t tiles_x, uint32_t tile_first, uint32_t tile_stride, uint32_t spp) {
+                                                  uint32_t tiles_x, uint32_t tile_first, uint32_t tile_stride, uint32_t spp, uint32_t rgb_mode) {
 	uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
 	if (p >= width * height) return;
 	uint32_t i = p % width, j = p / width;
 	uint32_t tile = (j >> 3) * tiles_x + (i >> 3);
 	float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	if (tile % tile_stride == tile_first) {
+	if (tile % tile_stride == tile_first && rgb_mode) { // renderer.cpp:304: avg /= double(spp)
+		const double n = (double)spp;
+		o.x = (float)(accum[4u * p + 0] / n);
+		o.y = (float)(accum[4u * p + 1] / n);
+		o.z = (float)(accum[4u * p + 2] / n);
+		o.w = (float)(accum[4u * p + 3] / n);
+	} else if (tile % tile_stride == tile_first) {
 		double sc = 1000.0 / (double)spp;
 		o.x = (float)(accum[4u * p + 0] * sc);
 		o.y = (float)(accum[4u * p + 1] * sc);

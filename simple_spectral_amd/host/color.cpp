@@ -115,7 +115,8 @@ void ColorData::specradflux_to_ciexyz(const Spectrum& flux, float xyz[3]) const 
 void ColorData::ciexyz_to_lrgb(const float xyz[3], float lrgb[3]) const { mul(matr_xyz_to_lrgb, xyz, lrgb); }
 void ColorData::ciexyz_to_srgb(const float xyz[3], float srgb[3]) const {
 	float lrgb[3];
-	if (meng_output_transform) { // color.cpp:243-254: inverse matrix as listed in Meng et al.'s code, on xyz / Y(D65)
+	if (rgb_output_transform) { lrgb[0] = xyz[0]; lrgb[1] = xyz[1]; lrgb[2] = xyz[2]; }
+	else if (meng_output_transform) { // color.cpp:243-254: inverse matrix as listed in Meng et al.'s code, on xyz / Y(D65)
 		static const float rows[9] = { 3.24156456f, -1.53766524f, -0.49870224f,  -0.96920119f, 1.87588535f, 0.04155324f,
 		                               0.05562416f, -0.20395525f, 1.05685902f };
 		const float rel[3] = { xyz[0] / D65_rad_XYZ[1], xyz[1] / D65_rad_XYZ[1], xyz[2] / D65_rad_XYZ[1] };

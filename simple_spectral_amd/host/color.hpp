@@ -24,6 +24,8 @@ public:
 	// RENDER_MODE_SPECTRAL_MENG swaps the output transform for the authors' matrix applied to
 	// xyz / D65_rad_XYZ.y (color.cpp:243-254); set by whoever selects that uplift.
 	bool meng_output_transform = false;
+	// RENDER_MODE_RGB: the pixel mean already is linear RGB; only the sRGB OETF remains (src/renderer.cpp:306)
+	bool rgb_output_transform = false;
 
 	void specradflux_to_ciexyz(const Spectrum& flux, float xyz[3]) const; // color.hpp:106-111
 	void ciexyz_to_lrgb(const float xyz[3], float lrgb[3]) const;         // color.hpp:150-152

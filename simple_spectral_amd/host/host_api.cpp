@@ -35,7 +35,9 @@ int ssh_scene_create_ex(const char* scene_name, const char* data_dir, int observ
 		auto s = std::make_unique<ssh_scene>();
 		s->color = std::make_unique<ssx::ColorData>(data_dir, observer);
 		const bool els = (uplift & 0x100u) == 0u; // bit 8 of `uplift`: scene built for the non-ELS integrator
+		const bool rgb_mode = (uplift & 0x200u) != 0u; // bit 9: RENDER_MODE_RGB (then the low byte is ignored)
 		uplift &= 0xFFu;
+		if (rgb_mode) { uplift = SSX_UPLIFT_OURS; s->color->rgb_output_transform = true; }
 		if (uplift == SSX_UPLIFT_JH) {
 			if (observer != 1931) throw ssx::HostError{ -3, "Only our algorithm currently implements support for the newest CIE standard observer!" };
 			const std::string path = jh_coeff_path ? jh_coeff_path : "";
@@ -64,7 +66,7 @@ int ssh_scene_create_ex(const char* scene_name, const char* data_dir, int observ
 			tex = ssx::load_png_rgb8(texture_path);
 			texp = &tex;
 		}
-		s->scene = std::make_unique<ssx::Scene>(*s->color, scene_name, data_dir, texp, light_scale, s->jh.get(), els, s->meng.get());
+		s->scene = std::make_unique<ssx::Scene>(*s->color, scene_name, data_dir, texp, light_scale, s->jh.get(), els, s->meng.get(), rgb_mode);
 		*out = s.release();
 		return SSX_OK;
 	} catch (const ssx::HostError& e) {

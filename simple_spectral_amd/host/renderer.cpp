@@ -90,7 +90,9 @@ Renderer::Renderer(const Options& opts) : options(opts), framebuffer(opts.res), 
 		tex = load_png_rgb8(path);
 		texp = &tex;
 	}
-	if (options.uplift == SSX_UPLIFT_JH) {
+	if (options.rgb_mode) {
+		color->rgb_output_transform = true;
+	} else if (options.uplift == SSX_UPLIFT_JH) {
 		const std::string path = options.jh_coeff_path.empty() ? options.data_dir + "/jakob-and-hanika-2019-srgb.coeff" : options.jh_coeff_path;
 		try { jh = std::make_unique<JHModel>(jh_load(path)); }
 		catch (const HostError&) { // the authors' table is not in the repository: fit our own once and keep it
@@ -104,7 +106,7 @@ Renderer::Renderer(const Options& opts) : options(opts), framebuffer(opts.res), 
 	} else if (options.uplift != SSX_UPLIFT_OURS) {
 		throw HostError{ -3, "unsupported uplift variant" };
 	}
-	scene = std::make_unique<Scene>(*color, options.scene_name, options.data_dir, texp, options.light_scale, jh.get(), options.explicit_light_sampling, meng.get());
+	scene = std::make_unique<Scene>(*color, options.scene_name, options.data_dir, texp, options.light_scale, jh.get(), options.explicit_light_sampling, meng.get(), options.rgb_mode);
 
 	api_ = std::make_unique<Api>(options.hip_library.empty() ? default_hip_library() : options.hip_library);
 	const int n = options.gpus < 1 ? 1 : options.gpus;

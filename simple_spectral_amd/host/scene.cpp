@@ -91,6 +91,11 @@ uint32_t Scene::add_spectrum(const Spectrum& s) {
 	return static_cast<uint32_t>(spectra_.size() - 1);
 }
 
+uint32_t Scene::add_rgb(float r, float g, float b) { return add_spectrum(Spectrum(std::vector<float>{ r, g, b, 0.0f }, 0.0f, 3.0f)); }
+uint32_t Scene::add_constant(float v) {
+	return rgb_ ? add_rgb(v, v, v) : add_spectrum(Spectrum(v, color_.lambda_min, color_.lambda_max));
+}
+
 uint32_t Scene::add_material(uint32_t kind, uint32_t albedo_mode, uint32_t albedo, uint32_t emission) {
 	ssx_material m{};
 	m.kind = kind; m.albedo_mode = albedo_mode;
@@ -126,21 +131,33 @@ void Scene::build_cornell(const std::string& data_dir) {
 	camera.near_plane = 0.1f; camera.far_plane = 1.0f;
 	camera.vfov_deg = 39.0f;
 
-	const auto wgr = load_spectral_data(data_dir + "/scenes/cornell/white-green-red.csv");
-	if (wgr.size() != 3) throw HostError{ -1, "Invalid data in file!" };
-	const uint32_t white = add_spectrum(Spectrum(wgr[0], 400, 700));
-	const uint32_t green = add_spectrum(Spectrum(wgr[1], 400, 700));
-	const uint32_t red = add_spectrum(Spectrum(wgr[2], 400, 700));
+	uint32_t white, green, red;
+	if (rgb_) { // src/scene.cpp:69-82: no measured spectra in the RGB build
+		white = add_rgb(1, 1, 1);
+		green = add_rgb(0.07f, 0.38f, 0.07f); // "Set heuristically.  There is no correct way to set it."
+		red = add_rgb(1, 0, 0);
+	} else {
+		const auto wgr = load_spectral_data(data_dir + "/scenes/cornell/white-green-red.csv");
+		if (wgr.size() != 3) throw HostError{ -1, "Invalid data in file!" };
+		white = add_spectrum(Spectrum(wgr[0], 400, 700));
+		green = add_spectrum(Spectrum(wgr[1], 400, 700));
+		red = add_spectrum(Spectrum(wgr[2], 400, 700));
+	}
 	const uint32_t m_white_back = add_material(SSX_MTL_LAMBERTIAN, SSX_ALBEDO_CONSTANT, white, zero_emission_);
 	const uint32_t m_white_blocks = add_material(SSX_MTL_LAMBERTIAN, SSX_ALBEDO_CONSTANT, white, zero_emission_);
 	const uint32_t m_white_floorceil = add_material(SSX_MTL_LAMBERTIAN, SSX_ALBEDO_CONSTANT, white, zero_emission_);
 	const uint32_t m_green = add_material(SSX_MTL_LAMBERTIAN, SSX_ALBEDO_CONSTANT, green, zero_emission_);
 	const uint32_t m_red = add_material(SSX_MTL_LAMBERTIAN, SSX_ALBEDO_CONSTANT, red, zero_emission_);
 
-	const auto lt = load_spectral_data(data_dir + "/scenes/cornell/light.csv");
-	if (lt.size() != 1) throw HostError{ -1, "Invalid data in file!" };
-	const uint32_t light_emission = add_spectrum(Spectrum(lt[0], 400, 700).scaled(200.0f));
-	const uint32_t light_albedo = add_spectrum(Spectrum(0.78f, color_.lambda_min, color_.lambda_max));
+	uint32_t light_emission;
+	if (rgb_) {
+		light_emission = add_rgb(1.0f * 200.0f, 1.0f * 200.0f, 1.0f * 200.0f); // RGB_Radiance(1,1,1) * 200.0f (src/scene.cpp:106)
+	} else {
+		const auto lt = load_spectral_data(data_dir + "/scenes/cornell/light.csv");
+		if (lt.size() != 1) throw HostError{ -1, "Invalid data in file!" };
+		light_emission = add_spectrum(Spectrum(lt[0], 400, 700).scaled(200.0f));
+	}
+	const uint32_t light_albedo = add_constant(0.78f);
 	const uint32_t m_light = add_material(SSX_MTL_LAMBERTIAN, SSX_ALBEDO_CONSTANT, light_albedo, light_emission);
 
 	struct QuadRow { uint32_t mtl; float p[4][3]; float st[4][2]; };
@@ -178,13 +195,14 @@ void Scene::build_cornell_srgb(const std::string& data_dir, const Texture* tex, 
 	if (!tex || tex->rgb.empty()) throw HostError{ -1, "Could not load texture" };
 	textures_.push_back(*tex);
 	const uint32_t m_tex = add_material(SSX_MTL_LAMBERTIAN, SSX_ALBEDO_TEXTURE, 0, zero_emission_);
-	const uint32_t white1 = add_spectrum(Spectrum(1.0f, color_.lambda_min, color_.lambda_max));
+	const uint32_t white1 = add_constant(1.0f);
 	const uint32_t m_white1 = add_material(SSX_MTL_LAMBERTIAN, SSX_ALBEDO_CONSTANT, white1, zero_emission_);
 	for (ssx_quad& q : quads_) {
 		if (q.material == 1 || q.material == 2) q.material = m_white1;
 		else if (q.material == 4) q.material = m_tex;
 	}
-	materials_[5].emission_spectrum = add_spectrum(color_.D65_rad.scaled(light_scale));
+	materials_[5].emission_spectrum = rgb_ ? add_rgb(1.0f * light_scale, 1.0f * light_scale, 1.0f * light_scale) // src/scene.cpp:314
+	                                       : add_spectrum(color_.D65_rad.scaled(light_scale));
 }
 
 // Textured unit quad seen head-on inside a +-10 box of D65 emitters (src/scene.cpp:320-415).
@@ -198,8 +216,8 @@ void Scene::build_plane_srgb(const Texture* tex) {
 	camera.vfov_deg = (2.0f * std::atan2(1.0f, camera.pos[2])) * 57.295779513082320876798154814105f; // glm::degrees
 	if (!tex || tex->rgb.empty()) throw HostError{ -1, "Could not load texture" };
 
-	const uint32_t black = add_spectrum(Spectrum(0.0f, color_.lambda_min, color_.lambda_max));
-	const uint32_t d65 = add_spectrum(color_.D65_rad);
+	const uint32_t black = add_constant(0.0f);
+	const uint32_t d65 = rgb_ ? add_rgb(1, 1, 1) : add_spectrum(color_.D65_rad); // src/scene.cpp:337-343
 	const uint32_t m_light = add_material(SSX_MTL_LAMBERTIAN, SSX_ALBEDO_CONSTANT, black, d65);
 	textures_.push_back(*tex);
 	// Lambertian with explicit light sampling, Mirror without (both converge to the same image; the
@@ -230,14 +248,21 @@ void Scene::finish() {
 	desc_.struct_size = sizeof(ssx_scene_desc);
 	std::memcpy(desc_.pv_inv, camera.matr_PV_inv, sizeof desc_.pv_inv);
 	std::memcpy(desc_.cam_pos, camera.pos, sizeof desc_.cam_pos);
-	desc_.lambda_min = color_.lambda_min;
-	desc_.lambda_step = color_.lambda_step;
-	desc_.spec_xbar = add_spectrum(color_.std_obs_xbar);
-	desc_.spec_ybar = add_spectrum(color_.std_obs_ybar);
-	desc_.spec_zbar = add_spectrum(color_.std_obs_zbar);
-	desc_.spec_basis_r = add_spectrum(color_.basis_r);
-	desc_.spec_basis_g = add_spectrum(color_.basis_g);
-	desc_.spec_basis_b = add_spectrum(color_.basis_b);
+	if (rgb_) { // no observer, no basis: the "wavelengths" are the component indices 0,1,2,(3)
+		desc_.lambda_min = 0.0f;
+		desc_.lambda_step = 1.0f;
+		desc_.spec_xbar = desc_.spec_ybar = desc_.spec_zbar = zero_emission_;
+		desc_.spec_basis_r = desc_.spec_basis_g = desc_.spec_basis_b = zero_emission_;
+	} else {
+		desc_.lambda_min = color_.lambda_min;
+		desc_.lambda_step = color_.lambda_step;
+		desc_.spec_xbar = add_spectrum(color_.std_obs_xbar);
+		desc_.spec_ybar = add_spectrum(color_.std_obs_ybar);
+		desc_.spec_zbar = add_spectrum(color_.std_obs_zbar);
+		desc_.spec_basis_r = add_spectrum(color_.basis_r);
+		desc_.spec_basis_g = add_spectrum(color_.basis_g);
+		desc_.spec_basis_b = add_spectrum(color_.basis_b);
+	}
 	desc_.spectra = spectra_.data(); desc_.n_spectra = static_cast<uint32_t>(spectra_.size());
 	desc_.samples = samples_.data(); desc_.n_samples = static_cast<uint32_t>(samples_.size());
 	desc_.materials = materials_.data(); desc_.n_materials = static_cast<uint32_t>(materials_.size());
@@ -245,19 +270,20 @@ void Scene::finish() {
 	desc_.lights = lights_.data(); desc_.n_lights = static_cast<uint32_t>(lights_.size());
 	desc_.textures = texture_descs_.data(); desc_.n_textures = static_cast<uint32_t>(texture_descs_.size());
 	// texel decode table: (u8 * (1/255)) -> srgb_to_lrgb, as sRGB_ReflectanceTexture::sample does per texel
-	desc_.uplift = meng_ ? SSX_UPLIFT_MENG : (jh_ ? SSX_UPLIFT_JH : SSX_UPLIFT_OURS);
+	const int mode = rgb_ ? static_cast<int>(SSX_MODE_RGB) : static_cast<int>(meng_ ? SSX_UPLIFT_MENG : (jh_ ? SSX_UPLIFT_JH : SSX_UPLIFT_OURS));
+	desc_.uplift = static_cast<uint32_t>(mode);
 	if (jh_) { desc_.jh_res = jh_->res; desc_.jh_scale = jh_->scale.data(); desc_.jh_data = jh_->data.data(); }
 	if (meng_) { meng_desc_ = meng_->desc(); desc_.meng = &meng_desc_; }
 	for (int u = 0; u < 256; ++u) desc_.srgb_to_linear[u] = srgb_to_lrgb(static_cast<float>(static_cast<uint8_t>(u)) * (1.0f / 255.0f));
 }
 
 Scene::Scene(const ColorData& color, const std::string& scene_name, const std::string& data_dir, const Texture* texture, float light_scale,
-             const JHModel* jh, bool explicit_light_sampling, const MengGrid* meng)
-	: name(scene_name), color_(color), jh_(jh), meng_(meng), els_(explicit_light_sampling) {
-	if (jh_ && meng_) throw HostError{ -3, "one uplift at a time" };
+             const JHModel* jh, bool explicit_light_sampling, const MengGrid* meng, bool rgb_mode)
+	: name(scene_name), color_(color), jh_(jh), meng_(meng), els_(explicit_light_sampling), rgb_(rgb_mode) {
+	if ((jh_ && meng_) || (rgb_ && (jh_ || meng_))) throw HostError{ -3, "one render mode / uplift at a time" };
 	if ((jh_ || meng_) && color_.observer != 1931) throw HostError{ -3, "Only our algorithm currently implements support for the newest CIE standard observer!" }; // stdafx.hpp:107-109
 	// MaterialBase's default emission: constant 0 over the rendered band (src/material.hpp:95-96)
-	zero_emission_ = add_spectrum(Spectrum(0.0f, color_.lambda_min, color_.lambda_max));
+	zero_emission_ = add_constant(0.0f);
 	if (name == "cornell") build_cornell(data_dir);
 	else if (name == "cornell-srgb") build_cornell_srgb(data_dir, texture, light_scale);
 	else if (name == "plane-srgb") build_plane_srgb(texture);

@@ -35,7 +35,7 @@ public:
 	// basis uplift (RENDER_MODE_SPECTRAL_OURS, the reference's default).  meng: the Meng et al. grid
 	// (RENDER_MODE_SPECTRAL_MENG); at most one of jh / meng.
 	Scene(const ColorData& color, const std::string& name, const std::string& data_dir, const Texture* texture, float light_scale,
-	      const JHModel* jh = nullptr, bool explicit_light_sampling = true, const MengGrid* meng = nullptr);
+	      const JHModel* jh = nullptr, bool explicit_light_sampling = true, const MengGrid* meng = nullptr, bool rgb_mode = false);
 
 	const ssx_scene_desc& desc() const { return desc_; }
 	Camera camera;
@@ -43,6 +43,10 @@ public:
 
 private:
 	uint32_t add_spectrum(const Spectrum& s);
+	// a constant reflectance/radiance: SpectralX(v) over the rendered band, or RGB_X(v) in RGB mode
+	uint32_t add_constant(float v);
+	// RENDER_MODE_RGB stand-in for a spectrum: the table {r,g,b,0} on the grid 0,1,2,3 (include/ssx.h, SSX_MODE_RGB)
+	uint32_t add_rgb(float r, float g, float b);
 	uint32_t add_material(uint32_t kind, uint32_t albedo_mode, uint32_t albedo, uint32_t emission);
 	void add_quad(uint32_t material, const float p[4][3], const float st[4][2]);
 	void build_cornell(const std::string& data_dir);
@@ -64,6 +68,7 @@ private:
 	const MengGrid* meng_ = nullptr;
 	ssx_meng_grid meng_desc_{};
 	bool els_ = true;
+	bool rgb_ = false;
 	ssx_scene_desc desc_{};
 };
 

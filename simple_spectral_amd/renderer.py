@@ -43,6 +43,8 @@ class Options:
     light_scale: float = 30.0            # lightsc (src/scene.cpp:291-293)
     explicit_light_sampling: bool = True  # EXPLICIT_LIGHT_SAMPLING (src/stdafx.hpp:44); False also makes
     #                                       plane-srgb's textured quad a mirror (src/scene.cpp:346-355)
+    render_mode: str = "spectral"        # "spectral" (RENDER_MODE_SPECTRAL) | "rgb" (RENDER_MODE_RGB, src/stdafx.hpp:91-93:
+    #                                       no spectra; `xyza` then holds linear RGB + alpha, `uplift`/`observer` are unused)
     uplift: str = "ours"                 # RENDER_MODE_SPECTRAL_ALGNUM: "ours" (1) | "meng" (2, Meng et al. 2015) | "jh" (3, Jakob-Hanika 2019)
     meng_grid_path: Optional[str] = None  # "SSXMENG1" file converted from the authors' header (simple_spectral_amd/meng.py)
     jh_res: int = 64                     # resolution of the fitted JH model when no coefficient file exists
@@ -69,7 +71,7 @@ class Scene:
     """Host-prepared scene + colour tables (libssx_host.so)."""
 
     def __init__(self, name, observer=1931, texture=None, light_scale=30.0, data_dir=DEFAULT_DATA_DIR,
-                 uplift="ours", jh_res=64, jh_coeff_path=None, explicit_light_sampling=True, meng_grid_path=None):
+                 uplift="ours", jh_res=64, jh_coeff_path=None, explicit_light_sampling=True, meng_grid_path=None, render_mode="spectral"):
         lib = _capi.host_lib()
         self._lib = lib
         self._h = C.c_void_p()
@@ -85,11 +87,13 @@ class Scene:
         tp, tw, th = (self._tex.ctypes.data, self._tex.shape[1], self._tex.shape[0]) if self._tex is not None else (None, 0, 0)
         if uplift not in ("ours", "meng", "jh"):
             raise SsxError(_capi.SSX_ERR_SCENE, "unsupported uplift %r (ours | meng | jh)" % (uplift,))
+        if render_mode not in ("spectral", "rgb"):
+            raise SsxError(_capi.SSX_ERR_SCENE, "unsupported render mode %r (spectral | rgb)" % (render_mode,))
         code = {"ours": _capi.SSX_UPLIFT_OURS, "meng": _capi.SSX_UPLIFT_MENG, "jh": _capi.SSX_UPLIFT_JH}[uplift]
         table_path = (meng_grid_path or os.path.join(data_dir, "meng-et-al-2015-grid.bin")) if uplift == "meng" else jh_coeff_path
         rc = lib.ssh_scene_create_ex(name.encode(), data_dir.encode(), observer, tp, tw, th,
                                      tex_path.encode() if tex_path else None, C.c_float(light_scale),
-                                     code | (0 if explicit_light_sampling else 0x100),
+                                     code | (0 if explicit_light_sampling else 0x100) | (0x200 if render_mode == "rgb" else 0),
                                      table_path.encode() if table_path else None, jh_res, C.byref(self._h))
         if rc != 0:
             raise SsxError(rc, lib.ssh_last_error().decode())
@@ -142,7 +146,7 @@ class Renderer:
     def __init__(self, options: Options):
         self.options = options
         self.scene = Scene(options.scene_name, options.observer, options.texture, options.light_scale, options.data_dir,
-                           options.uplift, options.jh_res, options.jh_coeff_path, options.explicit_light_sampling, options.meng_grid_path)
+                           options.uplift, options.jh_res, options.jh_coeff_path, options.explicit_light_sampling, options.meng_grid_path, options.render_mode)
         self._lib = _capi.hip_lib()
         self._ctx = C.c_void_p()
         rc = self._lib.ssx_create(options.device, C.byref(self._ctx))

@@ -93,6 +93,7 @@ def load(variant=""):
     lib.orc_jh_fetch.argtypes = [vp, f32p, f32p]
     lib.orc_jh_eval_precise.restype = C.c_float
     lib.orc_jh_eval_precise.argtypes = [f32p, C.c_float]
+    lib.orc_color_set_rgb_mode.argtypes = [vp, C.c_int]
     lib.orc_color_set_meng.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp, vp]
     lib.orc_meng_xyz_to_p.restype = C.c_float
     lib.orc_meng_xyz_to_p.argtypes = [vp, C.c_float, f32p]
@@ -101,6 +102,7 @@ def load(variant=""):
     lib.orc_scene_destroy.argtypes = [vp]
     lib.orc_scene_set_material_kind.argtypes = [vp, C.c_int, C.c_int]
     lib.orc_scene_quad_material.argtypes = [vp, C.c_int]
+    lib.orc_scene_material_rgb.argtypes = [vp, C.c_int, f32p]
     lib.orc_seed_sample.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(Rng)]
     lib.orc_render_sample.argtypes = [vp, vp, C.POINTER(Rng), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t,
                                       C.c_int, f32p, C.POINTER(Stats)]
@@ -170,10 +172,10 @@ class Oracle:
     """Colour tables + one scene, with render helpers.  observer: 1931 | 2006."""
 
     def __init__(self, scene="cornell-srgb", observer=1931, texture="test-img.png", light_scale=30.0,
-                 variant="", data_dir=DATA_DIR, jh=None, meng=None):
+                 variant="", data_dir=DATA_DIR, jh=None, meng=None, rgb=False):
         """jh: (res, scale, data) Jakob-Hanika model -> RENDER_MODE_SPECTRAL_JH; meng: grid dict as
         returned by ref_lib.meng_table() / simple_spectral_amd.meng.load_table -> RENDER_MODE_SPECTRAL_MENG;
-        neither -> "ours"."""
+        neither -> "ours".  rgb=True -> RENDER_MODE_RGB (no spectra; renders return lRGB+A)."""
         self.lib = load(variant)
         self.color = self.lib.orc_color_create(data_dir.encode(), observer)
         if not self.color:
@@ -183,6 +185,8 @@ class Oracle:
             scale = np.ascontiguousarray(scale, dtype=np.float32); data = np.ascontiguousarray(data, dtype=np.float32)
             if self.lib.orc_color_set_jh(self.color, int(res), scale.ctypes.data, data.ctypes.data) != 0:
                 raise RuntimeError(self.lib.orc_last_error().decode())
+        if rgb:
+            self.lib.orc_color_set_rgb_mode(self.color, 1)
         if meng is not None:
             cells = np.ascontiguousarray(meng["cells"], dtype=np.int32); points = np.ascontiguousarray(meng["points"], dtype=np.float32)
             m = np.ascontiguousarray(meng["xy_to_uv"], dtype=np.float32)

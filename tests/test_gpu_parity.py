@@ -279,3 +279,27 @@ def test_meng_grid_errors(meng_grid, tmp_path):
     with pytest.raises(SsxError) as e:
         Renderer(Options(scene_name="cornell-srgb", texture="test-img.png", uplift="meng", meng_grid_path=path, observer=2006))
     assert e.value.code == _capi.SSX_ERR_SCENE                # stdafx.hpp:107-109
+
+
+@pytest.mark.parametrize("scene,texture,W,H,spp,io,els", [
+    ("cornell", None, 64, 48, 6, False, True), ("cornell-srgb", "test-img.png", 48, 40, 5, False, True),
+    ("cornell-srgb", "crystal-lizard-512.png", 128, 128, 8, True, True), ("plane-srgb", "test-img.png", 48, 40, 5, False, True),
+    ("plane-srgb", "test-img.png", 40, 40, 4, False, False), ("cornell-srgb", "test-img.png", 33, 27, 3, False, False)])
+def test_rgb_render_mode_bit_exact(scene, texture, W, H, spp, io, els):
+    """RENDER_MODE_RGB (src/stdafx.hpp:91-93): the integrator carries linear RGB -- no wavelength draw
+    (src/renderer.cpp:134-143), texels as they are (src/material.cpp:61-63), RGB scene constants
+    (src/scene.cpp:69-82,106,314,341), plain mean of the samples (src/renderer.cpp:300-304), sRGB
+    transfer only on output (:306).  `xyza` then holds lRGB + alpha."""
+    kw = dict(texture=texture) if texture else {}
+    r = Renderer(Options(scene_name=scene, res=(W, H), spp=spp, seed=6, render_mode="rgb", indirect_only=io, explicit_light_sampling=els, **kw))
+    r.render_start(); r.render_wait()
+    orc = ol.Oracle(scene, rgb=True, **kw)
+    if not els and scene == "plane-srgb":
+        orc.lib.orc_scene_set_material_kind(orc.scene, orc.lib.orc_scene_quad_material(orc.scene, 0), 1)   # mirror (scene.cpp:346-355)
+    ref = orc.render(W, H, spp, seed=6, indirect_only=io, els=els)
+    assert np.array_equal(bits(r.xyza), bits(ref))
+    assert np.isfinite(ref).all() and ref[..., :3].max() > 0
+    assert np.array_equal(bits(r.framebuffer), bits(orc.to_srgba(ref)))
+    if scene != "plane-srgb" or els:
+        spectral = ol.Oracle(scene, **kw).render(W, H, spp, seed=6, indirect_only=io, els=els)
+        assert not np.array_equal(bits(spectral), bits(ref))

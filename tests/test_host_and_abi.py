@@ -163,3 +163,36 @@ def test_jakob_hanika_model_host_vs_oracle_and_round_trip(tmp_path):
     with pytest.raises(SsxError) as e:
         Scene("cornell-srgb", texture="test-img.png", uplift="jh", observer=2006)
     assert e.value.code == -3    # src/stdafx.hpp:107-109
+
+
+@pytest.mark.parametrize("scene", ["cornell", "cornell-srgb", "plane-srgb"])
+def test_rgb_mode_host_scene_equals_the_oracle(scene):
+    """RENDER_MODE_RGB: the host encodes every lRGB triple as the table {r,g,b,0} on the grid 0,1,2,3
+    (include/ssx.h, SSX_MODE_RGB); per quad those triples must be the oracle's (src/scene.cpp:69-82,
+    106,300-314,337-343), and the output transform is the sRGB transfer function alone."""
+    s = Scene(scene, texture="test-img.png", render_mode="rgb")
+    o = ol.Oracle(scene, texture="test-img.png", rgb=True)
+    d = s.desc.contents
+    assert d.uplift == _capi.SSX_MODE_RGB and (d.lambda_min, d.lambda_step) == (0.0, 1.0)
+    samples = np.ctypeslib.as_array(d.samples, shape=(d.n_samples,))
+    for i in range(d.n_spectra):
+        sp = d.spectra[i]
+        assert (sp.n, sp.low, sp.delta_recip) == (4, 0.0, 1.0) and samples[sp.offset + 3] == 0.0
+    npr, nl = C.c_int(), C.c_int()
+    o.lib.orc_scene_counts(o.scene, C.byref(npr), C.byref(nl), None)
+    assert (d.n_quads, d.n_lights) == (npr.value, nl.value)
+    for q in range(d.n_quads):
+        m = d.materials[d.quads[q].material]
+        want = np.zeros(6, np.float32)
+        mode = o.lib.orc_scene_material_rgb(o.scene, o.lib.orc_scene_quad_material(o.scene, q), want.ctypes.data_as(C.POINTER(C.c_float)))
+        assert mode == m.albedo_mode
+        e = d.spectra[m.emission_spectrum]
+        assert np.array_equal(samples[e.offset:e.offset + 3], want[:3]), q
+        if mode == 0:
+            a = d.spectra[m.albedo_spectrum]
+            assert np.array_equal(samples[a.offset:a.offset + 3], want[3:]), q
+        assert bool(d.quads[q].is_light) == bool((want[:3] > 0).any())
+    x = np.random.RandomState(1).uniform(0, 2, (64, 4)).astype(np.float32)
+    assert np.array_equal(s.xyza_to_srgba(x).view(np.uint32), o.to_srgba(x).view(np.uint32))
+    with pytest.raises(SsxError):
+        Scene(scene, texture="test-img.png", render_mode="nope")
