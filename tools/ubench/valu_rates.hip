@@ -40,6 +40,35 @@ KERNEL(k_and_b32, F8, OP1("v_and_b32"), SINKF)
 KERNEL(k_lshl_b32, F8, OP1("v_lshlrev_b32"), SINKF)
 KERNEL(k_div_fixup, F8, OP3("v_div_fixup_f32"), SINKF)
 KERNEL(k_cndmask, F8, OP1("v_cndmask_b32"), SINKF)
+KERNEL(k_sub_f32, F8, OP1("v_sub_f32"), SINKF)
+KERNEL(k_max_f32, F8, OP1("v_max_f32"), SINKF)
+KERNEL(k_min_f32, F8, OP1("v_min_f32"), SINKF)
+KERNEL(k_or_b32, F8, OP1("v_or_b32"), SINKF)
+KERNEL(k_xor_b32, F8, OP1("v_xor_b32"), SINKF)
+KERNEL(k_add_u32, F8, OP1("v_add_u32"), SINKF)
+KERNEL(k_max3_f32, F8, OP3("v_max3_f32"), SINKF)
+KERNEL(k_med3_f32, F8, OP3("v_med3_f32"), SINKF)
+// VOP2 fused multiply-accumulate: d += a*b
+#define OPMAC(ins) asm volatile(ins " %0, %1, %1" : "+v"(a0) : "v"(b)); asm volatile(ins " %0, %1, %1" : "+v"(a1) : "v"(b)); asm volatile(ins " %0, %1, %1" : "+v"(a2) : "v"(b)); asm volatile(ins " %0, %1, %1" : "+v"(a3) : "v"(b)); asm volatile(ins " %0, %1, %1" : "+v"(a4) : "v"(b)); asm volatile(ins " %0, %1, %1" : "+v"(a5) : "v"(b)); asm volatile(ins " %0, %1, %1" : "+v"(a6) : "v"(b)); asm volatile(ins " %0, %1, %1" : "+v"(a7) : "v"(b));
+KERNEL(k_fmac_f32, F8, OPMAC("v_fmac_f32_e32"), SINKF)
+// d = a*K + d with a literal (VOP2 + 32-bit literal)
+#define OPMK(ins) asm volatile(ins " %0, %1, 0x3fc00000, %0" : "+v"(a0) : "v"(b)); asm volatile(ins " %0, %1, 0x3fc00000, %0" : "+v"(a1) : "v"(b)); asm volatile(ins " %0, %1, 0x3fc00000, %0" : "+v"(a2) : "v"(b)); asm volatile(ins " %0, %1, 0x3fc00000, %0" : "+v"(a3) : "v"(b)); asm volatile(ins " %0, %1, 0x3fc00000, %0" : "+v"(a4) : "v"(b)); asm volatile(ins " %0, %1, 0x3fc00000, %0" : "+v"(a5) : "v"(b)); asm volatile(ins " %0, %1, 0x3fc00000, %0" : "+v"(a6) : "v"(b)); asm volatile(ins " %0, %1, 0x3fc00000, %0" : "+v"(a7) : "v"(b));
+KERNEL(k_fmamk_f32, F8, OPMK("v_fmamk_f32"), SINKF)
+// explicit-SGPR-mask select (VOP3) and compare into an SGPR pair / into VCC
+#define OPSEL asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a0) : "v"(b) : "s20", "s21"); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a1) : "v"(b)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a2) : "v"(b)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a3) : "v"(b)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a4) : "v"(b)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a5) : "v"(b)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a6) : "v"(b)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a7) : "v"(b));
+KERNEL(k_cndmask_e64, F8; asm volatile("s_mov_b64 s[20:21], 0x5555" ::: "s20", "s21"), OPSEL, SINKF)
+#define OPCMPS asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %1" :: "v"(a0), "v"(b) : "s20", "s21"); asm volatile("v_cmp_lt_f32_e64 s[22:23], %0, %1" :: "v"(a1), "v"(b) : "s22", "s23"); asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %1" :: "v"(a2), "v"(b) : "s20", "s21"); asm volatile("v_cmp_lt_f32_e64 s[22:23], %0, %1" :: "v"(a3), "v"(b) : "s22", "s23"); asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %1" :: "v"(a4), "v"(b) : "s20", "s21"); asm volatile("v_cmp_lt_f32_e64 s[22:23], %0, %1" :: "v"(a5), "v"(b) : "s22", "s23"); asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %1" :: "v"(a6), "v"(b) : "s20", "s21"); asm volatile("v_cmp_lt_f32_e64 s[22:23], %0, %1" :: "v"(a7), "v"(b) : "s22", "s23");
+KERNEL(k_cmp_e64, F8, OPCMPS, SINKF)
+#define OPCMPV asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" :: "v"(a0), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" :: "v"(a1), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" :: "v"(a2), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" :: "v"(a3), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" :: "v"(a4), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" :: "v"(a5), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" :: "v"(a6), "v"(b) : "vcc"); asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" :: "v"(a7), "v"(b) : "vcc");
+KERNEL(k_cmp_e32, F8, OPCMPV, SINKF)
+// compare + select pair through VCC, as the compiler emits for a ? b : c
+#define OPCS(A) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1\n\tv_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(A) : "v"(b) : "vcc");
+KERNEL(k_cmp_sel, F8, OPCS(a0) OPCS(a1) OPCS(a2) OPCS(a3) OPCS(a4) OPCS(a5) OPCS(a6) OPCS(a7), SINKF)
+// mul with an SGPR operand and with an inline constant
+#define OPS(ins, src) asm volatile(ins " %0, " src ", %0" : "+v"(a0)); asm volatile(ins " %0, " src ", %0" : "+v"(a1)); asm volatile(ins " %0, " src ", %0" : "+v"(a2)); asm volatile(ins " %0, " src ", %0" : "+v"(a3)); asm volatile(ins " %0, " src ", %0" : "+v"(a4)); asm volatile(ins " %0, " src ", %0" : "+v"(a5)); asm volatile(ins " %0, " src ", %0" : "+v"(a6)); asm volatile(ins " %0, " src ", %0" : "+v"(a7));
+KERNEL(k_mul_sgpr, F8; asm volatile("s_mov_b32 s20, 0x3f800001" ::: "s20"), OPS("v_mul_f32_e32", "s20"), SINKF)
+KERNEL(k_mul_inl, F8, OPS("v_mul_f32_e32", "2.0"), SINKF)
+KERNEL(k_mul_lit, F8, OPS("v_mul_f32_e32", "0x3f800001"), SINKF)
 
 #define D8 double a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7, b = seed * 0.5 + threadIdx.x
 #define SINKD if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 12345.678) out[threadIdx.x] = (float)a0
@@ -77,7 +106,11 @@ struct Entry { const char* name; kern_t k; };
 int main() {
 	Entry es[] = {
 		{"v_add_f32", k_add_f32}, {"v_mul_f32", k_mul_f32}, {"v_fma_f32", k_fma_f32}, {"v_min3_f32", k_min3_f32},
-		{"v_cndmask_b32", k_cndmask}, {"v_and_b32", k_and_b32}, {"v_lshlrev_b32", k_lshl_b32}, {"v_floor_f32", k_floor_f32},
+		{"v_cndmask_b32", k_cndmask}, {"v_sub_f32", k_sub_f32}, {"v_max_f32", k_max_f32}, {"v_min_f32", k_min_f32}, {"v_or_b32", k_or_b32},
+		{"v_xor_b32", k_xor_b32}, {"v_add_u32", k_add_u32}, {"v_max3_f32", k_max3_f32}, {"v_med3_f32", k_med3_f32},
+		{"v_fmac_f32_e32", k_fmac_f32}, {"v_fmamk_f32", k_fmamk_f32}, {"v_cndmask_b32_e64 sgpr", k_cndmask_e64},
+		{"v_cmp_lt_f32_e64 ->sgpr", k_cmp_e64}, {"v_cmp_lt_f32_e32 ->vcc", k_cmp_e32}, {"v_cmp+v_cndmask (2 instr)", k_cmp_sel},
+		{"v_mul_f32 sgpr src", k_mul_sgpr}, {"v_mul_f32 inline const", k_mul_inl}, {"v_mul_f32 literal", k_mul_lit}, {"v_and_b32", k_and_b32}, {"v_lshlrev_b32", k_lshl_b32}, {"v_floor_f32", k_floor_f32},
 		{"v_cvt_i32_f32", k_cvt_i32_f32}, {"v_cvt_f32_u32", k_cvt_f64_f32x}, {"v_div_fixup_f32", k_div_fixup},
 		{"v_rcp_f32", k_rcp_f32}, {"v_sqrt_f32", k_sqrt_f32}, {"v_rsq_f32", k_rsq_f32},
 		{"v_mul_lo_u32", k_mul_lo_u32}, {"v_mul_hi_u32", k_mul_hi_u32},
