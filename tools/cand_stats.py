@@ -1,6 +1,6 @@
 import sys, os, ctypes as C
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
-os.environ["SSX_HIP_LIB_OVERRIDE"] = os.path.join(R, "tools", "_abl", "abl_cands.so")
+os.environ["SSX_HIP_LIB_OVERRIDE"] = os.path.join(R, "tools", "_abl", "abl_%s.so" % (sys.argv[1] if len(sys.argv) > 1 else "cands"))
 import torch
 from simple_spectral_amd import Options, Renderer, _capi
 r = Renderer(Options(scene_name="cornell-srgb", res=(512, 512), spp=32, texture="crystal-lizard-512.png"))
