@@ -138,7 +138,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    r.set_timing(True)  # HIP events on the launch stream around each of the four kernels
+    r.set_timing(True)  # HIP events on the launch stream around each kernel of the pipeline
     # kernel duration: HIP events on the launch stream around each render (memset + megakernel +
     # finalize; the two small kernels are microseconds next to the megakernel)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -165,8 +165,10 @@ def main():
         per_gpu_samples = W * H * args.spp
         flop = FLOP_PER_SAMPLE.get(args.scene, 1.28e4)
         achieved_tflops = per_gpu_samples * flop / (kernel_ms * 1e-3) / 1e12
-        # algorithmic HBM traffic of the megakernel per launch: record read + rewrite, frames written
-        hbm_bytes = per_gpu_samples * (64 + 48 * FRAMES_PER_SAMPLE.get(args.scene, 3.29))
+        # algorithmic HBM traffic of the path kernel per launch and sample: record read (32 B) + rewritten at the end
+        # of the path (32) + read again and overwritten with XYZA by the fold (32 + 16); 48-B frames written once and
+        # read once by the fold
+        hbm_bytes = per_gpu_samples * (112 + 96 * FRAMES_PER_SAMPLE.get(args.scene, 3.29))
         info = r.kernel_info()
         line = {
             "metric": "Msamples/s (w*h*spp/s) %s %dx%d" % (args.scene, W, H),

@@ -183,9 +183,10 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* params, void* d_xyz
 /* Last error text for ctx (or for ssx_create when ctx is NULL). */
 const char* ssx_last_error(const ssx_ctx* ctx);
 
-/* Measurement aid: when enabled, HIP events are recorded on the launch stream around the four
- * stages of every launch; ssx_get_timing waits for them and returns (and clears) the summed
- * milliseconds {generate, path megakernel, resolve, accumulate} since the last call. */
+/* Measurement aid: when enabled, HIP events are recorded on the launch stream around the stages
+ * of every launch; ssx_get_timing waits for them and returns (and clears) the summed milliseconds
+ * {generate, path megakernel, resolve, accumulate} since the last call.  (The resolve stage -- fold
+ * of the recursion + XYZ -- runs inside the path kernel, so its slot reads ~0.) */
 int ssx_set_timing(ssx_ctx* ctx, int enable);
 int ssx_get_timing(ssx_ctx* ctx, float stage_ms[4]);
 

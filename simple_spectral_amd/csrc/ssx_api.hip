@@ -239,7 +239,7 @@ int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
 // accumulate pass consumes them; the buffer bounds how many samples per pixel one launch may cover.
 constexpr size_t kSampleBufferBudget = (size_t)32 << 30; // bytes: 32 B record + 9 x 48 B frames per sample in flight (288 GB HBM)
 constexpr size_t kBytesPerSampleInFlight = sizeof(SsxSampleRecord) + SSX_MAX_FRAMES * sizeof(SsxFrame);
-constexpr uint32_t kTargetUnits = 16384;               // wave work units wanted per launch (~8 per SIMD)
+constexpr uint32_t kTargetUnits = 32768;               // wave work units wanted per launch (~32 per SIMD; measured best of 4k..128k)
 
 struct LaunchPlan { SsxKernelArgs args; size_t lds_bytes; uint32_t max_spp_per_launch; };
 
@@ -349,9 +349,8 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 
 int enqueue_back(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stream) {
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[3], stream));
-	const uint64_t want = (b.n_rec + 255u) / 256u;
-	hipLaunchKernelGGL(ssx_resolve_kernel, dim3((uint32_t)(want < 8192u ? want : 8192u)), dim3(256), pl.lds_bytes, stream, b.a);
-	SSX_HIP(ctx, hipGetLastError());
+	// (the fold + XYZ conversion runs at the end of every wave's unit inside the path kernel; the stage keeps its
+	// slot in the timing report and reads 0)
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[4], stream));
 	hipLaunchKernelGGL(ssx_accumulate_kernel, dim3((b.a.my_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, b.a, ctx->d_accum);
 	SSX_HIP(ctx, hipGetLastError());

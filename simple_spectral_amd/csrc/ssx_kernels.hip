@@ -838,7 +838,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 		for (int k = 0; k < 4; ++k) rad[k] = direct[k];
 		return false;
 	}
-	// record this level for the backward fold (done by ssx_resolve_kernel): [depth][record] so that
+	// record this level for the backward fold (resolve_records, at the end of the wave's unit): [depth][record] so that
 	// the 64 lanes of a wave, which hold (mostly) consecutive records, store contiguously
 #ifndef SSX_ABL_NOSTORES
 	{
@@ -856,9 +856,57 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 	return true;
 }
 
+// Backward fold of the recursion for finished samples (renderer.cpp:247: radiance += L(next) *
+// n_dot_l * f_s / pdf, evaluated innermost first = the reference's post-order) over the frames the
+// path recorded, then flux -> CIE XYZ (util/color.hpp:115-139; FLAT_FIELD_CORRECTION: flux =
+// radiance, renderer.cpp:262-263).  A record becomes {X, Y, Z, alpha} ({R, G, B, alpha} in RGB mode).
+// Four records of the lane (consecutive k of its pixel) are folded side by side so that the frame
+// loads of a level are four independent requests instead of a chain of dependent round trips.
+#define SSX_RESOLVE_WAYS 4u
+__device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count) {
+	float rad[SSX_RESOLVE_WAYS][4];
+	uint32_t depth[SSX_RESOLVE_WAYS], lam[SSX_RESOLVE_WAYS], hitf[SSX_RESOLVE_WAYS];
+	uint32_t top = 0;
+#pragma unroll
+	for (uint32_t s = 0; s < SSX_RESOLVE_WAYS; ++s) {
+		depth[s] = 0; lam[s] = 0; hitf[s] = 0;
+		rad[s][0] = rad[s][1] = rad[s][2] = rad[s][3] = 0.0f;
+		if (s < count) {
+			const SsxSampleRecord rec = a.samples[r0 + s * stride];
+			rad[s][0] = rec.a.x; rad[s][1] = rec.a.y; rad[s][2] = rec.a.z; rad[s][3] = rec.a.w;
+			lam[s] = rec.b.x; hitf[s] = rec.b.y; depth[s] = rec.b.z;
+		}
+		top = max(top, depth[s]);
+	}
+	for (uint32_t d = top; d-- > 0u;) {
+		SsxFrame F[SSX_RESOLVE_WAYS];
+#pragma unroll
+		for (uint32_t s = 0; s < SSX_RESOLVE_WAYS; ++s)
+			if (d < depth[s]) F[s] = a.frames[d * (uint32_t)a.n_records + r0 + s * stride];
+#pragma unroll
+		for (uint32_t s = 0; s < SSX_RESOLVE_WAYS; ++s)
+			if (d < depth[s]) {
+				rad[s][0] = F[s].direct.x + ((rad[s][0] * F[s].np.x) * F[s].f_s.x) / F[s].np.y;
+				rad[s][1] = F[s].direct.y + ((rad[s][1] * F[s].np.x) * F[s].f_s.y) / F[s].np.y;
+				rad[s][2] = F[s].direct.z + ((rad[s][2] * F[s].np.x) * F[s].f_s.z) / F[s].np.y;
+				rad[s][3] = F[s].direct.w + ((rad[s][3] * F[s].np.x) * F[s].f_s.w) / F[s].np.y;
+			}
+	}
+#pragma unroll
+	for (uint32_t s = 0; s < SSX_RESOLVE_WAYS; ++s)
+		if (s < count) {
+			Hero flux; flux.v[0] = rad[s][0]; flux.v[1] = rad[s][1]; flux.v[2] = rad[s][2]; flux.v[3] = rad[s][3];
+			float xyz[3];
+			if (a.rgb_mode) { xyz[0] = rad[s][0]; xyz[1] = rad[s][1]; xyz[2] = rad[s][2]; } // renderer.cpp:274-276: lRGB_A_F32(pixel_flux_est, hit)
+			else
+			flux_to_xyz(L, flux, __uint_as_float(lam[s]), xyz);
+			a.samples[r0 + s * stride].a = make_float4(xyz[0], xyz[1], xyz[2], hitf[s] ? 1.0f : 0.0f);
+		}
+}
+
 } // namespace
 
-// Stage 1 of 4: one lane per sample.  Camera ray + hero wavelength (f64 camera maths of
+// Stage 1 of 3: one lane per sample.  Camera ray + hero wavelength (f64 camera maths of
 // renderer.cpp:113-138) for every (owned pixel, k in [k0,k1)) into the sample buffer,
 // layout [tile slot][k-k0][pixel in tile] so a wave writes 64 consecutive 32-byte records.
 extern "C" __global__ void __launch_bounds__(256) ssx_generate_kernel(SsxKernelArgs a) {
@@ -878,14 +926,14 @@ extern "C" __global__ void __launch_bounds__(256) ssx_generate_kernel(SsxKernelA
 	a.samples[rec_index] = rec;
 }
 
-// Stage 2 of 4: the path megakernel.  Work unit of one wave64 = one 8x8 tile (Framebuffer::Tile,
+// Stage 2 of 3: the path megakernel.  Work unit of one wave64 = one 8x8 tile (Framebuffer::Tile,
 // renderer.cpp:396-409) x a group of consecutive samples; its items (pixel of the tile, k) are
 // enumerated k-major and handed to lanes as they fall idle: every iteration the idle lanes
 // ballot, take consecutive item numbers by prefix count, and load those samples' camera rays, so
 // all 64 lanes trace a ray in (almost) every iteration although path lengths differ (26 % of
 // Cornell paths end after one interaction, 24 % run all nine).  The recursion L() of the
 // reference is evaluated as a forward pass here (each level's direct light and continuation
-// factors go to the frame buffer, write-only) and a backward fold in ssx_resolve_kernel.
+// factors go to the frame buffer) and a backward fold over them when the wave has finished its unit.
 extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArgs a) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_blob[];
 	for (uint32_t w = threadIdx.x; w < a.blob_words; w += blockDim.x) lds_blob[w] = a.blob[w];
@@ -949,7 +997,7 @@ extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArg
 			float rad[4];
 			if (!path_step(L, a, p, rad SSX_PROF_PASS)) {
 				// deepest level reached: its radiance, the number of recorded frames, lambda_0 and the
-				// hit flag replace the sample's record; the fold happens in ssx_resolve_kernel
+				// hit flag replace the sample's record; the fold happens at the end of the unit
 				SsxSampleRecord out;
 				out.a = make_float4(rad[0], rad[1], rad[2], rad[3]);
 				out.b = make_uint4(__float_as_uint(p.lambda_0), p.hit_anything ? 1u : 0u, p.depth, 0u);
@@ -958,6 +1006,17 @@ extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArg
 			}
 		}
 		SSX_MARK(8);
+	}
+	// Resolve this unit's samples: every lane folds the records of its own pixel.  The loads of this
+	// tail (frames and records this wave wrote during the unit) overlap with the arithmetic of the other
+	// waves on the SIMD, which a separate HBM-bound pass after the kernel could not.
+	__threadfence(); // the records were written by whichever lane ran the sample
+	{
+		const uint32_t lane = threadIdx.x & 63u;
+		const bool in_image = (lane & 7u) < tw && (lane >> 3) < th;
+		if (in_image)
+			for (uint32_t kq = 0; kq < kb - ka; kq += SSX_RESOLVE_WAYS)
+				resolve_records(L, a, rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, kb - ka - kq));
 	}
 #ifdef SSX_PROFILE_REGIONS
 	if ((threadIdx.x & 63u) == 0u && a.prof) {
@@ -969,47 +1028,7 @@ extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArg
 #endif
 }
 
-// Stage 3 of 4: one lane per sample.  Backward fold of the recursion (renderer.cpp:247:
-// radiance += L(next) * n_dot_l * f_s / pdf, evaluated innermost first = the reference's
-// post-order) over the frames the path kernel recorded, then flux -> CIE XYZ (util/color.hpp:
-// 115-139; FLAT_FIELD_CORRECTION: flux = radiance, renderer.cpp:262-263).  The record becomes
-// {X, Y, Z, alpha}.
-extern "C" __global__ void __launch_bounds__(256) ssx_resolve_kernel(SsxKernelArgs a) {
-	extern __shared__ __attribute__((aligned(16))) uint32_t lds_blob[];
-	for (uint32_t w = threadIdx.x; w < a.blob_words; w += blockDim.x) lds_blob[w] = a.blob[w];
-	__syncthreads();
-	Lds L; L.w = lds_blob;
-	// persistent blocks, grid-stride over the records: the scene tables are staged once per block
-	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_records; r += (uint64_t)gridDim.x * blockDim.x) {
-		if (a.width % 8u != 0u || a.height % 8u != 0u) { // records of lanes outside a ragged image were never generated
-			const uint32_t lane = (uint32_t)(r & 63u);
-			const uint32_t n_k = a.k1 - a.k0;
-			const uint32_t slot = (uint32_t)((r >> 6) / n_k);
-			const uint32_t tile = a.tile_first + slot * a.tile_stride;
-			const uint32_t i = (tile % a.tiles_x) * 8u + (lane & 7u), j = (tile / a.tiles_x) * 8u + (lane >> 3);
-			if (i >= a.width || j >= a.height) continue;
-		}
-		const SsxSampleRecord rec = a.samples[r];
-		float rad[4] = { rec.a.x, rec.a.y, rec.a.z, rec.a.w };
-		uint32_t depth = rec.b.z;
-		while (depth > 0u) {
-			--depth;
-			const SsxFrame F = a.frames[depth * (uint32_t)a.n_records + (uint32_t)r];
-			rad[0] = F.direct.x + ((rad[0] * F.np.x) * F.f_s.x) / F.np.y;
-			rad[1] = F.direct.y + ((rad[1] * F.np.x) * F.f_s.y) / F.np.y;
-			rad[2] = F.direct.z + ((rad[2] * F.np.x) * F.f_s.z) / F.np.y;
-			rad[3] = F.direct.w + ((rad[3] * F.np.x) * F.f_s.w) / F.np.y;
-		}
-		Hero flux; flux.v[0] = rad[0]; flux.v[1] = rad[1]; flux.v[2] = rad[2]; flux.v[3] = rad[3];
-		float xyz[3];
-		if (a.rgb_mode) { xyz[0] = rad[0]; xyz[1] = rad[1]; xyz[2] = rad[2]; } // renderer.cpp:274-276: lRGB_A_F32(pixel_flux_est, hit)
-		else
-		flux_to_xyz(L, flux, __uint_as_float(rec.b.x), xyz);
-		a.samples[r].a = make_float4(xyz[0], xyz[1], xyz[2], rec.b.y ? 1.0f : 0.0f);
-	}
-}
-
-// Stage 4 of 4: one lane per pixel.  renderer.cpp:292-295: avg += sample*0.001f (float multiply,
+// Stage 3 of 3: one lane per pixel.  renderer.cpp:292-295: avg += sample*0.001f (float multiply,
 // widened) in ascending k -- the reference's accumulation order, whichever lane of the path
 // kernel produced the sample.  Consecutive lanes read consecutive records.
 extern "C" __global__ void __launch_bounds__(256) ssx_accumulate_kernel(SsxKernelArgs a, double* accum) {
