@@ -185,7 +185,8 @@ def main():
                          "flop_per_sample": flop, "note": "FP32 VALU-issue bound, no MFMA, HBM idle by design; peak = 157.3/2 (no FMA contraction under the parity contract)",
                          "hbm": {"achieved": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 7)},
-                         "vgprs": info["vgprs"], "scratch_bytes": info["scratch_bytes"], "lds_bytes": info["lds_bytes"]},
+                         "vgprs": info["vgprs"], "scratch_bytes": info["scratch_bytes"], "lds_bytes": info["lds_bytes"],
+                         "plan": r.plan_info()},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.scene, W, H, texture)

@@ -185,14 +185,19 @@ const char* ssx_last_error(const ssx_ctx* ctx);
 
 /* Measurement aid: when enabled, HIP events are recorded on the launch stream around the stages
  * of every launch; ssx_get_timing waits for them and returns (and clears) the summed milliseconds
- * {generate, path megakernel, resolve, accumulate} since the last call.  (The resolve stage -- fold
- * of the recursion + XYZ -- runs inside the path kernel, so its slot reads ~0.) */
+ * {generate, path megakernel, resolve, accumulate} since the last call.  (When the resolve stage --
+ * fold of the recursion + XYZ -- runs inside the path kernel, see ssx_plan_info, its slot reads ~0.) */
 int ssx_set_timing(ssx_ctx* ctx, int enable);
 int ssx_get_timing(ssx_ctx* ctx, float stage_ms[4]);
 
 /* Introspection: ABI version, and per-kernel resource usage for reports. */
 int ssx_abi_version(void);
 int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* scratch_bytes, int* max_blocks_per_cu);
+/* What ssx_upload_scene's calibration render (64x64x4 samples of the scene, fixed seed) found and
+ * chose: frames (continued interactions) per sample, and whether the fold of the recursion runs at
+ * the end of each wave's unit inside the path kernel (1) or as a streaming kernel of its own (0).
+ * A performance choice only: both give the same bits. */
+int ssx_plan_info(ssx_ctx* ctx, float* frames_per_sample, int* fold_in_path_kernel);
 
 #ifdef __cplusplus
 }

@@ -68,7 +68,7 @@ SSX_OK, SSX_ERR_DATA, SSX_ERR_ARG, SSX_ERR_SCENE, SSX_ERR_DEVICE, SSX_ERR_STATE 
 # every symbol include/ssx.h and include/ssx_host.h declare (tests check the libraries export them)
 HIP_SYMBOLS = ["ssx_create", "ssx_destroy", "ssx_upload_scene", "ssx_render_start", "ssx_render_stop",
                "ssx_is_rendering", "ssx_progress", "ssx_render_wait", "ssx_render_device", "ssx_last_error",
-               "ssx_abi_version", "ssx_kernel_info", "ssx_set_timing", "ssx_get_timing"]
+               "ssx_abi_version", "ssx_kernel_info", "ssx_plan_info", "ssx_set_timing", "ssx_get_timing"]
 HOST_SYMBOLS = ["ssh_scene_create", "ssh_scene_create_ex", "ssh_scene_destroy", "ssh_scene_desc", "ssh_xyza_to_srgba", "ssh_save_image",
                 "ssh_load_png_rgb8", "ssh_free", "ssh_color_values", "ssh_last_error"]
 
@@ -136,6 +136,7 @@ def hip_lib():
         lib.ssx_render_wait.argtypes = [vp, vp]
         lib.ssx_render_device.argtypes = [vp, C.POINTER(SsxRenderParams), vp, vp]
         lib.ssx_kernel_info.argtypes = [vp] + [C.POINTER(C.c_int)] * 5
+        lib.ssx_plan_info.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         lib.ssx_set_timing.argtypes = [vp, C.c_int]
         lib.ssx_get_timing.argtypes = [vp, C.POINTER(C.c_float)]
         _hip = lib

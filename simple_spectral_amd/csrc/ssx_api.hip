@@ -38,6 +38,8 @@ struct ssx_ctx {
 	std::vector<uint8_t*> d_textures;
 	float* d_jh_data = nullptr;
 	bool rgb_mode = false;     // scene uploaded with uplift == SSX_MODE_RGB
+	bool fuse_resolve = true;  // fold inside the path kernel (long paths) or as its own streaming kernel (short paths)
+	float calib_frames = 0.0f; // frames per sample measured by the calibration render of ssx_upload_scene
 	double* d_accum = nullptr;  size_t accum_pixels = 0;
 	SsxSampleRecord* d_samples = nullptr; size_t sample_slots = 0; // record capacity of the sample buffer
 	SsxFrame* d_frames = nullptr;
@@ -255,6 +257,7 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	a.no_els = p->no_explicit_light_sampling ? 1u : 0u;
 	a.seed = p->seed;
 	a.rgb_mode = ctx->rgb_mode ? 1u : 0u;
+	a.fuse_resolve = ctx->fuse_resolve ? 1u : 0u;
 	a.my_tiles = a.n_tiles > p->tile_first ? (a.n_tiles - p->tile_first + p->tile_stride - 1u) / p->tile_stride : 0u;
 	pl.lds_bytes = (size_t)ctx->blob_words * 4;
 	size_t per_spp = (size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u * kBytesPerSampleInFlight;
@@ -349,8 +352,11 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 
 int enqueue_back(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stream) {
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[3], stream));
-	// (the fold + XYZ conversion runs at the end of every wave's unit inside the path kernel; the stage keeps its
-	// slot in the timing report and reads 0)
+	if (!b.a.fuse_resolve) { // otherwise the fold ran at the end of every wave's unit inside the path kernel (slot reads ~0)
+		const uint64_t want = (b.n_rec + 255u) / 256u;
+		hipLaunchKernelGGL(ssx_resolve_kernel, dim3((uint32_t)(want < 8192u ? want : 8192u)), dim3(256), pl.lds_bytes, stream, b.a);
+		SSX_HIP(ctx, hipGetLastError());
+	}
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[4], stream));
 	hipLaunchKernelGGL(ssx_accumulate_kernel, dim3((b.a.my_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, b.a, ctx->d_accum);
 	SSX_HIP(ctx, hipGetLastError());
@@ -403,6 +409,33 @@ int launch_pipelined(ssx_ctx* ctx, LaunchPlan& pl, uint32_t spp, uint32_t batch,
 		SSX_HIP(ctx, hipEventRecord(ctx->ev_back[h], ctx->aux_stream));
 	}
 	if (n) SSX_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_back[(n - 1) & 1u], 0)); // aux is serial: the last back half ends last
+	return SSX_OK;
+}
+
+// Where the fold runs is a pure performance choice (same arithmetic, same bits): inside the path
+// kernel its loads hide under other waves' arithmetic (Cornell: 49.4 against 52.6 ms), but its own
+// arithmetic adds to a VALU-bound kernel, which loses when paths are so short that the fold is a
+// large share of the work (plane-srgb: one frame per sample, 5.0 against 5.5 Gsamples/s).  A
+// 64x64x4-sample render of the scene at upload time counts the frames per sample and decides.
+int calibrate(ssx_ctx* ctx) {
+	ssx_render_params cp{};
+	cp.struct_size = sizeof cp; cp.width = 64; cp.height = 64; cp.spp = 4; cp.tile_stride = 1;
+	ctx->fuse_resolve = false; // records keep {radiance, lambda_0, hit, #frames}
+	LaunchPlan pl = make_plan(ctx, &cp);
+	int rc = ensure_samples(ctx, pl, cp.spp);
+	if (rc) return rc;
+	Batch b = make_batch(ctx, pl, 0, cp.spp, 0);
+	const int timing = ctx->timing; ctx->timing = 0;
+	rc = enqueue_front(ctx, pl, b, ctx->stream);
+	ctx->timing = timing;
+	if (rc) return rc;
+	SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	std::vector<SsxSampleRecord> recs((size_t)b.n_rec);
+	SSX_HIP(ctx, hipMemcpy(recs.data(), ctx->d_samples, recs.size() * sizeof(SsxSampleRecord), hipMemcpyDeviceToHost));
+	uint64_t frames = 0;
+	for (const SsxSampleRecord& r : recs) frames += r.b.z;
+	ctx->calib_frames = (float)((double)frames / (double)recs.size());
+	ctx->fuse_resolve = ctx->calib_frames >= 2.0f;
 	return SSX_OK;
 }
 
@@ -568,7 +601,7 @@ int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 	SSX_HIP(ctx, hipMemcpy(ctx->d_blob, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
 	ctx->blob_words = (uint32_t)blob.size();
 	ctx->have_scene = true;
-	return SSX_OK;
+	return calibrate(ctx);
 }
 
 int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out, void* hip_stream) {
@@ -665,6 +698,14 @@ int ssx_cand_stats(unsigned long long out[4], int reset) {
 	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cand_stats), 4 * sizeof(unsigned long long));
 }
 #endif
+
+int ssx_plan_info(ssx_ctx* ctx, float* frames_per_sample, int* fold_in_path_kernel) {
+	if (!ctx) return SSX_ERR_ARG;
+	if (!ctx->have_scene) return fail(ctx, SSX_ERR_STATE, "no scene uploaded");
+	if (frames_per_sample) *frames_per_sample = ctx->calib_frames;
+	if (fold_in_path_kernel) *fold_in_path_kernel = ctx->fuse_resolve ? 1 : 0;
+	return SSX_OK;
+}
 
 int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* scratch_bytes, int* max_blocks_per_cu) {
 	if (!ctx) return SSX_ERR_ARG;

@@ -93,5 +93,5 @@ struct SsxKernelArgs {
 	uint64_t n_records;       // my_tiles * (k1-k0) * 64
 	uint64_t* prof;           // region-timing builds only (NULL otherwise)
 	uint32_t rgb_mode;        // 1: RENDER_MODE_RGB (scene uplift == SSX_MODE_RGB): no wavelength draw, no XYZ, plain mean
-	uint32_t pad_;
+	uint32_t fuse_resolve;    // 1: the path kernel folds each unit's samples itself; 0: ssx_resolve_kernel does
 };

@@ -863,12 +863,13 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 // Four records of the lane (consecutive k of its pixel) are folded side by side so that the frame
 // loads of a level are four independent requests instead of a chain of dependent round trips.
 #define SSX_RESOLVE_WAYS 4u
+template <uint32_t WAYS>
 __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count) {
-	float rad[SSX_RESOLVE_WAYS][4];
-	uint32_t depth[SSX_RESOLVE_WAYS], lam[SSX_RESOLVE_WAYS], hitf[SSX_RESOLVE_WAYS];
+	float rad[WAYS][4];
+	uint32_t depth[WAYS], lam[WAYS], hitf[WAYS];
 	uint32_t top = 0;
 #pragma unroll
-	for (uint32_t s = 0; s < SSX_RESOLVE_WAYS; ++s) {
+	for (uint32_t s = 0; s < WAYS; ++s) {
 		depth[s] = 0; lam[s] = 0; hitf[s] = 0;
 		rad[s][0] = rad[s][1] = rad[s][2] = rad[s][3] = 0.0f;
 		if (s < count) {
@@ -879,12 +880,12 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 		top = max(top, depth[s]);
 	}
 	for (uint32_t d = top; d-- > 0u;) {
-		SsxFrame F[SSX_RESOLVE_WAYS];
+		SsxFrame F[WAYS];
 #pragma unroll
-		for (uint32_t s = 0; s < SSX_RESOLVE_WAYS; ++s)
+		for (uint32_t s = 0; s < WAYS; ++s)
 			if (d < depth[s]) F[s] = a.frames[d * (uint32_t)a.n_records + r0 + s * stride];
 #pragma unroll
-		for (uint32_t s = 0; s < SSX_RESOLVE_WAYS; ++s)
+		for (uint32_t s = 0; s < WAYS; ++s)
 			if (d < depth[s]) {
 				rad[s][0] = F[s].direct.x + ((rad[s][0] * F[s].np.x) * F[s].f_s.x) / F[s].np.y;
 				rad[s][1] = F[s].direct.y + ((rad[s][1] * F[s].np.x) * F[s].f_s.y) / F[s].np.y;
@@ -893,7 +894,7 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 			}
 	}
 #pragma unroll
-	for (uint32_t s = 0; s < SSX_RESOLVE_WAYS; ++s)
+	for (uint32_t s = 0; s < WAYS; ++s)
 		if (s < count) {
 			Hero flux; flux.v[0] = rad[s][0]; flux.v[1] = rad[s][1]; flux.v[2] = rad[s][2]; flux.v[3] = rad[s][3];
 			float xyz[3];
@@ -934,7 +935,8 @@ extern "C" __global__ void __launch_bounds__(256) ssx_generate_kernel(SsxKernelA
 // Cornell paths end after one interaction, 24 % run all nine).  The recursion L() of the
 // reference is evaluated as a forward pass here (each level's direct light and continuation
 // factors go to the frame buffer) and a backward fold over them when the wave has finished its unit.
-extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArgs a) {
+// 3 waves per SIMD (168 VGPRs): the register allocator otherwise settles one register above that
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) ssx_render_kernel(SsxKernelArgs a) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t lds_blob[];
 	for (uint32_t w = threadIdx.x; w < a.blob_words; w += blockDim.x) lds_blob[w] = a.blob[w];
 	__syncthreads();
@@ -1010,13 +1012,15 @@ extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArg
 	// Resolve this unit's samples: every lane folds the records of its own pixel.  The loads of this
 	// tail (frames and records this wave wrote during the unit) overlap with the arithmetic of the other
 	// waves on the SIMD, which a separate HBM-bound pass after the kernel could not.
-	__threadfence(); // the records were written by whichever lane ran the sample
-	{
+	// (For scenes with very short paths -- plane-srgb: one frame per sample -- the fold is a large share
+	// of the arithmetic and the separate streaming kernel is faster; the host picks, see ssx_api.hip.)
+	if (a.fuse_resolve) {
+		__threadfence(); // the records were written by whichever lane ran the sample
 		const uint32_t lane = threadIdx.x & 63u;
 		const bool in_image = (lane & 7u) < tw && (lane >> 3) < th;
 		if (in_image)
 			for (uint32_t kq = 0; kq < kb - ka; kq += SSX_RESOLVE_WAYS)
-				resolve_records(L, a, rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, kb - ka - kq));
+				resolve_records<SSX_RESOLVE_WAYS>(L, a, rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, kb - ka - kq));
 	}
 #ifdef SSX_PROFILE_REGIONS
 	if ((threadIdx.x & 63u) == 0u && a.prof) {
@@ -1026,6 +1030,26 @@ extern "C" __global__ void __launch_bounds__(256) ssx_render_kernel(SsxKernelArg
 		atomicAdd((unsigned long long*)&a.prof[SSX_NREG - 1], (unsigned long long)prof_lanes);
 	}
 #endif
+}
+
+// The fold as a pass of its own (one lane per sample, persistent blocks, streaming reads), used
+// instead of the path kernel's tail when SsxKernelArgs::fuse_resolve is 0.
+extern "C" __global__ void __launch_bounds__(256) ssx_resolve_kernel(SsxKernelArgs a) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds_blob[];
+	for (uint32_t w = threadIdx.x; w < a.blob_words; w += blockDim.x) lds_blob[w] = a.blob[w];
+	__syncthreads();
+	Lds L; L.w = lds_blob;
+	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_records; r += (uint64_t)gridDim.x * blockDim.x) {
+		if (a.width % 8u != 0u || a.height % 8u != 0u) { // records of lanes outside a ragged image were never generated
+			const uint32_t lane = (uint32_t)(r & 63u);
+			const uint32_t n_k = a.k1 - a.k0;
+			const uint32_t slot = (uint32_t)((r >> 6) / n_k);
+			const uint32_t tile = a.tile_first + slot * a.tile_stride;
+			const uint32_t i = (tile % a.tiles_x) * 8u + (lane & 7u), j = (tile / a.tiles_x) * 8u + (lane >> 3);
+			if (i >= a.width || j >= a.height) continue;
+		}
+		resolve_records<1u>(L, a, (uint32_t)r, 0u, 1u);
+	}
 }
 
 // Stage 3 of 3: one lane per pixel.  renderer.cpp:292-295: avg += sample*0.001f (float multiply,

@@ -214,6 +214,12 @@ class Renderer:
         self._check(self._lib.ssx_kernel_info(self._ctx, *[C.byref(x) for x in v]))
         return dict(zip(("vgprs", "sgprs", "lds_bytes", "scratch_bytes", "max_blocks_per_cu"), [x.value for x in v]))
 
+    def plan_info(self):
+        """What the calibration render at scene upload found: frames per sample, and where the fold runs."""
+        f, k = C.c_float(), C.c_int()
+        self._check(self._lib.ssx_plan_info(self._ctx, C.byref(f), C.byref(k)))
+        return {"frames_per_sample": round(f.value, 3), "fold": "path kernel" if k.value else "resolve kernel"}
+
     def save(self, path):
         fb = np.ascontiguousarray(self.framebuffer, dtype=np.float32)
         rc = _capi.host_lib().ssh_save_image(path.encode(), fb.ctypes.data, fb.shape[1], fb.shape[0])

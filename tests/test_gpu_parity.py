@@ -303,3 +303,16 @@ def test_rgb_render_mode_bit_exact(scene, texture, W, H, spp, io, els):
     if scene != "plane-srgb" or els:
         spectral = ol.Oracle(scene, **kw).render(W, H, spp, seed=6, indirect_only=io, els=els)
         assert not np.array_equal(bits(spectral), bits(ref))
+
+
+def test_fold_placement_is_calibrated_and_does_not_change_the_image():
+    """ssx_upload_scene renders 64x64x4 samples of the scene to count frames per sample and puts the
+    fold of the recursion inside the path kernel (long paths) or in its own kernel (short paths).
+    Both are covered bit-exactly by the parity tests above (Cornell scenes: path kernel; plane-srgb:
+    resolve kernel); here the choice itself."""
+    r = Renderer(Options(scene_name="cornell-srgb", res=(16, 16), spp=1, texture="test-img.png"))
+    info = r.plan_info()
+    assert info["fold"] == "path kernel" and 3.0 < info["frames_per_sample"] < 4.5      # interactions per sample - 1
+    r = Renderer(Options(scene_name="plane-srgb", res=(16, 16), spp=1, texture="test-img.png"))
+    info = r.plan_info()
+    assert info["fold"] == "resolve kernel" and 0.8 < info["frames_per_sample"] <= 1.0   # S = 2 where the plane is hit: one continued level
