@@ -135,6 +135,8 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	}
 	{
 		const ssx_spectrum &r = s->spectra[s->spec_basis_r], &g = s->spectra[s->spec_basis_g], &b = s->spectra[s->spec_basis_b];
+		const ssx_spectrum &ox = s->spectra[s->spec_xbar], &oy = s->spectra[s->spec_ybar], &oz = s->spectra[s->spec_zbar];
+		h.observer_one_grid = (ox.n == oy.n && ox.n == oz.n && ox.low == oy.low && ox.low == oz.low && ox.delta_recip == oy.delta_recip && ox.delta_recip == oz.delta_recip) ? 1u : 0u;
 		h.basis_one_grid = (r.n == g.n && r.n == b.n && r.low == g.low && r.low == b.low && r.delta_recip == g.delta_recip && r.delta_recip == b.delta_recip) ? 1u : 0u;
 	}
 

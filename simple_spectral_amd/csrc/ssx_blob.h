@@ -53,7 +53,8 @@ struct SsxBlobHeader {
 	// Jakob-Hanika uplift (uplift == 3): scale[jh_res] in the blob, coefficient table in HBM
 	uint32_t uplift, jh_res, off_jh_scale, jh_data_lo, jh_data_hi;
 	float pass1_tol;  // tolerance of the conservative edge-function filter: 1024 * 2^-24 * R^2
-	uint32_t pad[2];
+	uint32_t observer_one_grid; // the three observer tables share (low, delta_recip, n)
+	uint32_t pad[1];
 };
 static_assert(sizeof(SsxBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 

@@ -359,9 +359,12 @@ __device__ __forceinline__ Hero material_albedo(const Lds& L, const SsxBlobQuad&
 __device__ __forceinline__ void flux_to_xyz(const Lds& L, const Hero& flux, float lambda_0, float out[3]) {
 	const SsxBlobHeader& h = L.hdr();
 	const uint32_t ids[3] = { h.spec_xbar, h.spec_ybar, h.spec_zbar };
+	const SsxBlobSpectrum sx = L.spectrum(ids[0]);
+	const HeroIndex shared = hero_index(sx, lambda_0, h.lambda_step); // the CIE tables share one grid (wave-uniform flag)
 #pragma unroll
 	for (int ch = 0; ch < 3; ++ch) {
-		Hero bar = spectrum_hero(L, ids[ch], lambda_0, h.lambda_step);
+		const SsxBlobSpectrum sp = L.spectrum(ids[ch]);
+		Hero bar = h.observer_one_grid ? hero_gather(L, sp.offset, shared) : spectrum_hero(L, sp, lambda_0, h.lambda_step);
 		float acc = 0.0f;
 #pragma unroll
 		for (int i = 0; i < 4; ++i) acc += (bar.v[i] * flux.v[i]) * h.lambda_step;
