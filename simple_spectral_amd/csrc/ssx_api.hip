@@ -333,7 +333,7 @@ Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1, u
 	return b;
 }
 
-int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stream) {
+int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stream, bool calibration = false) {
 #ifdef SSX_PROFILE_REGIONS
 	{
 		static uint64_t* d_prof = nullptr;
@@ -346,7 +346,7 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	hipLaunchKernelGGL(ssx_generate_kernel, dim3((uint32_t)((b.n_rec + 255u) / 256u)), dim3(256), 0, stream, b.a);
 	SSX_HIP(ctx, hipGetLastError());
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[1], stream));
-	hipLaunchKernelGGL(ssx_render_kernel, dim3((b.units + 3u) / 4u), dim3(256), pl.lds_bytes, stream, b.a);
+	hipLaunchKernelGGL(calibration ? ssx_calibrate_kernel : ssx_render_kernel, dim3((b.units + 3u) / 4u), dim3(256), pl.lds_bytes, stream, b.a);
 	SSX_HIP(ctx, hipGetLastError());
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[2], stream));
 	return SSX_OK;
@@ -428,7 +428,7 @@ int calibrate(ssx_ctx* ctx) {
 	if (rc) return rc;
 	Batch b = make_batch(ctx, pl, 0, cp.spp, 0);
 	const int timing = ctx->timing; ctx->timing = 0;
-	rc = enqueue_front(ctx, pl, b, ctx->stream);
+	rc = enqueue_front(ctx, pl, b, ctx->stream, true);
 	ctx->timing = timing;
 	if (rc) return rc;
 	SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
