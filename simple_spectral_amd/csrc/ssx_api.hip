@@ -351,7 +351,7 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	hipLaunchKernelGGL(ssx_generate_kernel, dim3((uint32_t)((b.n_rec + 255u) / 256u)), dim3(256), 0, stream, b.a);
 	SSX_HIP(ctx, hipGetLastError());
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[1], stream));
-	hipLaunchKernelGGL(calibration ? ssx_calibrate_kernel : ssx_render_kernel, dim3((b.units + 3u) / 4u), dim3(256), pl.lds_bytes, stream, b.a);
+	hipLaunchKernelGGL(calibration ? ssx_calibrate_kernel : ssx_render_kernel, dim3((b.units + 3u) / 4u), dim3(256), pl.lds_bytes + 4u * SSX_WAVE_SCRATCH_WORDS * 4u, stream, b.a);
 	SSX_HIP(ctx, hipGetLastError());
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[2], stream));
 	return SSX_OK;
@@ -721,7 +721,7 @@ int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* s
 	SSX_HIP(ctx, hipFuncGetAttributes(&at, (const void*)ssx_render_kernel));
 	if (vgprs) *vgprs = at.numRegs;
 	if (sgprs) *sgprs = 0;
-	if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes + (int)ctx->blob_words * 4;
+	if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes + (int)ctx->blob_words * 4 + (int)(4u * SSX_WAVE_SCRATCH_WORDS * 4u); // path kernel: blob + 4 waves' shadow-ray queues
 	if (scratch_bytes) *scratch_bytes = (int)at.localSizeBytes;
 	if (max_blocks_per_cu) {
 		int nb = 0;

@@ -7,7 +7,11 @@
 #include <stdint.h>
 #include <hip/hip_runtime.h>
 
-#define SSX_BLOB_MAX_BYTES (48u * 1024u)
+#define SSX_BLOB_MAX_BYTES (40u * 1024u)
+// per-wave LDS scratch of the path kernel: the queue of parked shadow rays (ShadowQ in ssx_kernels.hip),
+// 128 entries x 12 words = 6 KB; a 256-lane workgroup takes blob + 24 KB, so three fit a CU's 160 KB for
+// blobs up to 29 KB
+#define SSX_WAVE_SCRATCH_WORDS (128u * 12u)
 
 // Permuted vertex table: for quad q and axis permutation p (0..5) the 12 floats
 //   v00[kx] v00[ky]  v10[kx] v10[ky]  v11[kx] v11[ky]  v01[kx] v01[ky] | v00[kz] v10[kz] v11[kz] v01[kz]

@@ -729,11 +729,33 @@ __device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const Ss
 	rec.b = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), (uint32_t)rng.inc, (uint32_t)(rng.inc >> 32));
 }
 
+// Deferred shadow rays.  Only about half of the lanes that shade a hit have a shadow ray
+// (n.l > 0), and a trace costs a wave the same whether 32 or 64 of its lanes hold a ray.  So the
+// shadow ray of an interaction is not traced on the spot: the lane parks it -- origin, direction,
+// quad to ignore, light, and the contribution ((emitted*n_dot_l)*f_s)/pdf it adds if the light
+// is visible (renderer.cpp:216) -- in a per-wave LDS queue, and whenever 64 have gathered the
+// wave traces them with every lane busy (any lane takes any entry) and adds the contributions of
+// the visible ones to where that level's direct light lives by then: the level's frame, or the
+// sample's record if the path ended there.  `direct` + contribution is one float addition either
+// way, with the same operands as `direct += ...` in place, so the bits do not change; the RNG
+// stream is untouched (the shadow test draws nothing).
+//   entry = 3 x float4: {orig.xyz, dir.x} {dir.y, dir.z, c0, c1} {c2, c3, light<<8|ignore, target}
+//   target: frame index depth*n_records+record, or 0x80000000|record for the record's radiance
+#define SSX_SQ_CAPACITY 128u // < 64 left over + 64 new per iteration
+struct ShadowQ {
+	float4* e;
+	uint32_t count; // wave-uniform
+};
+#define SSX_SQ_NONE 0xFFFFFFFFu
+__device__ __forceinline__ void sq_set_target(const ShadowQ& q, uint32_t slot, uint32_t target) {
+	if (slot != SSX_SQ_NONE) reinterpret_cast<uint32_t*>(q.e + 3u * slot + 2u)[3] = target;
+}
+
 // One level of the recursion L() (renderer.cpp:147-255) for the lane's current ray: closest hit,
 // emission (camera ray only), next-event estimation with its shadow ray, BSDF sample.  Returns
 // true when the path continues (a Frame was pushed and p holds the next ray); otherwise `rad`
 // holds the radiance of this deepest level.
-__device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, Path& p, float rad[4] SSX_PROF_ARGS) {
+__device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const SsxKernelArgs& a, Path& p, float rad[4], bool& pushed SSX_PROF_ARGS) {
 	const SsxBlobHeader& h = L.hdr();
 	HitInfo hit;
 	trace(L, p.orig, p.dir, p.ignore, hit);
@@ -781,7 +803,8 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 	for (int k = 0; k < 4; ++k) f_lamb[k] = alb.v[k] / SSX_PI_F;
 	SSX_MARK(2);
 
-	// direct lighting (:182-219)
+	// direct lighting (:182-219): sample the light; the shadow ray is parked (see ShadowQ)
+	uint32_t sq_slot = SSX_SQ_NONE;
 #ifndef SSX_ABL_NONEE
 	if (els && (!a.indirect_only || p.depth > 0u)) {
 		V3 sdir; uint32_t light; float spdf;
@@ -789,21 +812,21 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 		float n_dot_l = dot3(sdir, N);
 		SSX_MARK(3);
 		if (n_dot_l > 0.0f) {
-			HitInfo sh;
-#ifdef SSX_ABL_NOSHADOW
-			sh.tri = (int)(light * 2u);
-#else
-			trace(L, hit_pos, sdir, (int)hq, sh);
-#endif
-			SSX_MARK(4);
-			if (sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == light) {
-				Hero emitted = spectrum_hero(L, L.quad(light).emission, p.lambda_0, h.lambda_step);
+			Hero emitted = spectrum_hero(L, L.quad(light).emission, p.lambda_0, h.lambda_step);
+			float c[4];
 #pragma unroll
-				for (int k = 0; k < 4; ++k) {
-					float fs = (M.kind == 0u) ? f_lamb[k] : 0.0f; // Mirror::evaluate_bsdf -> 0
-					direct[k] += ((emitted.v[k] * n_dot_l) * fs) / spdf;
-				}
+			for (int k = 0; k < 4; ++k) {
+				float fs = (M.kind == 0u) ? f_lamb[k] : 0.0f; // Mirror::evaluate_bsdf -> 0
+				c[k] = ((emitted.v[k] * n_dot_l) * fs) / spdf;
 			}
+			const uint64_t pushing = __ballot(1);
+			sq_slot = q.count + __builtin_amdgcn_mbcnt_hi((uint32_t)(pushing >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushing, 0u));
+			float4* E = q.e + 3u * sq_slot;
+			E[0] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, sdir.x);
+			E[1] = make_float4(sdir.y, sdir.z, c[0], c[1]);
+			E[2] = make_float4(c[2], c[3], __uint_as_float((light << 8) | hq), 0.0f);
+			pushed = true;
+			SSX_MARK(4);
 		}
 	}
 #endif
@@ -839,6 +862,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 	if (!cont || (els && p.depth + 2u >= SSX_MAX_DEPTH_)) {
 #pragma unroll
 		for (int k = 0; k < 4; ++k) rad[k] = direct[k];
+		sq_set_target(q, sq_slot, 0x80000000u | p.rec_index); // this level's direct light ends up in the record
 		return false;
 	}
 	// record this level for the backward fold (resolve_records, at the end of the wave's unit): [depth][record] so that
@@ -853,10 +877,38 @@ __device__ __forceinline__ bool path_step(const Lds& L, const SsxKernelArgs& a, 
 #else
 	if (n_dot_l == 123.456f) a.frames[p.rec_index].np = make_float2(direct[0] + f_s[1], pdf_w_i);
 #endif
+	sq_set_target(q, sq_slot, p.depth * (uint32_t)a.n_records + p.rec_index); // ... or in the frame just written
 	p.orig = hit_pos; p.dir = w_i; p.ignore = (int)hq;
 	++p.depth;
 	SSX_MARK(7);
 	return true;
+}
+
+// Traces the parked shadow rays [first, first+n), n <= 64, one per lane, and adds the contribution
+// of every visible one to its target.  Called in uniform control flow.
+__device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& a, const ShadowQ& q, uint32_t first, uint32_t n) {
+	const uint32_t lane = threadIdx.x & 63u;
+	// The targets were written by whichever lane ran that sample, earlier in this wave's own
+	// instruction stream: a workgroup-scope fence (no cache maintenance, unlike __threadfence) orders the
+	// compiler and waits for those stores; the loads below bypass the CU's L1 (agent-scope atomics),
+	// which may still hold a record line from before the sample's last store.
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+	if (lane < n) {
+		const float4* E = q.e + 3u * (first + lane);
+		const float4 e0 = E[0], e1 = E[1], e2 = E[2];
+		const uint32_t tag = __float_as_uint(e2.z), target = __float_as_uint(e2.w);
+		float4* dst = (target & 0x80000000u) ? &a.samples[target & 0x7FFFFFFFu].a : &a.frames[target].direct;
+		float* d = reinterpret_cast<float*>(dst);
+		float4 old; // in flight during the trace
+		old.x = __hip_atomic_load(d + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		old.y = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		old.z = __hip_atomic_load(d + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		old.w = __hip_atomic_load(d + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		HitInfo sh;
+		trace(L, mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y), (int)(tag & 0xFFu), sh);
+		if (sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == (tag >> 8))
+			*dst = make_float4(old.x + e1.z, old.y + e1.w, old.z + e2.x, old.w + e2.y);
+	}
 }
 
 // Backward fold of the recursion for finished samples (renderer.cpp:247: radiance += L(next) *
@@ -963,6 +1015,9 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	Path p;
 	bool active = false;
 	uint32_t next_item = 0; // wave-uniform
+	ShadowQ sq; // this wave's queue behind the blob (16-byte aligned: blob_words is a multiple of 4)
+	sq.e = reinterpret_cast<float4*>(lds_words + a.blob_words + wave * SSX_WAVE_SCRATCH_WORDS);
+	sq.count = 0;
 #ifdef SSX_PROFILE_REGIONS
 	uint64_t prof_t[SSX_NREG] = {};
 	uint64_t prof_last = __builtin_readcyclecounter();
@@ -997,9 +1052,10 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 #ifdef SSX_PROFILE_REGIONS
 		prof_iters += 1; prof_lanes += (uint64_t)__popcll(__ballot(active));
 #endif
+		bool pushed = false;
 		if (active) {
 			float rad[4];
-			if (!path_step(L, a, p, rad SSX_PROF_PASS)) {
+			if (!path_step(L, sq, a, p, rad, pushed SSX_PROF_PASS)) {
 				// deepest level reached: its radiance, the number of recorded frames, lambda_0 and the
 				// hit flag replace the sample's record; the fold happens at the end of the unit
 				SsxSampleRecord out;
@@ -1009,8 +1065,14 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 				active = false;
 			}
 		}
+		sq.count += (uint32_t)__popcll(__ballot(pushed));
+		if (sq.count >= 64u) { // a full wave of shadow rays
+			sq.count -= 64u;
+			shadow_flush(L, a, sq, sq.count, 64u);
+		}
 		SSX_MARK(8);
 	}
+	if (sq.count) shadow_flush(L, a, sq, 0u, sq.count); // the rest, before the fold reads the records and frames
 	// Resolve this unit's samples: every lane folds the records of its own pixel.  The loads of this
 	// tail (frames and records this wave wrote during the unit) overlap with the arithmetic of the other
 	// waves on the SIMD, which a separate HBM-bound pass after the kernel could not.
