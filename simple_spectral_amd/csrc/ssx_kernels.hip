@@ -1079,7 +1079,11 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	// (For scenes with very short paths -- plane-srgb: one frame per sample -- the fold is a large share
 	// of the arithmetic and the separate streaming kernel is faster; the host picks, see ssx_api.hip.)
 	if (a.fuse_resolve) {
-		__threadfence(); // the records were written by whichever lane ran the sample
+		// the records and frames were written by whichever lane ran the sample, in this wave's own
+		// instruction stream: wait for those stores, then drop the CU's L1 lines (a record line may date
+		// from before its last store); no L2 write-back is needed, nobody else reads this unit's data
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 		const uint32_t lane = threadIdx.x & 63u;
 		const bool in_image = (lane & 7u) < tw && (lane >> 3) < th;
 		if (in_image)
