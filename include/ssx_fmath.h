@@ -20,7 +20,9 @@
 #ifndef SSX_FMATH_H
 #define SSX_FMATH_H
 
-#if defined(__HIPCC__) || defined(__HIP__)
+#if defined(SSX_FM_TABLE)
+#define SSX_FM_FN static __device__ __forceinline__   /* the table lives in LDS: device code only */
+#elif defined(__HIPCC__) || defined(__HIP__)
 #define SSX_FM_FN static __host__ __device__ __forceinline__
 #else
 #define SSX_FM_FN static inline
@@ -33,13 +35,71 @@
  * correctly rounded software fma() of libm on the host. */
 #define SSX_FMA(a, b, c) __builtin_fma((a), (b), (c))
 
+/* The coefficients, once.  On the host (and in the CPU oracle) SSX_FM_C(name) is the literal.  A
+ * HIP kernel may define SSX_FM_TABLE to an array of doubles in LDS that it filled from
+ * SSX_FM_COEFF_INIT (same order): the register allocator otherwise hoists these loop-invariant
+ * 64-bit constants into ~20 VGPRs for the whole kernel. */
+#define SSX_FM_LIST(X) \
+	X(INV_PIO2, 0x1.45f306dc9c883p-1) \
+	X(PIO2_1, 0x1.921fb54400000p+0) \
+	X(PIO2_1T, 0x1.0b4611a626331p-34) \
+	X(SHIFTER, 0x1.8p52) \
+	X(S8, 0x1.952c77030ad4ap-49) \
+	X(S7, -0x1.ae7f3e733b81fp-41) \
+	X(S6, 0x1.6124613a86d09p-33) \
+	X(S5, -0x1.ae64567f544e4p-26) \
+	X(S4, 0x1.71de3a556c734p-19) \
+	X(S3, -0x1.a01a01a01a01ap-13) \
+	X(S2, 0x1.1111111111111p-7) \
+	X(S1, -0x1.5555555555555p-3) \
+	X(C9, -0x1.6827863b97d97p-53) \
+	X(C8, 0x1.ae7f3e733b81fp-45) \
+	X(C7, -0x1.93974a8c07c9dp-37) \
+	X(C6, 0x1.1eed8eff8d898p-29) \
+	X(C5, -0x1.27e4fb7789f5cp-22) \
+	X(C4, 0x1.a01a01a01a01ap-16) \
+	X(C3, -0x1.6c16c16c16c17p-10) \
+	X(C2, 0x1.5555555555555p-5) \
+	X(A11, 0x1.cd864394d2ff2p-6) \
+	X(A10, -0x1.603991d6060e0p-7) \
+	X(A9, 0x1.06b9d26d10838p-6) \
+	X(A8, 0x1.ff5fc4d14c735p-8) \
+	X(A7, 0x1.8522ddffa6208p-7) \
+	X(A6, 0x1.c87265d47ef49p-7) \
+	X(A5, 0x1.1c593c7b1d958p-6) \
+	X(A4, 0x1.6e8b2b3b10be4p-6) \
+	X(A3, 0x1.f1c71f95269afp-6) \
+	X(A2, 0x1.6db6db684b6a1p-5) \
+	X(A1, 0x1.3333333336da5p-4) \
+	X(A0, 0x1.555555555554fp-3) \
+	X(PIO2_HI, 0x1.921fb54442d18p+0) \
+	X(PIO2_LO, 0x1.1a62633145c07p-54) \
+	X(PI_HI, 0x1.921fb54442d18p+1) \
+	X(PI_LO, 0x1.1a62633145c07p-53)
+enum {
+#define SSX_FM_ENUM(name, lit) SSX_FM_I_##name,
+	SSX_FM_LIST(SSX_FM_ENUM)
+#undef SSX_FM_ENUM
+	SSX_FM_N_COEFF
+};
+#define SSX_FM_VALUE(name, lit) lit,
+#define SSX_FM_COEFF_INIT { SSX_FM_LIST(SSX_FM_VALUE) }
+#ifdef SSX_FM_TABLE
+#define SSX_FM_C(name) (SSX_FM_TABLE[SSX_FM_I_##name])
+#else
+#define SSX_FM_LITERAL(name, lit) static const double ssx_fm_lit_##name = lit;
+SSX_FM_LIST(SSX_FM_LITERAL)
+#undef SSX_FM_LITERAL
+#define SSX_FM_C(name) (ssx_fm_lit_##name)
+#endif
+
 /* Cody-Waite reduction by pi/2: n = rint(x*2/pi), r = (x - n*P1) - n*P1T.
  * P1 holds the leading 33 bits of pi/2, so n*P1 is exact for |n| <= 2^20. */
 SSX_FM_FN int ssx_fm_reduce(double x, double* r_out) {
-	const double inv_pio2 = 0x1.45f306dc9c883p-1;  /* 2/pi */
-	const double pio2_1   = 0x1.921fb54400000p+0;  /* leading 33 bits of pi/2 */
-	const double pio2_1t  = 0x1.0b4611a626331p-34; /* pi/2 - pio2_1 */
-	const double shifter  = 0x1.8p52;               /* 1.5*2^52: adds then removes -> rint */
+	const double inv_pio2 = SSX_FM_C(INV_PIO2);  /* 2/pi */
+	const double pio2_1   = SSX_FM_C(PIO2_1);  /* leading 33 bits of pi/2 */
+	const double pio2_1t  = SSX_FM_C(PIO2_1T); /* pi/2 - pio2_1 */
+	const double shifter  = SSX_FM_C(SHIFTER);               /* 1.5*2^52: adds then removes -> rint */
 	double fn = (x * inv_pio2 + shifter) - shifter;
 	*r_out = (x - fn * pio2_1) - fn * pio2_1t;
 	return (int)fn;
@@ -49,14 +109,14 @@ SSX_FM_FN int ssx_fm_reduce(double x, double* r_out) {
  * first dropped term r^19/19! < 1e-19. */
 SSX_FM_FN double ssx_fm_ksin(double r) {
 	double z = r * r;
-	double p =      0x1.952c77030ad4ap-49;   /*  1/17! */
-	p = SSX_FMA(p, z, -0x1.ae7f3e733b81fp-41); /* -1/15! */
-	p = SSX_FMA(p, z,  0x1.6124613a86d09p-33); /*  1/13! */
-	p = SSX_FMA(p, z, -0x1.ae64567f544e4p-26); /* -1/11! */
-	p = SSX_FMA(p, z,  0x1.71de3a556c734p-19); /*  1/9!  */
-	p = SSX_FMA(p, z, -0x1.a01a01a01a01ap-13); /* -1/7!  */
-	p = SSX_FMA(p, z,  0x1.1111111111111p-7);  /*  1/5!  */
-	p = SSX_FMA(p, z, -0x1.5555555555555p-3);  /* -1/3!  */
+	double p =      SSX_FM_C(S8);   /*  1/17! */
+	p = SSX_FMA(p, z, SSX_FM_C(S7)); /* -1/15! */
+	p = SSX_FMA(p, z,  SSX_FM_C(S6)); /*  1/13! */
+	p = SSX_FMA(p, z, SSX_FM_C(S5)); /* -1/11! */
+	p = SSX_FMA(p, z,  SSX_FM_C(S4)); /*  1/9!  */
+	p = SSX_FMA(p, z, SSX_FM_C(S3)); /* -1/7!  */
+	p = SSX_FMA(p, z,  SSX_FM_C(S2));  /*  1/5!  */
+	p = SSX_FMA(p, z, SSX_FM_C(S1));  /* -1/3!  */
 	return SSX_FMA(r * z, p, r);
 }
 
@@ -64,14 +124,14 @@ SSX_FM_FN double ssx_fm_ksin(double r) {
  * first dropped term r^20/20! < 1e-20. */
 SSX_FM_FN double ssx_fm_kcos(double r) {
 	double z = r * r;
-	double p =     -0x1.6827863b97d97p-53;   /* -1/18! */
-	p = SSX_FMA(p, z,  0x1.ae7f3e733b81fp-45); /*  1/16! */
-	p = SSX_FMA(p, z, -0x1.93974a8c07c9dp-37); /* -1/14! */
-	p = SSX_FMA(p, z,  0x1.1eed8eff8d898p-29); /*  1/12! */
-	p = SSX_FMA(p, z, -0x1.27e4fb7789f5cp-22); /* -1/10! */
-	p = SSX_FMA(p, z,  0x1.a01a01a01a01ap-16); /*  1/8!  */
-	p = SSX_FMA(p, z, -0x1.6c16c16c16c17p-10); /* -1/6!  */
-	p = SSX_FMA(p, z,  0x1.5555555555555p-5);  /*  1/4!  */
+	double p =     SSX_FM_C(C9);   /* -1/18! */
+	p = SSX_FMA(p, z,  SSX_FM_C(C8)); /*  1/16! */
+	p = SSX_FMA(p, z, SSX_FM_C(C7)); /* -1/14! */
+	p = SSX_FMA(p, z,  SSX_FM_C(C6)); /*  1/12! */
+	p = SSX_FMA(p, z, SSX_FM_C(C5)); /* -1/10! */
+	p = SSX_FMA(p, z,  SSX_FM_C(C4)); /*  1/8!  */
+	p = SSX_FMA(p, z, SSX_FM_C(C3)); /* -1/6!  */
+	p = SSX_FMA(p, z,  SSX_FM_C(C2));  /*  1/4!  */
 	double hz = 0.5 * z;
 	/* (1 - hz) + z*z*p, with 1-hz exact-ish (hz <= 0.31) */
 	return SSX_FMA(z * z, p, 1.0 - hz);
@@ -121,24 +181,24 @@ SSX_FM_FN float ssx_cosf(float xf) {
 /* asin(s) = s + s*z*P(z), z = s*s in [0, 0.25]; P from tools/gen_fmath_coeffs.py (degree 11
  * Chebyshev fit, max abs error of P 2.3e-16 -> relative error of asin < 6e-17). */
 SSX_FM_FN double ssx_fm_asin_poly(double z) {
-	double p =      0x1.cd864394d2ff2p-6;
-	p = SSX_FMA(p, z, -0x1.603991d6060e0p-7);
-	p = SSX_FMA(p, z,  0x1.06b9d26d10838p-6);
-	p = SSX_FMA(p, z,  0x1.ff5fc4d14c735p-8);
-	p = SSX_FMA(p, z,  0x1.8522ddffa6208p-7);
-	p = SSX_FMA(p, z,  0x1.c87265d47ef49p-7);
-	p = SSX_FMA(p, z,  0x1.1c593c7b1d958p-6);
-	p = SSX_FMA(p, z,  0x1.6e8b2b3b10be4p-6);
-	p = SSX_FMA(p, z,  0x1.f1c71f95269afp-6);
-	p = SSX_FMA(p, z,  0x1.6db6db684b6a1p-5);
-	p = SSX_FMA(p, z,  0x1.3333333336da5p-4);
-	p = SSX_FMA(p, z,  0x1.555555555554fp-3);
+	double p =      SSX_FM_C(A11);
+	p = SSX_FMA(p, z, SSX_FM_C(A10));
+	p = SSX_FMA(p, z,  SSX_FM_C(A9));
+	p = SSX_FMA(p, z,  SSX_FM_C(A8));
+	p = SSX_FMA(p, z,  SSX_FM_C(A7));
+	p = SSX_FMA(p, z,  SSX_FM_C(A6));
+	p = SSX_FMA(p, z,  SSX_FM_C(A5));
+	p = SSX_FMA(p, z,  SSX_FM_C(A4));
+	p = SSX_FMA(p, z,  SSX_FM_C(A3));
+	p = SSX_FMA(p, z,  SSX_FM_C(A2));
+	p = SSX_FMA(p, z,  SSX_FM_C(A1));
+	p = SSX_FMA(p, z,  SSX_FM_C(A0));
 	return p;
 }
 
 SSX_FM_FN float ssx_acosf(float xf) {
-	const double pio2_hi = 0x1.921fb54442d18p+0, pio2_lo = 0x1.1a62633145c07p-54;
-	const double pi_hi   = 0x1.921fb54442d18p+1, pi_lo   = 0x1.1a62633145c07p-53;
+	const double pio2_hi = SSX_FM_C(PIO2_HI), pio2_lo = SSX_FM_C(PIO2_LO);
+	const double pi_hi   = SSX_FM_C(PI_HI), pi_lo   = SSX_FM_C(PI_LO);
 	double x = (double)xf;
 	double ax = x < 0.0 ? -x : x;
 	if (!(ax <= 1.0)) return SSX_FM_NAN;

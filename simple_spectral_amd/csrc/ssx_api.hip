@@ -41,6 +41,8 @@ struct ssx_ctx {
 	bool fuse_resolve = true;  // fold inside the path kernel (long paths) or as its own streaming kernel (short paths)
 	float calib_frames = 0.0f; // frames per sample measured by the calibration render of ssx_upload_scene
 	double* d_accum = nullptr;  size_t accum_pixels = 0;
+	uint32_t* d_unit_counter = nullptr; // work-unit counter of the path kernel's persistent waves
+	int resident_blocks = 0;            // 256-lane path-kernel workgroups the GPU holds at once
 	SsxSampleRecord* d_samples = nullptr; size_t sample_slots = 0; // record capacity of the sample buffer
 	SsxFrame* d_frames = nullptr;
 	float* d_out = nullptr;     size_t out_pixels = 0;
@@ -262,7 +264,7 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	a.rgb_mode = ctx->rgb_mode ? 1u : 0u;
 	a.fuse_resolve = ctx->fuse_resolve ? 1u : 0u;
 	a.my_tiles = a.n_tiles > p->tile_first ? (a.n_tiles - p->tile_first + p->tile_stride - 1u) / p->tile_stride : 0u;
-	pl.lds_bytes = (size_t)ctx->blob_words * 4;
+	pl.lds_bytes = ((size_t)ctx->blob_words + SSX_LDS_PREFIX_WORDS) * 4;
 	size_t per_spp = (size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u * kBytesPerSampleInFlight;
 	size_t cap = kSampleBufferBudget / per_spp;
 	pl.max_spp_per_launch = (uint32_t)(cap < 1 ? 1 : (cap > 65536 ? 65536 : cap));
@@ -351,7 +353,22 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	hipLaunchKernelGGL(ssx_generate_kernel, dim3((uint32_t)((b.n_rec + 255u) / 256u)), dim3(256), 0, stream, b.a);
 	SSX_HIP(ctx, hipGetLastError());
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[1], stream));
-	hipLaunchKernelGGL(calibration ? ssx_calibrate_kernel : ssx_render_kernel, dim3((b.units + 3u) / 4u), dim3(256), pl.lds_bytes + 4u * SSX_WAVE_SCRATCH_WORDS * 4u, stream, b.a);
+	// persistent waves: as many workgroups as the GPU holds at once (or fewer, for a small launch); they
+	// fetch work units from a counter
+	const size_t path_lds = pl.lds_bytes + 4u * SSX_WAVE_SCRATCH_WORDS * 4u;
+	if (!ctx->d_unit_counter) SSX_HIP(ctx, hipMalloc((void**)&ctx->d_unit_counter, sizeof(uint32_t)));
+	if (ctx->resident_blocks == 0) {
+		int per_cu = 0;
+		hipDeviceProp_t prop;
+		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ssx_render_kernel, 256, path_lds));
+		SSX_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+		ctx->resident_blocks = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
+	}
+	SSX_HIP(ctx, hipMemsetAsync(ctx->d_unit_counter, 0, sizeof(uint32_t), stream));
+	b.a.unit_counter = ctx->d_unit_counter;
+	const uint32_t want_blocks = (b.units + 3u) / 4u;
+	const uint32_t blocks = want_blocks < (uint32_t)ctx->resident_blocks ? want_blocks : (uint32_t)ctx->resident_blocks;
+	hipLaunchKernelGGL(calibration ? ssx_calibrate_kernel : ssx_render_kernel, dim3(blocks), dim3(256), path_lds, stream, b.a);
 	SSX_HIP(ctx, hipGetLastError());
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[2], stream));
 	return SSX_OK;
@@ -529,6 +546,7 @@ void ssx_destroy(ssx_ctx* ctx) {
 	if (ctx->d_jh_data) (void)hipFree(ctx->d_jh_data);
 	for (uint8_t* t : ctx->d_textures) (void)hipFree(t);
 	if (ctx->d_accum) (void)hipFree(ctx->d_accum);
+	if (ctx->d_unit_counter) (void)hipFree(ctx->d_unit_counter);
 	if (ctx->d_samples) (void)hipFree(ctx->d_samples);
 	if (ctx->d_frames) (void)hipFree(ctx->d_frames);
 	if (ctx->d_out) (void)hipFree(ctx->d_out);
@@ -607,6 +625,7 @@ int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 	SSX_HIP(ctx, hipMalloc((void**)&ctx->d_blob, blob.size() * 4));
 	SSX_HIP(ctx, hipMemcpy(ctx->d_blob, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
 	ctx->blob_words = (uint32_t)blob.size();
+	ctx->resident_blocks = 0; // depends on the blob's LDS footprint
 	ctx->have_scene = true;
 	return calibrate(ctx);
 }
@@ -721,11 +740,11 @@ int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* s
 	SSX_HIP(ctx, hipFuncGetAttributes(&at, (const void*)ssx_render_kernel));
 	if (vgprs) *vgprs = at.numRegs;
 	if (sgprs) *sgprs = 0;
-	if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes + (int)ctx->blob_words * 4 + (int)(4u * SSX_WAVE_SCRATCH_WORDS * 4u); // path kernel: blob + 4 waves' shadow-ray queues
+	if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes + (int)(ctx->blob_words + SSX_LDS_PREFIX_WORDS) * 4 + (int)(4u * SSX_WAVE_SCRATCH_WORDS * 4u); // path kernel: coefficients + blob + 4 waves' shadow-ray queues
 	if (scratch_bytes) *scratch_bytes = (int)at.localSizeBytes;
 	if (max_blocks_per_cu) {
 		int nb = 0;
-		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)ssx_render_kernel, 256, (size_t)ctx->blob_words * 4));
+		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)ssx_render_kernel, 256, ((size_t)ctx->blob_words + SSX_LDS_PREFIX_WORDS) * 4 + 4u * SSX_WAVE_SCRATCH_WORDS * 4u));
 		*max_blocks_per_cu = nb;
 	}
 	return SSX_OK;

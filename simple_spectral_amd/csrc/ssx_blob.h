@@ -12,6 +12,8 @@
 // 128 entries x 12 words = 6 KB; a 256-lane workgroup takes blob + 24 KB, so three fit a CU's 160 KB for
 // blobs up to 29 KB
 #define SSX_WAVE_SCRATCH_WORDS (128u * 12u)
+// dynamic LDS of the kernels that stage the blob: [coefficient table of ssx_fmath.h][blob][wave scratch]
+#define SSX_LDS_PREFIX_WORDS 80u
 
 // Permuted vertex table: for quad q and axis permutation p (0..5) the 12 floats
 //   v00[kx] v00[ky]  v10[kx] v10[ky]  v11[kx] v11[ky]  v01[kx] v01[ky] | v00[kz] v10[kz] v11[kz] v01[kz]
@@ -97,6 +99,7 @@ struct SsxKernelArgs {
 	SsxFrame* frames;         // [depth][record]
 	uint64_t n_records;       // my_tiles * (k1-k0) * 64
 	uint64_t* prof;           // region-timing builds only (NULL otherwise)
+	uint32_t* unit_counter;   // next work unit of the path kernel's persistent waves (zeroed before the launch)
 	uint32_t rgb_mode;        // 1: RENDER_MODE_RGB (scene uplift == SSX_MODE_RGB): no wavelength draw, no XYZ, plain mean
 	uint32_t fuse_resolve;    // 1: the path kernel folds each unit's samples itself; 0: ssx_resolve_kernel does
 };

@@ -20,8 +20,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/ssx_fmath.h"
 #include "ssx_blob.h"
+// The polynomial coefficients of ssx_fmath.h are read from LDS, filled at kernel start from the
+// header's own list: as literals the compiler hoists these loop-invariant 64-bit constants into ~20
+// VGPRs for the whole path kernel.  They sit at the start of the dynamic LDS area, in front of the
+// scene blob (same object as the buffers the kernels store to, so the loads stay where they are used).
+extern __shared__ __attribute__((aligned(16))) uint32_t ssx_lds[];
+#define SSX_FM_TABLE (reinterpret_cast<const double*>(ssx_lds))
+#include "../../include/ssx_fmath.h"
+__device__ const double ssx_fm_coeff_values[SSX_FM_N_COEFF] = SSX_FM_COEFF_INIT;
+static_assert(2 * SSX_FM_N_COEFF <= SSX_LDS_PREFIX_WORDS, "coefficient table");
+// stages the coefficient table and the scene blob; returns the blob's LDS address
+__device__ __forceinline__ uint32_t* stage_lds(const SsxKernelArgs& a) {
+	uint32_t* blob = ssx_lds + SSX_LDS_PREFIX_WORDS;
+	for (uint32_t w = threadIdx.x; w < a.blob_words; w += blockDim.x) blob[w] = a.blob[w];
+	if (threadIdx.x < (uint32_t)SSX_FM_N_COEFF) reinterpret_cast<double*>(ssx_lds)[threadIdx.x] = ssx_fm_coeff_values[threadIdx.x];
+	__syncthreads();
+	return blob;
+}
 
 // Timing-only ablations (tools/ablate.py builds separate libraries with these; results are wrong
 // by construction and such builds are never loaded by the package or the tests).
@@ -990,34 +1006,61 @@ extern "C" __global__ void __launch_bounds__(256) ssx_generate_kernel(SsxKernelA
 // Cornell paths end after one interaction, 24 % run all nine).  The recursion L() of the
 // reference is evaluated as a forward pass here (each level's direct light and continuation
 // factors go to the frame buffer) and a backward fold over them when the wave has finished its unit.
-__device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
-	extern __shared__ __attribute__((aligned(16))) uint32_t lds_words[];
-	for (uint32_t w = threadIdx.x; w < a.blob_words; w += blockDim.x) lds_words[w] = a.blob[w];
-	__syncthreads();
-	Lds L; L.w = lds_words;
-
-	const uint32_t wave = threadIdx.x >> 6;
-	const uint32_t unit = blockIdx.x * (blockDim.x >> 6) + wave;
-	if (unit >= a.my_tiles * a.n_groups) return;
+struct WorkUnit { // wave-uniform description of one work unit: 8x8 tile x a group of consecutive samples
+	uint32_t rec_base, n_kq, tw, th, npx, n_items;
+};
+__device__ __forceinline__ void unit_setup(const SsxKernelArgs& a, uint32_t unit, WorkUnit& u) {
 	const uint32_t slot = unit % a.my_tiles, grp = unit / a.my_tiles;
 	const uint32_t tile = a.tile_first + slot * a.tile_stride;
 	const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-	const uint32_t tw = min(8u, a.width - tx * 8u), th = min(8u, a.height - ty * 8u);
-	const uint32_t npx = tw * th;
+	u.tw = min(8u, a.width - tx * 8u); u.th = min(8u, a.height - ty * 8u);
+	u.npx = u.tw * u.th;
 	const uint32_t ka = a.k0 + grp * a.group_spp;
 	const uint32_t kb = min(ka + a.group_spp, a.k1);
-	const uint32_t n_items = npx * (kb - ka);
-	const uint32_t n_k = a.k1 - a.k0;
-	const uint32_t rec_base = (slot * n_k + (ka - a.k0)) * 64u;
+	u.n_kq = kb - ka;
+	u.n_items = u.npx * u.n_kq;
+	u.rec_base = (slot * (a.k1 - a.k0) + (ka - a.k0)) * 64u;
+}
+// Every lane folds the records of its own pixel of a finished unit.  The loads (frames and records
+// this wave wrote during the unit) overlap with the arithmetic of the other waves on the SIMD, which
+// a separate HBM-bound pass after the kernel could not.  (For scenes with very short paths --
+// plane-srgb: one frame per sample -- the fold is a large share of the arithmetic and the separate
+// streaming kernel is faster; the host picks, see ssx_api.hip.)
+__device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, const WorkUnit& u) {
+	// the records and frames were written by whichever lane ran the sample, in this wave's own
+	// instruction stream: wait for those stores, then drop the CU's L1 lines (a record line may date
+	// from before its last store); no L2 write-back is needed, nobody else reads this unit's data
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	const uint32_t lane = threadIdx.x & 63u;
+	if ((lane & 7u) < u.tw && (lane >> 3) < u.th)
+		for (uint32_t kq = 0; kq < u.n_kq; kq += SSX_RESOLVE_WAYS)
+			resolve_records<SSX_RESOLVE_WAYS>(L, a, u.rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, u.n_kq - kq));
+}
+
+__device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
+	uint32_t* const lds_words = stage_lds(a);
+	Lds L; L.w = lds_words;
+
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t total_units = a.my_tiles * a.n_groups;
 	const SsxBlobHeader& h = L.hdr();
 	const V3 cam = mk(h.cam_pos[0], h.cam_pos[1], h.cam_pos[2]);
 
 	Path p;
 	bool active = false;
-	uint32_t next_item = 0; // wave-uniform
+	uint32_t p_tag = 0; // which of the (at most two) units in flight the lane's sample belongs to
 	ShadowQ sq; // this wave's queue behind the blob (16-byte aligned: blob_words is a multiple of 4)
 	sq.e = reinterpret_cast<float4*>(lds_words + a.blob_words + wave * SSX_WAVE_SCRATCH_WORDS);
 	sq.count = 0;
+	// Persistent waves: units are fetched from a global counter, and the next unit's items are handed
+	// out as soon as the current one has none left -- its last paths finish alongside the new ones
+	// instead of on a draining wave (10 % of all wave iterations with one unit per wave).  `cur` feeds
+	// idle lanes; `old` is the previous unit, still waiting for its last lanes and then for its fold.
+	WorkUnit cur, old;
+	bool cur_valid = false, old_pending = false, more = true;
+	uint32_t cur_tag = 0, old_tag = 0;
+	uint32_t next_item = 0; // wave-uniform
 #ifdef SSX_PROFILE_REGIONS
 	uint64_t prof_t[SSX_NREG] = {};
 	uint64_t prof_last = __builtin_readcyclecounter();
@@ -1025,29 +1068,50 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	uint64_t prof_iters = 0, prof_lanes = 0;
 #endif
 	for (;;) {
-		// hand out items to idle lanes
-		const uint64_t idle = __ballot(!active);
-		if (!active) {
-			const uint32_t item = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-			if (item < n_items) {
-				uint32_t in_tile, kq;
-				if (npx == 64u) { in_tile = item & 63u; kq = item >> 6; }              // full tile (wave-uniform branch)
-				else { const uint32_t r = item % npx; kq = item / npx; in_tile = (r / tw) * 8u + r % tw; }
-				p.rec_index = rec_base + kq * 64u + in_tile;
-				const SsxSampleRecord rec = a.samples[p.rec_index];
-				p.dir = mk(rec.a.x, rec.a.y, rec.a.z);
-				p.lambda_0 = rec.a.w;
-				p.rng.state = ((uint64_t)rec.b.y << 32) | rec.b.x;
-				p.rng.inc = ((uint64_t)rec.b.w << 32) | rec.b.z;
-				p.orig = cam;
-				p.ignore = -1;
-				p.depth = 0;
-				p.hit_anything = false;
-				active = true;
-			}
+		// rotate: the current unit has no items left and the previous one is folded
+		if (cur_valid && next_item >= cur.n_items && !old_pending) {
+			if (a.fuse_resolve) { old = cur; old_tag = cur_tag; old_pending = true; }
+			cur_valid = false;
 		}
-		next_item = min(n_items, next_item + (uint32_t)__popcll(idle));
-		if (!__any(active)) break;
+		if (!cur_valid && more) {
+			uint32_t u = 0;
+			if (lane == 0u) u = atomicAdd(a.unit_counter, 1u);
+			u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
+			if (u < total_units) { unit_setup(a, u, cur); cur_tag ^= 1u; next_item = 0; cur_valid = true; }
+			else more = false;
+		}
+		// hand out items to idle lanes
+		if (cur_valid && next_item < cur.n_items) {
+			const uint64_t idle = __ballot(!active);
+			if (!active) {
+				const uint32_t item = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+				if (item < cur.n_items) {
+					uint32_t in_tile, kq;
+					if (cur.npx == 64u) { in_tile = item & 63u; kq = item >> 6; }              // full tile (wave-uniform branch)
+					else { const uint32_t r = item % cur.npx; kq = item / cur.npx; in_tile = (r / cur.tw) * 8u + r % cur.tw; }
+					p.rec_index = cur.rec_base + kq * 64u + in_tile;
+					const SsxSampleRecord rec = a.samples[p.rec_index];
+					p.dir = mk(rec.a.x, rec.a.y, rec.a.z);
+					p.lambda_0 = rec.a.w;
+					p.rng.state = ((uint64_t)rec.b.y << 32) | rec.b.x;
+					p.rng.inc = ((uint64_t)rec.b.w << 32) | rec.b.z;
+					p.orig = cam;
+					p.ignore = -1;
+					p.depth = 0;
+					p.hit_anything = false;
+					p_tag = cur_tag;
+					active = true;
+				}
+			}
+			next_item = min(cur.n_items, next_item + (uint32_t)__popcll(idle));
+		}
+		if (!__any(active)) {
+			// nothing is running: fold what is pending; stop when nothing is left to hand out either
+			if (sq.count) { shadow_flush(L, a, sq, 0u, sq.count); sq.count = 0; }
+			if (old_pending) { unit_fold(L, a, old); old_pending = false; }
+			if (!cur_valid && !more) break;
+			continue;
+		}
 		SSX_MARK(0);
 #ifdef SSX_PROFILE_REGIONS
 		prof_iters += 1; prof_lanes += (uint64_t)__popcll(__ballot(active));
@@ -1057,7 +1121,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			float rad[4];
 			if (!path_step(L, sq, a, p, rad, pushed SSX_PROF_PASS)) {
 				// deepest level reached: its radiance, the number of recorded frames, lambda_0 and the
-				// hit flag replace the sample's record; the fold happens at the end of the unit
+				// hit flag replace the sample's record; the fold happens when its unit is complete
 				SsxSampleRecord out;
 				out.a = make_float4(rad[0], rad[1], rad[2], rad[3]);
 				out.b = make_uint4(__float_as_uint(p.lambda_0), p.hit_anything ? 1u : 0u, p.depth, 0u);
@@ -1070,28 +1134,16 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			sq.count -= 64u;
 			shadow_flush(L, a, sq, sq.count, 64u);
 		}
+		// the previous unit's last paths are done: apply the parked shadow rays (some may be its), fold it
+		if (old_pending && !__any(active && p_tag == old_tag)) {
+			if (sq.count) { shadow_flush(L, a, sq, 0u, sq.count); sq.count = 0; }
+			unit_fold(L, a, old);
+			old_pending = false;
+		}
 		SSX_MARK(8);
 	}
-	if (sq.count) shadow_flush(L, a, sq, 0u, sq.count); // the rest, before the fold reads the records and frames
-	// Resolve this unit's samples: every lane folds the records of its own pixel.  The loads of this
-	// tail (frames and records this wave wrote during the unit) overlap with the arithmetic of the other
-	// waves on the SIMD, which a separate HBM-bound pass after the kernel could not.
-	// (For scenes with very short paths -- plane-srgb: one frame per sample -- the fold is a large share
-	// of the arithmetic and the separate streaming kernel is faster; the host picks, see ssx_api.hip.)
-	if (a.fuse_resolve) {
-		// the records and frames were written by whichever lane ran the sample, in this wave's own
-		// instruction stream: wait for those stores, then drop the CU's L1 lines (a record line may date
-		// from before its last store); no L2 write-back is needed, nobody else reads this unit's data
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-		const uint32_t lane = threadIdx.x & 63u;
-		const bool in_image = (lane & 7u) < tw && (lane >> 3) < th;
-		if (in_image)
-			for (uint32_t kq = 0; kq < kb - ka; kq += SSX_RESOLVE_WAYS)
-				resolve_records<SSX_RESOLVE_WAYS>(L, a, rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, kb - ka - kq));
-	}
 #ifdef SSX_PROFILE_REGIONS
-	if ((threadIdx.x & 63u) == 0u && a.prof) {
+	if (lane == 0u && a.prof) {
 		for (int r = 0; r < SSX_NREG - 3; ++r) atomicAdd((unsigned long long*)&a.prof[r], (unsigned long long)prof_t[r]);
 		atomicAdd((unsigned long long*)&a.prof[SSX_NREG - 3], (unsigned long long)(__builtin_readcyclecounter() - prof_start));
 		atomicAdd((unsigned long long*)&a.prof[SSX_NREG - 2], (unsigned long long)prof_iters);
@@ -1109,10 +1161,7 @@ extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_pe
 // The fold as a pass of its own (one lane per sample, persistent blocks, streaming reads), used
 // instead of the path kernel's tail when SsxKernelArgs::fuse_resolve is 0.
 extern "C" __global__ void __launch_bounds__(256) ssx_resolve_kernel(SsxKernelArgs a) {
-	extern __shared__ __attribute__((aligned(16))) uint32_t lds_blob[];
-	for (uint32_t w = threadIdx.x; w < a.blob_words; w += blockDim.x) lds_blob[w] = a.blob[w];
-	__syncthreads();
-	Lds L; L.w = lds_blob;
+	Lds L; L.w = stage_lds(a);
 	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_records; r += (uint64_t)gridDim.x * blockDim.x) {
 		if (a.width % 8u != 0u || a.height % 8u != 0u) { // records of lanes outside a ragged image were never generated
 			const uint32_t lane = (uint32_t)(r & 63u);
