@@ -246,7 +246,6 @@ int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
 constexpr size_t kSampleBufferBudget = (size_t)32 << 30; // bytes: 32 B record + 9 x 48 B frames per sample in flight (288 GB HBM)
 constexpr size_t kBytesPerSampleInFlight = sizeof(SsxSampleRecord) + SSX_MAX_FRAMES * sizeof(SsxFrame);
 constexpr uint32_t kMinUnits = 3072;                   // one wave work unit per wave slot of the GPU (256 CUs x 4 SIMDs x 3 waves)
-constexpr uint32_t kTargetUnits = 32768;               // wave work units wanted per launch (~32 per SIMD; measured best of 4k..128k)
 
 struct LaunchPlan { SsxKernelArgs args; size_t lds_bytes; uint32_t max_spp_per_launch; };
 
@@ -327,12 +326,12 @@ Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1, u
 	a.samples = ctx->d_samples + rec_off;
 	a.frames = ctx->d_frames + rec_off * SSX_MAX_FRAMES;
 	a.n_records = (uint64_t)a.my_tiles * n_k * 64u;
-	uint64_t g = ((uint64_t)n_k * a.my_tiles + kTargetUnits - 1) / kTargetUnits;
-	// at least 8 samples per pixel and unit (512 items keep the refill going) unless the launch is so small
-	// that this would leave SIMDs without a wave (3 waves x 1024 SIMDs)
-	uint32_t g_min = 8;
-	while (g_min > 1u && (uint64_t)((n_k + g_min - 1u) / g_min) * a.my_tiles < kMinUnits) g_min >>= 1;
-	a.group_spp = (uint32_t)(g < g_min ? g_min : g);
+	// 8 samples per pixel and unit (512 items: enough for the refill, and short units balance the end of
+	// the launch; measured best of 1..64 with persistent waves) unless the launch is so small that this
+	// would leave SIMDs without a wave (3 waves x 1024 SIMDs)
+	uint32_t g = 8;
+	while (g > 1u && (uint64_t)((n_k + g - 1u) / g) * a.my_tiles < kMinUnits) g >>= 1;
+	a.group_spp = g;
 	if (a.group_spp > n_k) a.group_spp = n_k;
 	a.n_groups = (n_k + a.group_spp - 1) / a.group_spp;
 	b.units = a.my_tiles * a.n_groups;
