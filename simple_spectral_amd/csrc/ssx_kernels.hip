@@ -526,7 +526,11 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		}
 	}
 #endif
+#ifdef SSX_ABL_ONETRIP   // timing-only ablation: finish the first candidate only (wrong image)
+	for (int only_once = 0; only_once < 1 && cand; ++only_once) {
+#else
 	while (cand) {
+#endif
 		uint32_t bit = (uint32_t)__builtin_ctzll(cand);
 		cand &= cand - 1ull;
 		uint32_t q = bit >> 1, which = bit & 1u;
