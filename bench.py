@@ -46,7 +46,7 @@ def cpu_baseline(scene, W, H, texture, target_seconds=12.0):
     t = time.time()
     o.render(W, H, 1, nthreads=cores)
     t1 = max(time.time() - t, 1e-3)
-    spp = int(max(1, min(256, target_seconds / t1)))
+    spp = int(max(1, min(128, target_seconds / t1)))
     t = time.time()
     o.render(W, H, spp, nthreads=cores)
     dt = time.time() - t
