@@ -490,6 +490,12 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		cand |= (uint64_t)bits << (2u * q);
 	}
 #else
+#ifdef SSX_DUP_PASS1 // timing-only: the pass-1 loop runs twice (same result), the time difference is its cost
+	for (int dup_rep = 0; dup_rep < 2; ++dup_rep) {
+	RaySetup rs_dup = rs;
+	asm volatile("" : "+v"(rs_dup.Sx), "+v"(rs_dup.okx));
+#define rs rs_dup
+#endif
 	for (uint32_t q = 0; q < nq; ++q) {
 		float pv[12];
 		load_perm(L.perm(q, rs.perm), pv);
@@ -507,6 +513,10 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		uint32_t bits = ((mn0 < 0.0f && mx0 > 0.0f) ? 0u : 1u) | ((mn1 < 0.0f && mx1 > 0.0f) ? 0u : 2u);
 		cand |= (uint64_t)bits << (2u * q);
 	}
+#ifdef SSX_DUP_PASS1
+#undef rs
+	}
+#endif
 #endif
 	if (ignore_quad >= 0) cand &= ~(3ull << (2u * (uint32_t)ignore_quad));
 
@@ -525,6 +535,13 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 			atomicAdd((unsigned long long*)&g_cand_stats[3], (unsigned long long)mx);
 		}
 	}
+#endif
+#ifdef SSX_DUP_PASS2 // timing-only: the candidate loop runs twice
+	const uint64_t cand_saved = cand;
+	for (int dup2 = 0; dup2 < 2; ++dup2) {
+	cand = cand_saved;
+	asm volatile("" : "+v"(cand));
+	hit.tri = -1; hit.dist = __builtin_inff();
 #endif
 #ifdef SSX_ABL_ONETRIP   // timing-only ablation: finish the first candidate only (wrong image)
 	for (int only_once = 0; only_once < 1 && cand; ++only_once) {
@@ -566,6 +583,9 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 			if (which == 0u) cand &= ~(1ull << (bit + 1u)); // PrimQuad::intersect: tri0 hit -> tri1 not tested
 		}
 	}
+#ifdef SSX_DUP_PASS2
+	}
+#endif
 }
 
 // ------------------------------------------------------------------ light sampling ----
@@ -817,6 +837,9 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 		st_y = (bx * s0[1] + by * s1[1]) + bz * s2[1];
 	}
 	// albedo(lambda) is shared by evaluate_bsdf and interact_bsdf (material.cpp:120-143)
+#ifdef SSX_DUP_ALBEDO // timing-only: the albedo lookup runs twice
+	{ float sx = st_x; asm volatile("" : "+v"(sx)); Hero a2 = material_albedo(L, Q, sx, st_y, p.lambda_0); asm volatile("" :: "v"(a2.v[0]), "v"(a2.v[1]), "v"(a2.v[2]), "v"(a2.v[3])); }
+#endif
 	Hero alb = material_albedo(L, Q, st_x, st_y, p.lambda_0);
 	float f_lamb[4];
 #pragma unroll
@@ -828,10 +851,16 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 #ifndef SSX_ABL_NONEE
 	if (els && (!a.indirect_only || p.depth > 0u)) {
 		V3 sdir; uint32_t light; float spdf;
+#ifdef SSX_DUP_SAMPLELIGHT // timing-only: light sampling runs twice (first on a copy of the stream)
+		{ Rng rng_dup = p.rng; V3 hp = hit_pos; asm volatile("" : "+v"(hp.x)); sample_light(L, rng_dup, hp, sdir, light, spdf); asm volatile("" :: "v"(sdir.x), "v"(spdf), "v"(light), "v"(rng_dup.state)); }
+#endif
 		sample_light(L, p.rng, hit_pos, sdir, light, spdf);
 		float n_dot_l = dot3(sdir, N);
 		SSX_MARK(3);
 		if (n_dot_l > 0.0f) {
+#ifdef SSX_DUP_CONTRIB // timing-only: emission lookup + contribution computed twice
+			{ float l2 = p.lambda_0; asm volatile("" : "+v"(l2)); Hero e2 = spectrum_hero(L, L.quad(light).emission, l2, h.lambda_step); float acc = 0; for (int k = 0; k < 4; ++k) acc += ((e2.v[k] * n_dot_l) * f_lamb[k]) / spdf; asm volatile("" :: "v"(acc)); }
+#endif
 			Hero emitted = spectrum_hero(L, L.quad(light).emission, p.lambda_0, h.lambda_step);
 			float c[4];
 #pragma unroll
@@ -855,6 +884,9 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	// indirect lighting (:222-250)
 	V3 w_i; float pdf_w_i; float f_s[4];
 	if (M.kind == 0u) {
+#ifdef SSX_DUP_BSDF // timing-only: the BSDF sample runs twice (first on a copy of the stream)
+		{ Rng r2 = p.rng; V3 n2 = N; asm volatile("" : "+v"(n2.x)); float pd; V3 w2 = get_rotated_to(rand_coshemi(r2, pd), n2); asm volatile("" :: "v"(w2.x), "v"(w2.y), "v"(w2.z), "v"(pd), "v"(r2.state)); }
+#endif
 		w_i = rand_coshemi(p.rng, pdf_w_i);
 		w_i = get_rotated_to(w_i, N);
 #pragma unroll
