@@ -1,13 +1,17 @@
 // ssx_kernels.hip -- the per-pixel spectral integrator as a gfx950 megakernel.
 //
 // Path covered (reference file:line, paths relative to the reference's src/):
-//   renderer.cpp:309-395  tile loop            -> one wave64 per 8x8 tile, one lane per pixel
-//   renderer.cpp:278-299  _render_pixel        -> per-lane f64 XYZA accumulation over samples
-//   renderer.cpp:104-277  _render_sample / L   -> iterative path loop + post-order fold (R5)
+//   renderer.cpp:309-395  tile loop            -> persistent waves fetching work units (8x8 tile x 8
+//                                                 samples per pixel); lanes take (pixel, k) items
+//   renderer.cpp:278-299  _render_pixel        -> ssx_accumulate_kernel: f64 XYZA sum in ascending k
+//   renderer.cpp:104-277  _render_sample / L   -> ssx_generate_kernel (camera ray, lambda_0), then the
+//                                                 iterative path loop of ssx_render_kernel with the
+//                                                 shadow rays parked and traced 64 at a time, and the
+//                                                 post-order fold + XYZ when a unit is complete
 //   scene.cpp:433-445, geometry.cpp:12-139     -> trace(): quad-batched watertight test
 //   scene.cpp:417-431, geometry.cpp:103-145, util/spherical-tri.cpp, util/random.cpp:101-154
 //                                              -> sample_light()
-//   material.cpp:45-143, util/color.cpp:167-173, spectrum.cpp:39-67 -> albedo / spectrum lookups
+//   material.cpp:45-143, util/color.cpp:167-232, spectrum.cpp:39-67 -> albedo / spectrum lookups, uplifts
 //   util/color.hpp:115-139                     -> flux_to_xyz()
 //
 // Numerics contract: every float expression is evaluated in the reference's order with IEEE
