@@ -479,7 +479,13 @@ void worker_main(ssx_ctx* ctx) {
 		size_t pixels = (size_t)p.width * p.height;
 		SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, pixels * 4 * sizeof(double), ctx->stream));
 		LaunchPlan pl = make_plan(ctx, &p);
+		// progress / cancel granularity: 1/32 of the render, but at least ~32 M samples (~20 ms) per launch so
+		// that the synchronisation between launches stays a few percent
 		uint32_t chunk = p.spp_per_launch ? p.spp_per_launch : (p.spp + 31u) / 32u;
+		if (!p.spp_per_launch) {
+			const uint64_t min_spp = ((uint64_t)32 << 20) / (pixels ? pixels : 1) + 1u;
+			if (chunk < min_spp) chunk = (uint32_t)(min_spp < p.spp ? min_spp : p.spp);
+		}
 		if (chunk == 0) chunk = 1;
 		if (chunk > pl.max_spp_per_launch) chunk = pl.max_spp_per_launch;
 		{ int r = ensure_samples(ctx, pl, chunk < p.spp ? chunk : p.spp); if (r) return r; }

@@ -1,6 +1,9 @@
 #include "color.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <thread>
+#include <vector>
 
 namespace ssx {
 namespace {
@@ -124,6 +127,24 @@ void ColorData::ciexyz_to_srgb(const float xyz[3], float srgb[3]) const {
 	} else
 	ciexyz_to_lrgb(xyz, lrgb);
 	for (int i = 0; i < 3; ++i) srgb[i] = lrgb_to_srgb(lrgb[i]);
+}
+void ColorData::xyza_to_srgba(const float* xyza, float* srgba, size_t n) const {
+	auto range = [&](size_t a, size_t b) {
+		for (size_t p = a; p < b; ++p) {
+			ciexyz_to_srgb(xyza + 4 * p, srgba + 4 * p);
+			srgba[4 * p + 3] = xyza[4 * p + 3];
+		}
+	};
+	unsigned nt = std::thread::hardware_concurrency();
+	if (nt > 16) nt = 16;
+	if (nt < 2 || n < (size_t)1 << 16) { range(0, n); return; }
+	std::vector<std::thread> pool;
+	const size_t per = (n + nt - 1) / nt;
+	for (unsigned t = 0; t < nt; ++t) {
+		const size_t a = (size_t)t * per, b = std::min(n, a + per);
+		if (a < b) pool.emplace_back(range, a, b);
+	}
+	for (std::thread& th : pool) th.join();
 }
 void ColorData::round_trip_lrgb(const float in[3], float out[3]) const {
 	const Spectrum reflectance = basis_r.scaled(in[0]).plus(basis_g.scaled(in[1])).plus(basis_b.scaled(in[2]));

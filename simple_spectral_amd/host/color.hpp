@@ -30,6 +30,9 @@ public:
 	void specradflux_to_ciexyz(const Spectrum& flux, float xyz[3]) const; // color.hpp:106-111
 	void ciexyz_to_lrgb(const float xyz[3], float lrgb[3]) const;         // color.hpp:150-152
 	void ciexyz_to_srgb(const float xyz[3], float srgb[3]) const;         // color.cpp:238-254
+	// the same for n float4 {X,Y,Z,alpha} pixels -> {sR,sG,sB,alpha}, spread over the host's cores
+	// (the reference's workers do this per pixel as they go, src/renderer.cpp:298)
+	void xyza_to_srgba(const float* xyza, float* srgba, size_t n) const;
 	void round_trip_lrgb(const float lrgb_in[3], float lrgb_out[3]) const; // color.cpp:260-289
 };
 

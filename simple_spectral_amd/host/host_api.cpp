@@ -89,10 +89,7 @@ const ssx_scene_desc* ssh_scene_desc(const ssh_scene* scene) { return scene ? &s
 
 int ssh_xyza_to_srgba(const ssh_scene* scene, const float* xyza, float* srgba, size_t n) {
 	if (!scene || !xyza || !srgba) { g_error = "NULL argument"; return SSX_ERR_ARG; }
-	for (size_t p = 0; p < n; ++p) {
-		scene->color->ciexyz_to_srgb(xyza + 4 * p, srgba + 4 * p);
-		srgba[4 * p + 3] = xyza[4 * p + 3];
-	}
+	scene->color->xyza_to_srgba(xyza, srgba, n);
 	return SSX_OK;
 }
 

@@ -195,10 +195,7 @@ void Renderer::render_wait() {
 	}
 	started_ = false;
 	// framebuffer(i,j) = sRGB_A_F32(ciexyz_to_srgb(XYZ), alpha)  (src/renderer.cpp:298)
-	for (size_t p = 0; p < options.res[0] * options.res[1]; ++p) {
-		color->ciexyz_to_srgb(&xyza[4 * p], framebuffer.data() + 4 * p);
-		framebuffer.data()[4 * p + 3] = xyza[4 * p + 3];
-	}
+	color->xyza_to_srgba(xyza.data(), framebuffer.data(), options.res[0] * options.res[1]);
 	print_progress();
 	if (!options.output_path.empty()) framebuffer.save(options.output_path); // src/renderer.cpp:393
 }
