@@ -316,3 +316,24 @@ def test_fold_placement_is_calibrated_and_does_not_change_the_image():
     r = Renderer(Options(scene_name="plane-srgb", res=(16, 16), spp=1, texture="test-img.png"))
     info = r.plan_info()
     assert info["fold"] == "resolve kernel" and 0.8 < info["frames_per_sample"] <= 1.0   # S = 2 where the plane is hit: one continued level
+
+
+def test_many_units_per_wave_parity_and_determinism():
+    """Rare-event guard for the persistent-wave machinery (unit rotation, the shadow-ray queue's
+    read-modify-write of frames and records, the fold's view of this wave's own stores): a render with
+    ~10 units per wave against the oracle bit for bit, and a larger one three times over.
+    tools/stress_parity.py does the same at 1.6 G samples."""
+    import torch
+    r = Renderer(Options(scene_name="cornell-srgb", res=(512, 512), spp=32, seed=11, texture="crystal-lizard-512.png"))
+    r.render_start(); r.render_wait()
+    ref = ol.Oracle("cornell-srgb", texture="crystal-lizard-512.png").render(512, 512, 32, seed=11)
+    assert np.array_equal(bits(r.xyza), bits(ref))
+    r = Renderer(Options(scene_name="cornell", res=(1024, 1024), spp=96, seed=5))
+    outs = []
+    for _ in range(3):
+        out = torch.zeros((1024, 1024, 4), device="cuda")
+        r.render_device(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(bits(outs[0]), bits(outs[1])) and np.array_equal(bits(outs[0]), bits(outs[2]))
+    assert np.isfinite(outs[0]).all()
