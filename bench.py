@@ -29,6 +29,7 @@ FLOP_PER_SAMPLE = {"cornell-srgb": 1.28e4, "cornell": 1.28e4, "plane-srgb": 2.8e
 # record is read and rewritten, and one 48-byte frame is written per continued bounce
 # (frames/sample = interactions that continue: 3.29 Cornell, 1 plane [oracle statistics]).
 FRAMES_PER_SAMPLE = {"cornell-srgb": 3.29, "cornell": 3.29, "plane-srgb": 1.0}
+SHADOW_RMW_BYTES = {"cornell-srgb": 80, "cornell": 80, "plane-srgb": 30}
 # gfx950 FP32 vector peak is 157.3 TFLOP/s counting FMA as 2; the parity contract forbids
 # contraction, so the ceiling that applies is the non-fused issue rate, half of it.
 PEAK_VALU_TFLOPS = 78.6
@@ -168,7 +169,9 @@ def main():
         # algorithmic HBM traffic of the path kernel per launch and sample: record read (32 B) + rewritten at the end
         # of the path (32) + read again and overwritten with XYZA by the fold (32 + 16); 48-B frames written once and
         # read once by the fold
-        hbm_bytes = per_gpu_samples * (112 + 96 * FRAMES_PER_SAMPLE.get(args.scene, 3.29))
+        # read once by the fold; ~3 parked shadow rays per Cornell sample read 16 B of their target and write it back
+        # when the light is visible
+        hbm_bytes = per_gpu_samples * (112 + 96 * FRAMES_PER_SAMPLE.get(args.scene, 3.29) + SHADOW_RMW_BYTES.get(args.scene, 80))
         info = r.kernel_info()
         line = {
             "metric": "Msamples/s (w*h*spp/s) %s %dx%d" % (args.scene, W, H),
