@@ -973,7 +973,9 @@ __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& 
 // radiance, renderer.cpp:262-263).  A record becomes {X, Y, Z, alpha} ({R, G, B, alpha} in RGB mode).
 // Four records of the lane (consecutive k of its pixel) are folded side by side so that the frame
 // loads of a level are four independent requests instead of a chain of dependent round trips.
+#ifndef SSX_RESOLVE_WAYS
 #define SSX_RESOLVE_WAYS 4u
+#endif
 template <uint32_t WAYS>
 __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count) {
 	float rad[WAYS][4];
