@@ -1194,8 +1194,11 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 #endif
 }
 
+#ifndef SSX_WAVES_PER_EU
+#define SSX_WAVES_PER_EU 4
+#endif
 // 3 waves per SIMD (168 VGPRs): the register allocator otherwise settles one register above that
-extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) ssx_render_kernel(SsxKernelArgs a) { render_body(a); }
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SSX_WAVES_PER_EU))) ssx_render_kernel(SsxKernelArgs a) { render_body(a); }
 // The same kernel under another name for the calibration render of ssx_upload_scene, so that
 // kernel traces and statistics of ssx_render_kernel contain real launches only.
 extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) ssx_calibrate_kernel(SsxKernelArgs a) { render_body(a); }
