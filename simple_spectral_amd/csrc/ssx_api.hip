@@ -150,6 +150,10 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	const uint32_t off_samples = off; off = align4(off + s->n_samples);
 	h.off_lut = off;       off = align4(off + 256u);
 	h.off_tex = off;       off = align4(off + s->n_textures * (uint32_t)(sizeof(SsxBlobTexture) / 4));
+#if defined(SSX_MFMA_PASS1) // experimental pass 1 on the matrix cores (ssx_kernels.hip, trace()): its edge table
+	const uint32_t n_mtiles = (s->n_quads + 3u) / 4u; // 8 edge rows per quad, 32 rows per MFMA row tile
+	h.off_plucker = off;   off = align4(off + n_mtiles * 3u * 64u);
+#endif
 	h.uplift = s->uplift;
 	if (s->uplift == SSX_UPLIFT_JH) {
 		h.jh_res = s->jh_res;
@@ -196,6 +200,29 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 		bq[q].is_emissive = 0;
 		for (uint32_t k = 0; k < es.n; ++k) if (s->samples[es.offset + k] != 0.0f) bq[q].is_emissive = 1;
 	}
+#if defined(SSX_MFMA_PASS1)
+	{
+		// Pluecker rows of the directed triangle edges p->q: (p x q, q - p), in double, rounded once.  Row
+		// 8q+r: r = 0..2 edges ab, bc, ca of tri0 = (v00, v10, v11); r = 4..6 edges ac, cd, da of tri1 =
+		// (v00, v11, v01); r = 3, 7 zero.  Stored as the MFMA A operand: [row tile][K step][lane] = A[32t + lane%32][2s + lane/32].
+		float* pt = reinterpret_cast<float*>(blob.data() + h.off_plucker);
+		for (uint32_t t = 0; t < n_mtiles; ++t) for (uint32_t st = 0; st < 3; ++st) for (uint32_t lane = 0; lane < 64; ++lane) {
+			const uint32_t row = 32u * t + (lane & 31u), k = 2u * st + (lane >> 5);
+			const uint32_t q = row >> 3, r = row & 7u;
+			float v = 0.0f;
+			if (q < s->n_quads && (r & 3u) != 3u) {
+				const ssx_quad& Q = s->quads[q];
+				const float* tri[2][3] = { { Q.v00.pos, Q.v10.pos, Q.v11.pos }, { Q.v00.pos, Q.v11.pos, Q.v01.pos } };
+				const float* P = tri[r >> 2][r & 3u];
+				const float* Qv = tri[r >> 2][((r & 3u) + 1u) % 3u];
+				const double p0 = P[0], p1 = P[1], p2 = P[2], q0 = Qv[0], q1 = Qv[1], q2 = Qv[2];
+				const double row6[6] = { p1 * q2 - p2 * q1, p2 * q0 - p0 * q2, p0 * q1 - p1 * q0, q0 - p0, q1 - p1, q2 - p2 };
+				v = (float)row6[k];
+			}
+			pt[(3u * t + st) * 64u + lane] = v;
+		}
+	}
+#endif
 	memcpy(blob.data() + h.off_lights, s->lights, 4 * s->n_lights);
 	SsxBlobSpectrum* bs = reinterpret_cast<SsxBlobSpectrum*>(blob.data() + h.off_spectra);
 	for (uint32_t i = 0; i < s->n_spectra; ++i) {

@@ -11,7 +11,11 @@
 // per-wave LDS scratch of the path kernel: the queue of parked shadow rays (ShadowQ in ssx_kernels.hip),
 // 128 entries x 12 words = 6 KB; a 256-lane workgroup takes blob + 24 KB, so three fit a CU's 160 KB for
 // blobs up to 29 KB
+#if defined(SSX_MFMA_PASS1)
+#define SSX_WAVE_SCRATCH_WORDS (116u * 12u)
+#else
 #define SSX_WAVE_SCRATCH_WORDS (128u * 12u)
+#endif
 // dynamic LDS of the kernels that stage the blob: [coefficient table of ssx_fmath.h][blob][wave scratch]
 #define SSX_LDS_PREFIX_WORDS 80u
 
@@ -60,7 +64,7 @@ struct SsxBlobHeader {
 	uint32_t uplift, jh_res, off_jh_scale, jh_data_lo, jh_data_hi;
 	float pass1_tol;  // tolerance of the conservative edge-function filter: 1024 * 2^-24 * R^2
 	uint32_t observer_one_grid; // the three observer tables share (low, delta_recip, n)
-	uint32_t pad[1];
+	uint32_t off_plucker;       // MFMA pass 1: Pluecker coordinates of the triangle edges, [row tile][K step][lane] (see trace())
 };
 static_assert(sizeof(SsxBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 

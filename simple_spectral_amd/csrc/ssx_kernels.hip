@@ -455,11 +455,74 @@ __device__ __forceinline__ SV shear_vertex(const float* pv, int v, const RaySetu
 // visiting order): finish candidates exactly -- f64 edge fallback, det, T, sign test, 1/det,
 // dist, closest-so-far with strict '<' -- and skip tri1 when tri0 of the same quad was accepted
 // (the `goto HIT` of PrimQuad::intersect).
-__device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_quad, HitInfo& hit) {
+//
+// SSX_MFMA_PASS1: pass 1 on the matrix cores.  The sign of an edge function is the sign of the
+// Pluecker side product of the ray (d, o x d) and the directed edge (q - p, p x q):
+//     side = d . (p x q) + (o x d) . (q - p)
+// -- a [rays x 6] x [6 x edges] product.  One v_mfma_f32_32x32x2_f32 chain of three (K = 6) gives
+// 32 edges x 32 rays; the edge rows are laid out 8 per quad {tri0: ab, bc, ca, 0 | tri1: ac, cd, da, 0}
+// so that a lane's 16 accumulators of a tile are four whole triangles: lanes 0-31 get tri0 of four
+// quads for ray (lane % 32) of the column tile, lanes 32-63 tri1.  The ray operands of both column
+// tiles come from three v_permlane32_swap, the two result masks go back to the rays' own lanes with a
+// fourth.  The products are rounded differently from the reference's sheared edge functions, so this
+// is a conservative filter: a triangle is dropped only if one side value is below -tol and another
+// above +tol (tol = 1024 u R^2 covers both roundings); pass 2 decides exactly.
+// trace() must then be called by all 64 lanes (has_ray tells whether the lane traces anything).
+__device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_quad, bool has_ray, HitInfo& hit) {
 	const RaySetup rs = ray_setup(orig, dir);
 	const uint32_t nq = L.hdr().n_quads;
 	uint64_t cand = 0;
-#ifdef SSX_CONSERVATIVE_PASS1
+#if defined(SSX_MFMA_PASS1)
+	uint32_t m0 = 0u, m1 = 0u;
+	{
+		typedef float f16v __attribute__((ext_vector_type(16)));
+		const uint32_t lane = threadIdx.x & 63u;
+#ifndef SSX_TOL_SCALE
+#define SSX_TOL_SCALE 1.0f
+#endif
+		const float tol = L.hdr().pass1_tol * SSX_TOL_SCALE;
+		// ray in Pluecker coordinates
+		const float c[6] = { dir.x, dir.y, dir.z,
+		                     orig.y * dir.z - orig.z * dir.y, orig.z * dir.x - orig.x * dir.z, orig.x * dir.y - orig.y * dir.x };
+		float B0[3], B1[3]; // operand of column tile 0 (rays 0-31) and 1 (rays 32-63), K step s
+#pragma unroll
+		for (int st = 0; st < 3; ++st) {
+			auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[2 * st]), __float_as_uint(c[2 * st + 1]), false, false);
+			B0[st] = __uint_as_float(r[0]); B1[st] = __uint_as_float(r[1]);
+		}
+		const float* atab = reinterpret_cast<const float*>(L.w + L.hdr().off_plucker) + lane;
+		const uint32_t n_mtiles = (nq + 3u) >> 2;
+		uint32_t v1 = 0u, v2 = 0u; // "mixed" flags of the triangle groups, first group highest (one v_alignbit each), column tile 0 / 1
+		for (uint32_t t = 0; t < n_mtiles; ++t) {
+			const float a0 = atab[(3u * t + 0u) * 64u], a1 = atab[(3u * t + 1u) * 64u], a2 = atab[(3u * t + 2u) * 64u];
+			f16v z = { 0 };
+			f16v d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, B0[0], z, 0, 0, 0);
+			f16v d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, B1[0], z, 0, 0, 0);
+			d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, B0[1], d0, 0, 0, 0);
+			d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, B1[1], d1, 0, 0, 0);
+			d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, B0[2], d0, 0, 0, 0);
+			d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, B1[2], d1, 0, 0, 0);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				// mixed <=> min < -tol and max > tol <=> min(-min, max) > tol <=> tol - min(-min, max) < 0
+				const float mn0 = __builtin_fminf(__builtin_fminf(d0[4 * j], d0[4 * j + 1]), d0[4 * j + 2]);
+				const float mx0 = __builtin_fmaxf(__builtin_fmaxf(d0[4 * j], d0[4 * j + 1]), d0[4 * j + 2]);
+				const float mn1 = __builtin_fminf(__builtin_fminf(d1[4 * j], d1[4 * j + 1]), d1[4 * j + 2]);
+				const float mx1 = __builtin_fmaxf(__builtin_fmaxf(d1[4 * j], d1[4 * j + 1]), d1[4 * j + 2]);
+				v1 = __builtin_amdgcn_alignbit(v1, __float_as_uint(tol - __builtin_fminf(-mn0, mx0)), 31u);
+				v2 = __builtin_amdgcn_alignbit(v2, __float_as_uint(tol - __builtin_fminf(-mn1, mx1)), 31u);
+			}
+		}
+		// flag k = 4t+j sits at bit (4*n_mtiles - 1 - k): reverse, align, invert (1 = candidate)
+		const uint32_t sh = 32u - 4u * n_mtiles;
+		v1 = ~(__builtin_bitreverse32(v1) >> sh);
+		v2 = ~(__builtin_bitreverse32(v2) >> sh);
+		// v1: lanes 0-31 tri0 of ray lane, lanes 32-63 tri1 of ray lane-32; v2: lanes 0-31 tri0 of ray lane+32, lanes 32-63 tri1 of ray lane
+		auto r = __builtin_amdgcn_permlane32_swap(v1, v2, false, false);
+		const uint32_t valid = nq >= 32u ? 0xFFFFFFFFu : ((1u << nq) - 1u);
+		m0 = r[0] & valid; m1 = r[1] & valid; // tri0 / tri1 candidates of this lane's own ray, one bit per quad
+	}
+#elif defined(SSX_CONSERVATIVE_PASS1)
 	// Experimental (measured +0.7 % only, so not the default): conservative filter.  The edge functions are evaluated in a cheaper, differently rounded form
 	// (x'' = fma(-Sx, v[kz], v[kx]) - (o[kx] - Sx*o[kz]), fused products) and a triangle is dropped
 	// only if one of them is below -tol and another above +tol.  tol = 1024 u R^2 (u = 2^-24, R =
@@ -522,7 +585,14 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 	}
 #endif
 #endif
+#if defined(SSX_MFMA_PASS1)
+	if (ignore_quad >= 0) { m0 &= ~(1u << (uint32_t)ignore_quad); m1 &= ~(1u << (uint32_t)ignore_quad); }
+	if (!has_ray) { m0 = 0u; m1 = 0u; }
+	(void)cand;
+#else
 	if (ignore_quad >= 0) cand &= ~(3ull << (2u * (uint32_t)ignore_quad));
+	if (!has_ray) cand = 0ull;
+#endif
 
 	hit.tri = -1;
 	hit.dist = __builtin_inff();
@@ -547,6 +617,13 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 	asm volatile("" : "+v"(cand));
 	hit.tri = -1; hit.dist = __builtin_inff();
 #endif
+#if defined(SSX_MFMA_PASS1)
+	while (m0 | m1) { // ascending triangle order: tri0 of quad q (bit 2q) before tri1 (bit 2q+1)
+		const uint32_t q0 = m0 ? (uint32_t)__builtin_ctz(m0) : 32u, q1 = m1 ? (uint32_t)__builtin_ctz(m1) : 32u;
+		const uint32_t which = q1 < q0 ? 1u : 0u, q = which ? q1 : q0;
+		if (which) m1 &= m1 - 1u; else m0 &= m0 - 1u;
+		const uint32_t bit = 2u * q + which;
+#else
 #ifdef SSX_ABL_ONETRIP   // timing-only ablation: finish the first candidate only (wrong image)
 	for (int only_once = 0; only_once < 1 && cand; ++only_once) {
 #else
@@ -555,6 +632,7 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		uint32_t bit = (uint32_t)__builtin_ctzll(cand);
 		cand &= cand - 1ull;
 		uint32_t q = bit >> 1, which = bit & 1u;
+#endif
 		float pv[12];
 		load_perm(L.perm(q, rs.perm), pv);
 		SV A = shear_vertex(pv, 0, rs);
@@ -584,7 +662,11 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		if (dist >= SSX_EPS && dist < hit.dist) {
 			hit.tri = (int)bit; hit.dist = dist;
 			hit.U = U; hit.V = V; hit.W = W; hit.det_recip = det_recip;
+#if defined(SSX_MFMA_PASS1)
+			if (which == 0u) m1 &= ~(1u << q); // PrimQuad::intersect: tri0 hit -> tri1 not tested
+#else
 			if (which == 0u) cand &= ~(1ull << (bit + 1u)); // PrimQuad::intersect: tri0 hit -> tri1 not tested
+#endif
 		}
 	}
 #ifdef SSX_DUP_PASS2
@@ -785,7 +867,13 @@ __device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const Ss
 // stream is untouched (the shadow test draws nothing).
 //   entry = 3 x float4: {orig.xyz, dir.x} {dir.y, dir.z, c0, c1} {c2, c3, light<<8|ignore, target}
 //   target: frame index depth*n_records+record, or 0x80000000|record for the record's radiance
+#if defined(SSX_MFMA_PASS1)
+#define SSX_SQ_FLUSH_AT 52u
+#define SSX_SQ_CAPACITY 116u // <= 51 left over + 64 new per iteration (smaller queue: the edge table needs the LDS)
+#else
+#define SSX_SQ_FLUSH_AT 64u
 #define SSX_SQ_CAPACITY 128u // < 64 left over + 64 new per iteration
+#endif
 struct ShadowQ {
 	float4* e;
 	uint32_t count; // wave-uniform
@@ -799,10 +887,8 @@ __device__ __forceinline__ void sq_set_target(const ShadowQ& q, uint32_t slot, u
 // emission (camera ray only), next-event estimation with its shadow ray, BSDF sample.  Returns
 // true when the path continues (a Frame was pushed and p holds the next ray); otherwise `rad`
 // holds the radiance of this deepest level.
-__device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const SsxKernelArgs& a, Path& p, float rad[4], bool& pushed SSX_PROF_ARGS) {
+__device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const SsxKernelArgs& a, Path& p, const HitInfo& hit, float rad[4], bool& pushed SSX_PROF_ARGS) {
 	const SsxBlobHeader& h = L.hdr();
-	HitInfo hit;
-	trace(L, p.orig, p.dir, p.ignore, hit);
 	SSX_MARK(1);
 	if (hit.tri < 0) { rad[0] = rad[1] = rad[2] = rad[3] = 0.0f; return false; }
 	p.hit_anything = true;
@@ -949,22 +1035,25 @@ __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& 
 	// compiler and waits for those stores; the loads below bypass the CU's L1 (agent-scope atomics),
 	// which may still hold a record line from before the sample's last store.
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-	if (lane < n) {
+	const bool have = lane < n;
+	float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = make_float4(1.0f, 0.0f, 0.0f, 0.0f), e2 = e0, old = e0;
+	float4* dst = nullptr;
+	if (have) {
 		const float4* E = q.e + 3u * (first + lane);
-		const float4 e0 = E[0], e1 = E[1], e2 = E[2];
-		const uint32_t tag = __float_as_uint(e2.z), target = __float_as_uint(e2.w);
-		float4* dst = (target & 0x80000000u) ? &a.samples[target & 0x7FFFFFFFu].a : &a.frames[target].direct;
-		float* d = reinterpret_cast<float*>(dst);
-		float4 old; // in flight during the trace
+		e0 = E[0]; e1 = E[1]; e2 = E[2];
+		const uint32_t target = __float_as_uint(e2.w);
+		dst = (target & 0x80000000u) ? &a.samples[target & 0x7FFFFFFFu].a : &a.frames[target].direct;
+		float* d = reinterpret_cast<float*>(dst); // in flight during the trace
 		old.x = __hip_atomic_load(d + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		old.y = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		old.z = __hip_atomic_load(d + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		old.w = __hip_atomic_load(d + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		HitInfo sh;
-		trace(L, mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y), (int)(tag & 0xFFu), sh);
-		if (sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == (tag >> 8))
-			*dst = make_float4(old.x + e1.z, old.y + e1.w, old.z + e2.x, old.w + e2.y);
 	}
+	const uint32_t tag = __float_as_uint(e2.z);
+	HitInfo sh;
+	trace(L, mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y), (int)(tag & 0xFFu), have, sh);
+	if (have && sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == (tag >> 8))
+		*dst = make_float4(old.x + e1.z, old.y + e1.w, old.z + e2.x, old.w + e2.y);
 }
 
 // Backward fold of the recursion for finished samples (renderer.cpp:247: radiance += L(next) *
@@ -1090,6 +1179,8 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	const V3 cam = mk(h.cam_pos[0], h.cam_pos[1], h.cam_pos[2]);
 
 	Path p;
+	p.orig = cam; p.dir = mk(0.0f, 0.0f, 1.0f); p.ignore = -1; p.depth = 0; p.rec_index = 0; p.lambda_0 = 0.0f; p.hit_anything = false;
+	p.rng.state = 0; p.rng.inc = 1;
 	bool active = false;
 	uint32_t p_tag = 0; // which of the (at most two) units in flight the lane's sample belongs to
 	ShadowQ sq; // this wave's queue behind the blob (16-byte aligned: blob_words is a multiple of 4)
@@ -1159,9 +1250,11 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		prof_iters += 1; prof_lanes += (uint64_t)__popcll(__ballot(active));
 #endif
 		bool pushed = false;
+		HitInfo hit; // the primary rays of all lanes: traced in uniform control flow (idle lanes help out in the MFMA pass 1)
+		trace(L, p.orig, p.dir, p.ignore, active, hit);
 		if (active) {
 			float rad[4];
-			if (!path_step(L, sq, a, p, rad, pushed SSX_PROF_PASS)) {
+			if (!path_step(L, sq, a, p, hit, rad, pushed SSX_PROF_PASS)) {
 				// deepest level reached: its radiance, the number of recorded frames, lambda_0 and the
 				// hit flag replace the sample's record; the fold happens when its unit is complete
 				SsxSampleRecord out;
@@ -1172,9 +1265,10 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			}
 		}
 		sq.count += (uint32_t)__popcll(__ballot(pushed));
-		if (sq.count >= 64u) { // a full wave of shadow rays
-			sq.count -= 64u;
-			shadow_flush(L, a, sq, sq.count, 64u);
+		if (sq.count >= SSX_SQ_FLUSH_AT) { // a full wave of shadow rays
+			const uint32_t take = min(sq.count, 64u);
+			sq.count -= take;
+			shadow_flush(L, a, sq, sq.count, take);
 		}
 		// the previous unit's last paths are done: apply the parked shadow rays (some may be its), fold it
 		if (old_pending && !__any(active && p_tag == old_tag)) {
