@@ -2,7 +2,10 @@
 """bench.py -- Msamples/s of the spectral integrator on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 runs one process per GPU over RCCL: either launched by torch.distributed.run (the driver's way:
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or, when WORLD_SIZE is not set, this
+script spawns the N ranks itself (127.0.0.1 rendezvous) and relays rank 0's JSON line.
 
 A step = one full render of BASELINE.json configs[1] (cornell-srgb 512x512, hero-wavelength,
 CIE 1931, spp=256 per GPU): the 8x8 tile list is dealt round-robin over the N ranks, every rank
@@ -16,6 +19,8 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,47 +30,125 @@ sys.path.insert(0, ROOT)
 # Algorithmic FP32 work per sample, SURVEY.md section 8(d): 33*T + 28*P + 550*S + 150 with the
 # measured per-sample counts (T tri tests, P edge-test passes, S surface interactions).
 FLOP_PER_SAMPLE = {"cornell-srgb": 1.28e4, "cornell": 1.28e4, "plane-srgb": 2.8e3}
-# Algorithmic HBM bytes per sample of the path megakernel: the 32-byte
-# record is read and rewritten, and one 48-byte frame is written per continued bounce
-# (frames/sample = interactions that continue: 3.29 Cornell, 1 plane [oracle statistics]).
-FRAMES_PER_SAMPLE = {"cornell-srgb": 3.29, "cornell": 3.29, "plane-srgb": 1.0}
-SHADOW_RMW_BYTES = {"cornell-srgb": 80, "cornell": 80, "plane-srgb": 30}
+# Algorithmic HBM bytes per sample of the whole pipeline (SoA layout), with
+# L = continued levels per sample (3.35 Cornell, 1 plane: oracle statistics at 128x128 spp 16) and R = parked
+# shadow rays per sample (3.14 Cornell, 1.36 plane), V of them visible (2.69 / 1.33):
+#   generate  : write ray 16 + stream 16
+#   path      : read ray 16 + stream 16; per level write direct 16 (L+1 levels) + fs 16 + np 8 (L levels);
+#               at the end write {lambda, hit|levels, final stream state} 16
+#   shadow    : R x read direct 16 + V x write 16
+#   fold      : read stream 16 + direct 16 (L+1) + (fs 16 + np 8) L; write XYZA 16
+#   accumulate: read XYZA 16
+LEVELS = {"cornell-srgb": 3.35, "cornell": 3.35, "plane-srgb": 1.0}
+SHADOW = {"cornell-srgb": (3.14, 2.69), "cornell": (3.14, 2.69), "plane-srgb": (1.36, 1.33)}
 # gfx950 FP32 vector peak is 157.3 TFLOP/s counting FMA as 2; the parity contract forbids
 # contraction, so the ceiling that applies is the non-fused issue rate, half of it.
 PEAK_VALU_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(scene, W, H, texture, target_seconds=12.0):
-    """The CPU oracle (oracle/, a port of the reference's threaded tile renderer) on the host
-    cores of this box, on a bounded sample of the same workload."""
+def algorithmic_bytes_per_sample(scene):
+    L = LEVELS.get(scene, 3.35)
+    R, V = SHADOW.get(scene, (3.14, 2.69))
+    return 32 + (32 + 16 * (L + 1) + 24 * L + 16) + (16 * R + 16 * V) + (16 + 16 * (L + 1) + 24 * L + 16) + 16
+
+
+def host_cpu_info():
+    """What the CPU baseline may use: affinity mask, cgroup CPU quota, physical cores."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(p)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    phys = set()
+    model = ""
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pid = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":")[1].strip()
+                phys.add((pid, cid))
+            elif ln.startswith("model name") and not model:
+                model = ln.split(":")[1].strip()
+    except Exception:
+        pass
+    return {"affinity_threads": aff, "cgroup_quota_cpus": quota, "physical_cores": len(phys) or None, "model": model}
+
+
+def cpu_baseline(scene, W, H, texture, target_seconds=10.0):
+    """The CPU oracle (oracle/, a port of the reference's threaded tile renderer: 8x8 tile queue under a
+    mutex, src/renderer.cpp:340-409) on the host cores of this box, on a bounded sample of the same
+    workload: first one thread (a tile rectangle), then all usable threads (the whole image).
+    Usable = affinity mask, capped by the cgroup CPU quota when there is one."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as ol
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    info = host_cpu_info()
+    cores = info["affinity_threads"]
+    if info["cgroup_quota_cpus"]:
+        cores = max(1, min(cores, int(info["cgroup_quota_cpus"] + 0.5)))
+    cores = min(cores, 256)
     o = ol.Oracle(scene, texture=texture)
-    t = time.time()
-    o.render(W, H, 1, nthreads=cores)
-    t1 = max(time.time() - t, 1e-3)
-    spp = int(max(1, min(128, target_seconds / t1)))
-    t = time.time()
-    o.render(W, H, spp, nthreads=cores)
-    dt = time.time() - t
-    return {"value": round(W * H * spp / dt / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": "%s %dx%d spp=%d (%.1f s, oracle/libssx_oracle.so, %d threads, 8x8 tile queue)" % (scene, W, H, spp, dt, cores)}
+    # one thread: 64x64 pixels in the middle of the image
+    rect = (W // 2 - 32, H // 2 - 32, W // 2 + 32, H // 2 + 32) if W >= 64 and H >= 64 else (0, 0, W, H)
+    npx = (rect[2] - rect[0]) * (rect[3] - rect[1])
+    t = time.time(); o.render(W, H, 2, rect=rect, nthreads=1); t1 = max(time.time() - t, 1e-3)
+    spp1 = int(max(2, min(64, 2 * 2.5 / t1)))
+    t = time.time(); o.render(W, H, spp1, rect=rect, nthreads=1); dt1 = time.time() - t
+    rate1 = npx * spp1 / dt1 / 1e6
+    # all threads: the whole image
+    t = time.time(); o.render(W, H, 1, nthreads=cores); tn = max(time.time() - t, 1e-3)
+    spp = int(max(1, min(256, target_seconds / tn)))
+    t = time.time(); o.render(W, H, spp, nthreads=cores); dt = time.time() - t
+    rate = W * H * spp / dt / 1e6
+    phys = info["physical_cores"] or cores
+    return {"value": round(rate, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "one_thread": round(rate1, 4), "scaling_efficiency": round(rate / (rate1 * cores), 3),
+            "efficiency_vs_physical_cores": round(rate / (rate1 * min(cores, phys)), 3), "host": info,
+            "sample": "%s %dx%d spp=%d (%.1f s, oracle/libssx_oracle.so, %d threads, 8x8 tile queue); one thread: %d px x spp=%d (%.1f s)"
+                      % (scene, W, H, spp, dt, cores, npx, spp1, dt1)}
 
 
 def measured_traffic(args, world):
-    """HBM bytes per launch of the megakernel from the PMC passes (FETCH_SIZE, WRITE_SIZE collected
-    in separate rocprofv3 --pmc runs, FETCH_SIZE doubled per MI355X_MICROARCH.md for wide coalesced
-    reads), as recorded by tools/collect_traffic.py for this exact workload; None otherwise."""
+    """HBM bytes per launch of the pipeline's dominant kernel as recorded from rocprofv3 --pmc passes of
+    THIS workload (separate FETCH_SIZE / WRITE_SIZE passes, corrected with the factors calibrated on known
+    byte counts in the same access patterns: tools/profile_round.sh, tools/collect_traffic.py ->
+    profiles/traffic.json).  Replayed from that file: counters cannot be read from inside this process."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         t = json.load(open(path))
         key = "%s %d spp%d obs%d gpus%d" % (args.scene, args.res, args.spp, args.observer, world)
-        return t.get(key)
+        return t.get(key), t.get(key + " detail")
     except Exception:
-        return None
+        return None, None
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) ourselves."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, p.wait())
+    sys.exit(rc)
 
 
 def main():
@@ -78,9 +161,13 @@ def main():
     ap.add_argument("--spp", type=int, default=256, help="samples per pixel PER GPU")
     ap.add_argument("--observer", type=int, default=1931)
     ap.add_argument("--uplift", default="ours", choices=["ours", "jh"])
+    ap.add_argument("--texture", default="crystal-lizard-512.png", help="PNG under data/scenes, or procedural:N[:SEED]")
     ap.add_argument("--batch", type=int, default=0, help="spp per pipelined batch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
 
     import torch
     import torch.distributed as dist
@@ -91,8 +178,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: simple_spectral_amd has no CPU path")
     # SSX_BENCH_TEST_ONE_GPU=1: plumbing test of the N>1 path on a 1-GPU box (all ranks share
@@ -110,7 +196,7 @@ def main():
 
     W = H = args.res
     spp_total = args.spp * world
-    texture = "crystal-lizard-512.png"
+    texture = args.texture
     r = Renderer(Options(scene_name=args.scene, res=(W, H), spp=spp_total, texture=texture, device=local_rank,
                          tile_first=rank, tile_stride=world, seed=0, observer=args.observer, uplift=args.uplift,
                          spp_per_launch=args.batch))
@@ -140,8 +226,6 @@ def main():
         step()
     fence()
     r.set_timing(True)  # HIP events on the launch stream around each kernel of the pipeline
-    # kernel duration: HIP events on the launch stream around each render (memset + megakernel +
-    # finalize; the two small kernels are microseconds next to the megakernel)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -159,6 +243,10 @@ def main():
         tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cpu" if test_one_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(tt[0]), float(tt[1])
+    if os.environ.get("SSX_BENCH_DUMP"):  # tests: rank 0's combined image
+        if rank == 0:
+            import numpy as np
+            np.save(os.environ["SSX_BENCH_DUMP"], out.cpu().numpy())
 
     if rank == 0:
         samples_per_step = W * H * spp_total
@@ -166,12 +254,8 @@ def main():
         per_gpu_samples = W * H * args.spp
         flop = FLOP_PER_SAMPLE.get(args.scene, 1.28e4)
         achieved_tflops = per_gpu_samples * flop / (kernel_ms * 1e-3) / 1e12
-        # algorithmic HBM traffic of the path kernel per launch and sample: record read (32 B) + rewritten at the end
-        # of the path (32) + read again and overwritten with XYZA by the fold (32 + 16); 48-B frames written once and
-        # read once by the fold
-        # read once by the fold; ~3 parked shadow rays per Cornell sample read 16 B of their target and write it back
-        # when the light is visible
-        hbm_bytes = per_gpu_samples * (112 + 96 * FRAMES_PER_SAMPLE.get(args.scene, 3.29) + SHADOW_RMW_BYTES.get(args.scene, 80))
+        hbm_bytes = per_gpu_samples * algorithmic_bytes_per_sample(args.scene)
+        traffic, traffic_detail = measured_traffic(args, world)
         info = r.kernel_info()
         line = {
             "metric": "Msamples/s (w*h*spp/s) %s %dx%d" % (args.scene, W, H),
@@ -182,17 +266,25 @@ def main():
                        "parallelism": "tile-split x%d + RCCL reduce" % world if world > 1 else "single GPU",
                        "texture": texture, "seed": 0},
             "roofline": {"bound": "valu", "achieved": round(achieved_tflops, 3), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved_tflops / PEAK_VALU_TFLOPS, 4), "traffic": measured_traffic(args, world),
+                         "frac": round(achieved_tflops / PEAK_VALU_TFLOPS, 4),
+                         "traffic": traffic,
+                         "traffic_source": "replayed from profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, corrected by factors calibrated on known byte counts in the same access patterns; NOT measured in this run" if traffic else None,
+                         "traffic_detail": traffic_detail,
                          "kernel": "ssx_render_kernel", "kernel_ms": round(kernel_ms, 3),
                          "pipeline_ms": round(pipeline_ms, 3), "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
-                         "flop_per_sample": flop, "note": "FP32 VALU-issue bound, no MFMA, HBM idle by design; peak = 157.3/2 (no FMA contraction under the parity contract)",
-                         "hbm": {"achieved": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": round(hbm_bytes / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 7)},
+                         "flop_per_sample": flop,
+                         "note": "FP32 VALU-issue bound (no MFMA: traversal/sampling); peak = 157.3/2 TFLOP/s because the parity contract forbids FMA contraction. HBM is busy but not the limiter: see hbm.",
+                         "hbm": {"algorithmic_bytes_per_sample": round(algorithmic_bytes_per_sample(args.scene), 1),
+                                 "algorithmic_GBps": round(hbm_bytes / (pipeline_ms * 1e-3) / 1e9, 1),
+                                 "measured_GBps": round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None,
+                                 "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac_algorithmic": round(hbm_bytes / (pipeline_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                 "frac_measured": round(traffic / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else None},
                          "vgprs": info["vgprs"], "scratch_bytes": info["scratch_bytes"], "lds_bytes": info["lds_bytes"],
                          "plan": r.plan_info()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.scene, W, H, texture)
+            line["cpu_baseline"] = cpu_baseline(args.scene, W, H, texture if not texture.startswith("procedural:") else "crystal-lizard-512.png")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -180,6 +180,17 @@ int ssx_render_wait(ssx_ctx* ctx, float* xyza_out);
  * for the RCCL reduce).  hip_stream is a hipStream_t (NULL = default stream). */
 int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* params, void* d_xyza_out, void* hip_stream);
 
+/* ssx_render_start's result stays in a context-owned DEVICE buffer; these give the C++ host's multi-GPU
+ * combine access to it (north_star: "final reduce over xGMI of the per-GPU framebuffer"; the reference
+ * has one address space and no such step).  ssx_render_wait(ctx, NULL) skips the copy to the host. */
+void* ssx_device_framebuffer(ssx_ctx* ctx);            /* float4[width*height] on ctx's device, valid until the next render */
+int ssx_device_index(ssx_ctx* ctx);
+int ssx_read_framebuffer(ssx_ctx* ctx, float* xyza_out); /* device framebuffer -> host */
+/* d_dst (on ctx's device) += d_src (on HIP device src_device), both float4[width*height]: one
+ * hipMemcpyPeerAsync (device to device over xGMI) into a staging buffer + one add kernel.  Every pixel
+ * is nonzero on exactly one device (tile_first/tile_stride), so the sum is exact.  Synchronous. */
+int ssx_accumulate_peer(ssx_ctx* ctx, void* d_dst, int src_device, const void* d_src, uint32_t width, uint32_t height, void* hip_stream);
+
 /* Last error text for ctx (or for ssx_create when ctx is NULL). */
 const char* ssx_last_error(const ssx_ctx* ctx);
 
@@ -198,6 +209,29 @@ int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* s
  * the end of each wave's unit inside the path kernel (1) or as a streaming kernel of its own (0).
  * A performance choice only: both give the same bits. */
 int ssx_plan_info(ssx_ctx* ctx, float* frames_per_sample, int* fold_in_path_kernel);
+
+/* ---- Diagnostics for the parity tests (not part of the reference's interface) ---------------------
+ * ssx_debug_eval runs one building block of the path kernel -- the same device function the kernel
+ * inlines -- on n items, one per lane: `in` holds in_words 32-bit words per item, `out` receives
+ * out_words (<= 12) per item.  A scene must be uploaded (its tables are staged as in a render). */
+enum {
+	SSX_DBG_FMATH = 1,        /* in: x                                  out: sin, cos, acos, sincos.s, sincos.c (include/ssx_fmath.h) */
+	SSX_DBG_SPHTRI = 2,       /* in: A[3], B[3], C[3]                   out: b, cos_c, alpha, cos_alpha, area (src/util/spherical-tri.cpp:18-124) */
+	SSX_DBG_ARVO = 3,         /* in: A, B, C, b, cos_c, alpha, cos_alpha, area, rng[4]   out: dir[3], rng state lo, hi (src/util/random.cpp:101-154) */
+	SSX_DBG_SAMPLE_LIGHT = 4, /* in: from[3], rng[4]                    out: dir[3], light quad, pdf, rng state lo, hi (src/scene.cpp:417-431) */
+	SSX_DBG_COSHEMI = 5,      /* in: normal[3], rng[4]                  out: w_i[3], pdf, rng state lo, hi (src/util/random.cpp:29-49 + math-helpers.hpp:35-39) */
+	SSX_DBG_TRACE = 6,        /* in: orig[3], dir[3], ignore quad (int) out: quad (0xFFFFFFFF: none), triangle of the quad, dist, st[2] (src/scene.cpp:433-445) */
+	SSX_DBG_RAND_CHOICE = 7,  /* in: rng[4], n                          out: choice, rng state lo, hi (src/util/random.hpp:75-78) */
+	SSX_DBG_ALBEDO = 8,       /* in: quad, st[2], lambda_0              out: albedo[4] (src/material.cpp:45-143) */
+	SSX_DBG_FLUX_TO_XYZ = 9,  /* in: flux[4], lambda_0                  out: X, Y, Z (src/util/color.hpp:115-139) */
+	SSX_DBG_RAND_1F = 10      /* in: rng[4]                             out: rand_1f, rng state lo, hi (src/util/random.hpp:68-70) */
+};
+/* rng[4] = PCG32 {state lo, state hi, inc lo, inc hi} */
+int ssx_debug_eval(ssx_ctx* ctx, uint32_t op, const void* in, uint32_t in_words, void* out, uint32_t out_words, uint32_t n);
+/* One launch of the whole image (tile_first 0, tile_stride 1), per-sample results in [j][i][k] order:
+ * xyza = what Renderer::_render_sample returns (float4), rng_state = the sample's PCG32 state after its
+ * last draw (i.e. the number of draws consumed), levels = continued recursion levels.  Any may be NULL. */
+int ssx_debug_samples(ssx_ctx* ctx, const ssx_render_params* params, float* xyza, uint64_t* rng_state, uint32_t* levels);
 
 #ifdef __cplusplus
 }

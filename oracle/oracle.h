@@ -147,6 +147,15 @@ typedef struct {
 	uint64_t rays, tri_tests, tri_edge_pass, tri_f64, interactions, spectrum_lookups, tex_samples;
 	uint64_t path_len_hist[ORC_MAX_DEPTH + 1];
 	uint64_t samples, hits;
+	/* branch-coverage counters (tests prove that a crafted scene reached a rare branch):
+	 * spherical-tri.cpp:62-73 regular / :74-123 ladder (one side 0 or pi: alpha = pi/2 resp. acos) / all-NaN;
+	 * geometry.cpp:115 pdf = 1/0; random.cpp:116-131 denom == 0, :132-135 sin(alpha) <= 0; random.cpp:139-144
+	 * zero-length func_bar; random.cpp:29-49 retry; Lemire redraw (bits/uniform_int_dist.h) */
+	uint64_t sphtri_regular, sphtri_half_pi, sphtri_only_a, sphtri_nan;
+	uint64_t light_pdf_inf, arvo_denom_zero, arvo_sin_alpha_le0, funcbar_zero;
+	uint64_t coshemi_retries, lemire_redraws;
+	uint64_t nee_front, nee_visible; /* shadow rays started (n.l > 0), light seen */
+	uint64_t draws;                  /* PCG32 outputs consumed */
 } orc_stats;
 
 /* ---------- exported API (ctypes) ---------- */
@@ -172,6 +181,19 @@ float orc_meng_xyz_to_p(const orc_color*, float lambda, const float xyz[3]); /* 
  * tex_rgb/tex_w/tex_h: decoded RGB8 texture for the -srgb scenes (rows top-to-bottom). */
 orc_scene* orc_scene_create(const orc_color*, const char* name, const char* data_dir,
                             const uint8_t* tex_rgb, int tex_w, int tex_h, float light_scale);
+/* test hook: a scene from a flat description -- the fields the C ABI's ssx_scene_desc carries
+ * (Scene::primitives as quads v00,v10,v11,v01 + materials + spectra + textures + camera.matr_PV_inv / pos).
+ * Triangle normals (geometry.hpp:62-69), is_light (geometry.cpp:7-9) and the light list (scene.cpp:26-30)
+ * are derived as the reference derives them.  Spectral mode only. */
+typedef struct { float pos[4][3]; float st[4][2]; int material; } orc_quad_in;
+typedef struct { int kind, albedo_mode, albedo_spectrum, texture, emission_spectrum; } orc_material_in;
+typedef struct { int n; float low, high; const float* data; } orc_spectrum_in;
+typedef struct { int w, h; const uint8_t* rgb; } orc_texture_in;
+orc_scene* orc_scene_create_custom(const orc_color*, const double pv_inv[16], const float cam_pos[3],
+                                   const orc_spectrum_in* spectra, int n_spectra, const orc_material_in* mats, int n_mats,
+                                   const orc_texture_in* tex, int n_tex, const orc_quad_in* quads, int n_quads);
+void orc_scene_quad_normals(const orc_scene*, int quad, float out[6]); /* tri0, tri1 */
+int orc_scene_light(const orc_scene*, int i);                           /* Scene::lights[i] */
 void orc_scene_destroy(orc_scene*);
 /* test hook: change a material's kind (ORC_MTL_LAMBERTIAN / ORC_MTL_MIRROR), e.g. to build the
  * reference's non-ELS plane scene material (scene.cpp:346-355) or any mirror surface */
@@ -200,6 +222,7 @@ int orc_render(const orc_color*, const orc_scene*, uint64_t seed, size_t W, size
 void orc_xyza_to_srgba(const orc_color*, const float* xyza, float* srgba, size_t n);
 
 /* ---- unit-level entry points used by the per-function parity tests ---- */
+void orc_debug_set_stats(orc_stats*); /* branch counters of direct unit-level calls go here (NULL: off) */
 void orc_rng_seed_u32(orc_rng*, uint32_t v);                  /* random.hpp:39-42 */
 uint32_t orc_rng_next(orc_rng*);                              /* random.hpp:52-58 */
 float orc_rand_1f(orc_rng*);                                  /* random.hpp:68-70 */

@@ -7,6 +7,11 @@
 
 void orc_set_error(const char* fmt, const char* arg);
 
+/* branch-coverage counters: orc_render_sample points this at its stats block for the duration of a
+ * sample (NULL otherwise); the unit-level functions bump through it */
+extern __thread orc_stats* orc_tls_stats;
+#define ORC_COUNT(field) do { if (orc_tls_stats) orc_tls_stats->field++; } while (0)
+
 /* spectrum.cpp */
 int orc_spectrum_init(orc_spectrum* s, const float* data, int n, float low, float high);
 int orc_spectrum_init_const(orc_spectrum* s, float value, float lambda_min, float lambda_max);

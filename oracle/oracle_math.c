@@ -20,6 +20,9 @@ float orc_acosf(float x) { return ssx_acosf(x); }
 static float cos_via_double(float x) { return ssx_cosf(x); }
 #endif
 float orc_sqrtf(float x) { return __builtin_sqrtf(x); }
+__thread orc_stats* orc_tls_stats = NULL;
+/* test hook: branch counters for direct calls of the unit-level functions (calling thread only) */
+void orc_debug_set_stats(orc_stats* st) { orc_tls_stats = st; }
 
 /* ------------------------------------------------------------------ hashing ---- */
 /* stdafx.hpp:242-261, the sizeof(size_t)==8 branch (FNV-1a 64) on an integral item. */
@@ -42,6 +45,7 @@ uint32_t orc_rng_next(orc_rng* r) {
 	int rot = (int)(r->state >> 59u);
 	uint32_t result = (xorshifted >> rot) | (xorshifted << ((-rot) & 31));
 	r->state = r->state * 6364136223846793005ull + r->inc;
+	ORC_COUNT(draws);
 	return result;
 }
 
@@ -85,6 +89,7 @@ size_t orc_rand_choice(orc_rng* r, size_t length) {
 	if (low < range) {
 		uint32_t threshold = (uint32_t)(-range) % range;
 		while (low < threshold) {
+			ORC_COUNT(lemire_redraws);
 			product = (uint64_t)orc_rng_next(r) * (uint64_t)range;
 			low = (uint32_t)product;
 		}
@@ -117,7 +122,9 @@ orc_v3 orc_reflect(orc_v3 vec, orc_v3 normal) {
 orc_v3 orc_rand_coshemi(orc_rng* rng, float* pdf) {
 	const float pi = 3.14159265358979323846f;
 	orc_v3 result;
+	int tries = 0;
 	do {
+		if (tries++) ORC_COUNT(coshemi_retries);
 		float angle = orc_rand_1f(rng) * (2.0f * pi);
 		float c = orc_cosf(angle);
 		float s = orc_sinf(angle);
@@ -162,16 +169,19 @@ void orc_sphtri_make(orc_v3 A, orc_v3 B, orc_v3 C, orc_sphtri* t) {
 		t->gamma = f_clamp(orc_acosf(t->cos_gamma), 0.0f, under_pi);
 		t->surface_area = t->alpha + t->beta + t->gamma - pi;
 		if (t->surface_area >= 0); else t->surface_area = 0;
+		ORC_COUNT(sphtri_regular);
 		return;
 	}
 	t->surface_area = 0;
 	if (t->sin_a > 0) {
 		if (t->sin_b > 0) {
 			if (t->sin_c > 0) goto degenerate;
+			ORC_COUNT(sphtri_half_pi);
 			t->cos_alpha = t->cos_beta = 1; t->alpha = t->beta = pi * 0.5f;
 			t->cos_gamma = f_clamp(numer2 / denom2, -1.0f, 1.0f); t->gamma = orc_acosf(t->cos_gamma);
 		} else {
 			if (t->sin_c > 0) {
+				ORC_COUNT(sphtri_half_pi);
 				t->cos_alpha = t->cos_gamma = 1; t->alpha = t->gamma = pi * 0.5f;
 				t->cos_beta = f_clamp(numer1 / denom1, -1.0f, 1.0f); t->beta = orc_acosf(t->cos_beta);
 			} else goto degenerate;
@@ -179,6 +189,7 @@ void orc_sphtri_make(orc_v3 A, orc_v3 B, orc_v3 C, orc_sphtri* t) {
 	} else {
 		if (t->sin_b > 0) {
 			if (t->sin_c > 0) {
+				ORC_COUNT(sphtri_only_a);
 				t->cos_beta = t->cos_gamma = 1; t->beta = t->gamma = pi * 0.5f;
 				t->cos_alpha = f_clamp(numer0 / denom0, -1.0f, 1.0f); t->alpha = orc_acosf(t->cos_alpha);
 			} else goto degenerate;
@@ -186,6 +197,7 @@ void orc_sphtri_make(orc_v3 A, orc_v3 B, orc_v3 C, orc_sphtri* t) {
 	}
 	return;
 degenerate:
+	ORC_COUNT(sphtri_nan);
 	t->cos_alpha = t->cos_beta = t->cos_gamma = t->alpha = t->beta = t->gamma = nanv;
 }
 
@@ -193,7 +205,7 @@ degenerate:
 static orc_v3 func_bar(orc_v3 x, orc_v3 y) {
 	orc_v3 dir = v3_sub(x, v3_scale(v3_dot(x, y), y));
 	float lensq = v3_dot(dir, dir);
-	if (lensq == 0.0f) return v3_make(0, 0, 0);
+	if (lensq == 0.0f) { ORC_COUNT(funcbar_zero); return v3_make(0, 0, 0); }
 	float is = f_inversesqrt(lensq);
 	return v3_make(dir.x * is, dir.y * is, dir.z * is);
 }
@@ -212,8 +224,9 @@ orc_v3 orc_rand_toward_sphericaltri(orc_rng* rng, const orc_sphtri* tri) {
 		float v = s + sin_alpha * tri->cos_c;
 		float denom = (v * s + u * t) * sin_alpha;
 		if (denom != 0.0f) q = ((v * t - u * s) * tri->cos_alpha - v) / denom;
-		else q = tri->cos_c;
+		else { ORC_COUNT(arvo_denom_zero); q = tri->cos_c; }
 	} else {
+		ORC_COUNT(arvo_sin_alpha_le0);
 		/* random.cpp:134: unqualified `cos` on a float resolves to ::cos(double) */
 		q = cos_via_double(tri->b * r0);
 	}

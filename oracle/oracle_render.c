@@ -48,10 +48,12 @@ static orc_hero radiance_L(path_ctx* c, const orc_ray* ray, int last_was_delta, 
 				orc_scene_get_rand_toward_light(c->sc, c->rng, hit_pos, &shad_ray_dir, &light, &shad_pdf);
 				float n_dot_l = v3_dot(shad_ray_dir, hitrec.normal);
 				if (n_dot_l > 0.0f) {
+					ORC_COUNT(nee_front);
 					orc_ray ray_shad = { hit_pos, shad_ray_dir };
 					orc_hit hitrec_shad;
 					orc_scene_intersect(c->sc, &ray_shad, &hitrec_shad, hitrec.prim, c->st);
 					if (hitrec_shad.prim == light) {
+						ORC_COUNT(nee_visible);
 						const orc_material* lm = &c->sc->materials[c->sc->prims[hitrec_shad.prim].material];
 						float emitted[4], f_s[4];
 						orc_material_emission(c->cd, lm, c->lambda_0, emitted);
@@ -110,6 +112,8 @@ static void dmat4_mul_vec4(const double* m, const double v[4], double o[4]) {
 /* renderer.cpp:104-277 */
 void orc_render_sample(const orc_color* cd, const orc_scene* sc, orc_rng* rng, size_t i, size_t j,
                        size_t W, size_t H, int indirect_only, float out_xyza[4], orc_stats* st) {
+	orc_stats* const tls_saved = orc_tls_stats;
+	orc_tls_stats = st;
 	/* :113 glm::dvec2 subpixel(rand_1d(rng),rand_1d(rng)) -- g++ evaluates the constructor
 	 * arguments right to left, so .y takes the first two draws. */
 	double sub_y = orc_rand_1d(rng);
@@ -150,6 +154,7 @@ void orc_render_sample(const orc_color* cd, const orc_scene* sc, orc_rng* rng, s
 		st->path_len_hist[c.interactions]++;
 		st->spectrum_lookups += 3;
 	}
+	orc_tls_stats = tls_saved;
 }
 
 /* renderer.cpp:278-299 with the per-sample seeding contract; returns float(avg) XYZA */

@@ -111,6 +111,7 @@ static void tri_get_rand_toward(const orc_tri* tri, orc_rng* rng, orc_v3 from, o
 	                v3_normalize(v3_sub(tri->verts[2].pos, from)), &st);
 	*dir = orc_rand_toward_sphericaltri(rng, &st);
 	*pdf = 1.0f / st.surface_area;
+	if (st.surface_area == 0.0f) ORC_COUNT(light_pdf_inf);
 }
 /* geometry.cpp:141-145 */
 static void quad_get_rand_toward(const orc_quad* q, orc_rng* rng, orc_v3 from, orc_v3* dir, float* pdf) {
@@ -458,6 +459,60 @@ orc_scene* orc_scene_create(const orc_color* cd, const char* name, const char* d
 	scene_finish(sc);
 	return sc;
 }
+/* test hook (see oracle.h): flat description -> scene, derived data as the reference derives it */
+orc_scene* orc_scene_create_custom(const orc_color* cd, const double pv_inv[16], const float cam_pos[3],
+                                   const orc_spectrum_in* spectra, int n_spectra, const orc_material_in* mats, int n_mats,
+                                   const orc_texture_in* tex, int n_tex, const orc_quad_in* quads, int n_quads) {
+	if (cd->rgb_mode) { orc_set_error("%s", "custom scenes are spectral-mode only"); return NULL; }
+	orc_scene* sc = (orc_scene*)calloc(1, sizeof *sc);
+	sc->textures = (orc_texture*)calloc((size_t)(n_tex ? n_tex : 1), sizeof(orc_texture));
+	sc->n_textures = n_tex;
+	for (int i = 0; i < n_tex; ++i) {
+		sc->textures[i].w = tex[i].w; sc->textures[i].h = tex[i].h;
+		size_t bytes = (size_t)3 * (size_t)tex[i].w * (size_t)tex[i].h;
+		sc->textures[i].rgb = (uint8_t*)malloc(bytes);
+		memcpy(sc->textures[i].rgb, tex[i].rgb, bytes);
+	}
+	sc->materials = (orc_material*)calloc((size_t)(n_mats ? n_mats : 1), sizeof(orc_material));
+	sc->n_materials = n_mats;
+	for (int i = 0; i < n_mats; ++i) {
+		orc_material* m = &sc->materials[i];
+		const orc_material_in* in = &mats[i];
+		if (in->emission_spectrum < 0 || in->emission_spectrum >= n_spectra ||
+		    (in->albedo_mode == ORC_ALBEDO_CONSTANT && (in->albedo_spectrum < 0 || in->albedo_spectrum >= n_spectra)) ||
+		    (in->albedo_mode == ORC_ALBEDO_TEXTURE && (in->texture < 0 || in->texture >= n_tex))) {
+			orc_set_error("%s", "custom scene: material index out of range"); orc_scene_destroy(sc); return NULL;
+		}
+		m->kind = in->kind; m->albedo_mode = in->albedo_mode;
+		const orc_spectrum_in* e = &spectra[in->emission_spectrum];
+		orc_spectrum_init(&m->emission, e->data, e->n, e->low, e->high);
+		const orc_spectrum_in* a = &spectra[in->albedo_mode == ORC_ALBEDO_CONSTANT ? in->albedo_spectrum : in->emission_spectrum];
+		orc_spectrum_init(&m->albedo, a->data, a->n, a->low, a->high);
+		m->texture = in->albedo_mode == ORC_ALBEDO_TEXTURE ? &sc->textures[in->texture] : NULL;
+	}
+	for (int q = 0; q < n_quads; ++q) {
+		const orc_quad_in* in = &quads[q];
+		if (in->material < 0 || in->material >= n_mats) { orc_set_error("%s", "custom scene: quad material out of range"); orc_scene_destroy(sc); return NULL; }
+		orc_vertex v[4];
+		for (int k = 0; k < 4; ++k) v[k] = vtx(in->pos[k][0], in->pos[k][1], in->pos[k][2], in->st[k][0], in->st[k][1]);
+		scene_add_quad(sc, in->material, v[0], v[1], v[2], v[3]);
+	}
+	memcpy(sc->camera.matr_PV_inv, pv_inv, sizeof sc->camera.matr_PV_inv);
+	sc->camera.pos = v3_make(cam_pos[0], cam_pos[1], cam_pos[2]);
+	for (int p = 0; p < sc->n_prims; ++p) if (sc->prims[p].is_light) { /* scene.cpp:26-30 */
+		sc->lights = (int*)realloc(sc->lights, sizeof(int) * (size_t)(sc->n_lights + 1));
+		sc->lights[sc->n_lights++] = p;
+	}
+	if (sc->n_lights == 0) { orc_set_error("%s", "custom scene: no lights (scene.cpp:30 asserts !lights.empty())"); orc_scene_destroy(sc); return NULL; }
+	return sc;
+}
+void orc_scene_quad_normals(const orc_scene* sc, int quad, float out[6]) {
+	const orc_quad* q = &sc->prims[quad];
+	out[0] = q->tri0.normal.x; out[1] = q->tri0.normal.y; out[2] = q->tri0.normal.z;
+	out[3] = q->tri1.normal.x; out[4] = q->tri1.normal.y; out[5] = q->tri1.normal.z;
+}
+int orc_scene_light(const orc_scene* sc, int i) { return (i >= 0 && i < sc->n_lights) ? sc->lights[i] : -1; }
+
 void orc_scene_destroy(orc_scene* sc) {
 	if (!sc) return;
 	for (int i = 0; i < sc->n_materials; ++i) { orc_spectrum_free(&sc->materials[i].emission); orc_spectrum_free(&sc->materials[i].albedo); }

@@ -68,7 +68,12 @@ SSX_OK, SSX_ERR_DATA, SSX_ERR_ARG, SSX_ERR_SCENE, SSX_ERR_DEVICE, SSX_ERR_STATE 
 # every symbol include/ssx.h and include/ssx_host.h declare (tests check the libraries export them)
 HIP_SYMBOLS = ["ssx_create", "ssx_destroy", "ssx_upload_scene", "ssx_render_start", "ssx_render_stop",
                "ssx_is_rendering", "ssx_progress", "ssx_render_wait", "ssx_render_device", "ssx_last_error",
-               "ssx_abi_version", "ssx_kernel_info", "ssx_plan_info", "ssx_set_timing", "ssx_get_timing"]
+               "ssx_abi_version", "ssx_kernel_info", "ssx_plan_info", "ssx_set_timing", "ssx_get_timing",
+               "ssx_device_framebuffer", "ssx_device_index", "ssx_read_framebuffer", "ssx_accumulate_peer",
+               "ssx_debug_eval", "ssx_debug_samples"]
+# ssx_debug_eval ops (include/ssx.h)
+(SSX_DBG_FMATH, SSX_DBG_SPHTRI, SSX_DBG_ARVO, SSX_DBG_SAMPLE_LIGHT, SSX_DBG_COSHEMI, SSX_DBG_TRACE, SSX_DBG_RAND_CHOICE,
+ SSX_DBG_ALBEDO, SSX_DBG_FLUX_TO_XYZ, SSX_DBG_RAND_1F) = range(1, 11)
 HOST_SYMBOLS = ["ssh_scene_create", "ssh_scene_create_ex", "ssh_scene_destroy", "ssh_scene_desc", "ssh_xyza_to_srgba", "ssh_save_image",
                 "ssh_load_png_rgb8", "ssh_free", "ssh_color_values", "ssh_last_error"]
 
@@ -139,5 +144,12 @@ def hip_lib():
         lib.ssx_plan_info.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
         lib.ssx_set_timing.argtypes = [vp, C.c_int]
         lib.ssx_get_timing.argtypes = [vp, C.POINTER(C.c_float)]
+        lib.ssx_device_framebuffer.argtypes = [vp]
+        lib.ssx_device_framebuffer.restype = vp
+        lib.ssx_device_index.argtypes = [vp]
+        lib.ssx_read_framebuffer.argtypes = [vp, vp]
+        lib.ssx_accumulate_peer.argtypes = [vp, vp, C.c_int, vp, C.c_uint32, C.c_uint32, vp]
+        lib.ssx_debug_eval.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32]
+        lib.ssx_debug_samples.argtypes = [vp, C.POINTER(SsxRenderParams), vp, vp, vp]
         _hip = lib
     return _hip

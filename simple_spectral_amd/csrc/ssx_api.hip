@@ -2,6 +2,7 @@
 // kernels so the host launches them directly.  No CPU fallback of any kind lives here: every
 // entry point either drives the HIP kernels or returns an error.
 #include "ssx_kernels.hip"
+#include "ssx_debug.hip"
 
 #include "../../include/ssx.h"
 
@@ -43,9 +44,9 @@ struct ssx_ctx {
 	double* d_accum = nullptr;  size_t accum_pixels = 0;
 	uint32_t* d_unit_counter = nullptr; // work-unit counter of the path kernel's persistent waves
 	int resident_blocks = 0;            // 256-lane path-kernel workgroups the GPU holds at once
-	SsxSampleRecord* d_samples = nullptr; size_t sample_slots = 0; // record capacity of the sample buffer
-	SsxFrame* d_frames = nullptr;
+	uint8_t* d_samples = nullptr; size_t sample_slots = 0; // per-sample arrays (ssx_blob.h), one allocation; record capacity
 	float* d_out = nullptr;     size_t out_pixels = 0;
+	float* d_peer = nullptr;    size_t peer_pixels = 0; // staging buffer of ssx_accumulate_peer
 	bool have_scene = false;
 
 	std::thread worker;
@@ -67,21 +68,30 @@ struct ssx_ctx {
 	size_t ev_used = 0;
 	float stage_ms[4] = { 0, 0, 0, 0 };
 
+	// ssx_render_device returns with work still queued on the caller's stream that uses the ctx-owned buffers:
+	// later entry points wait for this event before they touch them
+	hipEvent_t ev_device_done = nullptr;
+	bool device_pending = false;
+
+	std::mutex error_mutex; // `error` is written by the worker thread and read by ssx_last_error
 	std::string error;
+	std::string error_out;  // what ssx_last_error hands out (stable until the next call)
 };
 
 namespace {
+
+void set_error(ssx_ctx* ctx, const std::string& msg) { std::lock_guard<std::mutex> g(ctx->error_mutex); ctx->error = msg; }
 
 #define SSX_HIP(ctx, call)                                                                          \
 	do {                                                                                            \
 		hipError_t e_ = (call);                                                                     \
 		if (e_ != hipSuccess) {                                                                     \
-			(ctx)->error = fmt("%s failed: %s", #call, hipGetErrorString(e_));                      \
+			set_error((ctx), fmt("%s failed: %s", #call, hipGetErrorString(e_)));                   \
 			return SSX_ERR_DEVICE;                                                                  \
 		}                                                                                           \
 	} while (0)
 
-int fail(ssx_ctx* ctx, int code, const std::string& msg) { ctx->error = msg; return code; }
+int fail(ssx_ctx* ctx, int code, const std::string& msg) { set_error(ctx, msg); return code; }
 
 uint32_t align4(uint32_t words) { return (words + 3u) & ~3u; }
 
@@ -124,18 +134,6 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	h.spec_basis_r = s->spec_basis_r; h.spec_basis_g = s->spec_basis_g; h.spec_basis_b = s->spec_basis_b;
 	h.n_textures = s->n_textures;
 	{
-		// R bounds every coordinate a ray origin or vertex can take: vertices and the camera (paths start at
-		// the camera and continue from points on the quads), with 1 % slack for the rounding of hit points
-		float R = 0.0f;
-		for (int k = 0; k < 3; ++k) R = std::max(R, std::fabs(s->cam_pos[k]));
-		for (uint32_t q = 0; q < s->n_quads; ++q) {
-			const ssx_vertex* vs[4] = { &s->quads[q].v00, &s->quads[q].v10, &s->quads[q].v11, &s->quads[q].v01 };
-			for (const ssx_vertex* v : vs) for (int k = 0; k < 3; ++k) R = std::max(R, std::fabs(v->pos[k]));
-		}
-		R *= 1.01f;
-		h.pass1_tol = 1024.0f * 5.9604644775390625e-8f * R * R;
-	}
-	{
 		const ssx_spectrum &r = s->spectra[s->spec_basis_r], &g = s->spectra[s->spec_basis_g], &b = s->spectra[s->spec_basis_b];
 		const ssx_spectrum &ox = s->spectra[s->spec_xbar], &oy = s->spectra[s->spec_ybar], &oz = s->spectra[s->spec_zbar];
 		h.observer_one_grid = (ox.n == oy.n && ox.n == oz.n && ox.low == oy.low && ox.low == oz.low && ox.delta_recip == oy.delta_recip && ox.delta_recip == oz.delta_recip) ? 1u : 0u;
@@ -150,10 +148,6 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	const uint32_t off_samples = off; off = align4(off + s->n_samples);
 	h.off_lut = off;       off = align4(off + 256u);
 	h.off_tex = off;       off = align4(off + s->n_textures * (uint32_t)(sizeof(SsxBlobTexture) / 4));
-#if defined(SSX_MFMA_PASS1) // experimental pass 1 on the matrix cores (ssx_kernels.hip, trace()): its edge table
-	const uint32_t n_mtiles = (s->n_quads + 3u) / 4u; // 8 edge rows per quad, 32 rows per MFMA row tile
-	h.off_plucker = off;   off = align4(off + n_mtiles * 3u * 64u);
-#endif
 	h.uplift = s->uplift;
 	if (s->uplift == SSX_UPLIFT_JH) {
 		h.jh_res = s->jh_res;
@@ -163,6 +157,7 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 		h.jh_data_lo = (uint32_t)(uintptr_t)d_jh; h.jh_data_hi = (uint32_t)((uint64_t)(uintptr_t)d_jh >> 32);
 	}
 	h.total_words = off;
+	// prefix + blob + the four waves' shadow-ray queues is what a path-kernel workgroup allocates (<= 64 KiB)
 	if ((size_t)off * 4 > SSX_BLOB_MAX_BYTES) return fail(ctx, SSX_ERR_SCENE, fmt("scene tables need %u bytes of LDS (max %u)", off * 4, SSX_BLOB_MAX_BYTES));
 
 	blob.assign(off, 0u);
@@ -200,29 +195,6 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 		bq[q].is_emissive = 0;
 		for (uint32_t k = 0; k < es.n; ++k) if (s->samples[es.offset + k] != 0.0f) bq[q].is_emissive = 1;
 	}
-#if defined(SSX_MFMA_PASS1)
-	{
-		// Pluecker rows of the directed triangle edges p->q: (p x q, q - p), in double, rounded once.  Row
-		// 8q+r: r = 0..2 edges ab, bc, ca of tri0 = (v00, v10, v11); r = 4..6 edges ac, cd, da of tri1 =
-		// (v00, v11, v01); r = 3, 7 zero.  Stored as the MFMA A operand: [row tile][K step][lane] = A[32t + lane%32][2s + lane/32].
-		float* pt = reinterpret_cast<float*>(blob.data() + h.off_plucker);
-		for (uint32_t t = 0; t < n_mtiles; ++t) for (uint32_t st = 0; st < 3; ++st) for (uint32_t lane = 0; lane < 64; ++lane) {
-			const uint32_t row = 32u * t + (lane & 31u), k = 2u * st + (lane >> 5);
-			const uint32_t q = row >> 3, r = row & 7u;
-			float v = 0.0f;
-			if (q < s->n_quads && (r & 3u) != 3u) {
-				const ssx_quad& Q = s->quads[q];
-				const float* tri[2][3] = { { Q.v00.pos, Q.v10.pos, Q.v11.pos }, { Q.v00.pos, Q.v11.pos, Q.v01.pos } };
-				const float* P = tri[r >> 2][r & 3u];
-				const float* Qv = tri[r >> 2][((r & 3u) + 1u) % 3u];
-				const double p0 = P[0], p1 = P[1], p2 = P[2], q0 = Qv[0], q1 = Qv[1], q2 = Qv[2];
-				const double row6[6] = { p1 * q2 - p2 * q1, p2 * q0 - p0 * q2, p0 * q1 - p1 * q0, q0 - p0, q1 - p1, q2 - p2 };
-				v = (float)row6[k];
-			}
-			pt[(3u * t + st) * 64u + lane] = v;
-		}
-	}
-#endif
 	memcpy(blob.data() + h.off_lights, s->lights, 4 * s->n_lights);
 	SsxBlobSpectrum* bs = reinterpret_cast<SsxBlobSpectrum*>(blob.data() + h.off_spectra);
 	for (uint32_t i = 0; i < s->n_spectra; ++i) {
@@ -270,8 +242,8 @@ int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
 
 // Every launch writes its samples to [tile slot][k][64] float4 (16 B per sample) and the ordered
 // accumulate pass consumes them; the buffer bounds how many samples per pixel one launch may cover.
-constexpr size_t kSampleBufferBudget = (size_t)32 << 30; // bytes: 32 B record + 9 x 48 B frames per sample in flight (288 GB HBM)
-constexpr size_t kBytesPerSampleInFlight = sizeof(SsxSampleRecord) + SSX_MAX_FRAMES * sizeof(SsxFrame);
+constexpr size_t kSampleBufferBudget = (size_t)32 << 30; // bytes of per-sample arrays one launch may use (288 GB HBM)
+constexpr size_t kBytesPerSampleInFlight = SSX_BYTES_PER_SAMPLE; // 408: ray 16 + stream 16 + 10 levels x 16 + 9 x (16 + 8)
 constexpr uint32_t kMinUnits = 3072;                   // one wave work unit per wave slot of the GPU (256 CUs x 4 SIMDs x 3 waves)
 
 struct LaunchPlan { SsxKernelArgs args; size_t lds_bytes; uint32_t max_spp_per_launch; };
@@ -292,7 +264,16 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	a.my_tiles = a.n_tiles > p->tile_first ? (a.n_tiles - p->tile_first + p->tile_stride - 1u) / p->tile_stride : 0u;
 	pl.lds_bytes = ((size_t)ctx->blob_words + SSX_LDS_PREFIX_WORDS) * 4;
 	size_t per_spp = (size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u * kBytesPerSampleInFlight;
-	size_t cap = kSampleBufferBudget / per_spp;
+	// the budget, or 80 % of what is free on the device right now (plus what this context already holds)
+	size_t budget = kSampleBufferBudget, free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+		const size_t avail = (size_t)((double)(free_b + ctx->sample_slots * kBytesPerSampleInFlight) * 0.8);
+		if (avail < budget) budget = avail;
+	}
+	size_t cap = budget / per_spp;
+	// level indices l*n + r are 32-bit in the kernels
+	const size_t idx_cap = ((size_t)0xFFFFFFFFu / SSX_MAX_LEVELS) / ((size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u);
+	if (cap > idx_cap) cap = idx_cap;
 	pl.max_spp_per_launch = (uint32_t)(cap < 1 ? 1 : (cap > 65536 ? 65536 : cap));
 	return pl;
 }
@@ -301,13 +282,22 @@ int ensure_samples(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t n_k) {
 	size_t need = (size_t)pl.args.my_tiles * 64u * n_k;
 	if (ctx->sample_slots < need) {
 		if (ctx->d_samples) (void)hipFree(ctx->d_samples);
-		if (ctx->d_frames) (void)hipFree(ctx->d_frames);
-		ctx->d_samples = nullptr; ctx->d_frames = nullptr; ctx->sample_slots = 0;
-		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_samples, need * sizeof(SsxSampleRecord)));
-		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_frames, need * SSX_MAX_FRAMES * sizeof(SsxFrame)));
+		ctx->d_samples = nullptr; ctx->sample_slots = 0;
+		hipError_t e = hipMalloc((void**)&ctx->d_samples, need * kBytesPerSampleInFlight);
+		if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(ctx, SSX_ERR_DEVICE, fmt("out of device memory for %zu samples in flight; lower spp_per_launch", need)); }
+		SSX_HIP(ctx, e);
 		ctx->sample_slots = need;
 	}
 	return SSX_OK;
+}
+
+// the per-sample arrays of one batch inside a region of `cap` records starting at `base` (ssx_blob.h)
+void bind_arrays(SsxKernelArgs& a, uint8_t* base, uint64_t cap) {
+	a.ray = reinterpret_cast<float4*>(base);                      base += cap * 16u;
+	a.st = reinterpret_cast<uint4*>(base);                        base += cap * 16u;
+	a.direct = reinterpret_cast<float4*>(base);                   base += cap * 16u * SSX_MAX_LEVELS;
+	a.fs = reinterpret_cast<float4*>(base);                       base += cap * 16u * SSX_MAX_FRAMES;
+	a.np = reinterpret_cast<float2*>(base);
 }
 
 // adds the stage durations of the recorded batches to ctx->stage_ms
@@ -350,9 +340,10 @@ Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1, u
 	SsxKernelArgs& a = b.a;
 	const uint32_t n_k = k1 - k0;
 	a.k0 = k0; a.k1 = k1;
-	a.samples = ctx->d_samples + rec_off;
-	a.frames = ctx->d_frames + rec_off * SSX_MAX_FRAMES;
 	a.n_records = (uint64_t)a.my_tiles * n_k * 64u;
+	// rec_off = 0, or the first record of the second half of a double-buffered allocation: each half is a
+	// region of its own (capacity = records of a full batch >= this batch)
+	bind_arrays(a, ctx->d_samples + rec_off * kBytesPerSampleInFlight, rec_off ? rec_off : a.n_records);
 	// 8 samples per pixel and unit (512 items: enough for the refill, and short units balance the end of
 	// the launch; measured best of 1..64 with persistent waves) unless the launch is so small that this
 	// would leave SIMDs without a wave (3 waves x 1024 SIMDs)
@@ -367,14 +358,6 @@ Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1, u
 }
 
 int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stream, bool calibration = false) {
-#ifdef SSX_PROFILE_REGIONS
-	{
-		static uint64_t* d_prof = nullptr;
-		if (!d_prof) { SSX_HIP(ctx, hipMalloc((void**)&d_prof, 16 * sizeof(uint64_t))); }
-		SSX_HIP(ctx, hipMemsetAsync(d_prof, 0, 16 * sizeof(uint64_t), stream));
-		b.a.prof = d_prof;
-	}
-#endif
 	if (ctx->timing) { int r = timing_events(ctx, &b.tev); if (r) return r; SSX_HIP(ctx, hipEventRecord(b.tev[0], stream)); }
 	hipLaunchKernelGGL(ssx_generate_kernel, dim3((uint32_t)((b.n_rec + 255u) / 256u)), dim3(256), 0, stream, b.a);
 	SSX_HIP(ctx, hipGetLastError());
@@ -411,17 +394,6 @@ int enqueue_back(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t strea
 	hipLaunchKernelGGL(ssx_accumulate_kernel, dim3((b.a.my_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, b.a, ctx->d_accum);
 	SSX_HIP(ctx, hipGetLastError());
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[5], stream));
-#ifdef SSX_PROFILE_REGIONS
-	{
-		uint64_t h[16];
-		SSX_HIP(ctx, hipStreamSynchronize(stream));
-		SSX_HIP(ctx, hipMemcpy(h, b.a.prof, sizeof h, hipMemcpyDeviceToHost));
-		static const char* names[12] = { "refill", "trace_primary", "hit+albedo", "sample_light", "trace_shadow", "nee_contrib", "bsdf_sample", "frame_push", "finish/fold", "total_wave_cycles", "wave_iterations", "active_lanes" };
-		fprintf(stderr, "[region profile] ");
-		for (int r = 0; r < 12; ++r) fprintf(stderr, "%s=%llu ", names[r], (unsigned long long)h[r]);
-		fprintf(stderr, "\n");
-	}
-#endif
 	return SSX_OK;
 }
 
@@ -480,20 +452,21 @@ int calibrate(ssx_ctx* ctx) {
 	ctx->timing = timing;
 	if (rc) return rc;
 	SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	std::vector<SsxSampleRecord> recs((size_t)b.n_rec);
-	SSX_HIP(ctx, hipMemcpy(recs.data(), ctx->d_samples, recs.size() * sizeof(SsxSampleRecord), hipMemcpyDeviceToHost));
+	std::vector<uint4> recs((size_t)b.n_rec);
+	SSX_HIP(ctx, hipMemcpy(recs.data(), b.a.st, recs.size() * sizeof(uint4), hipMemcpyDeviceToHost));
 	uint64_t frames = 0;
-	for (const SsxSampleRecord& r : recs) frames += r.b.z;
+	for (const uint4& r : recs) frames += r.y >> 8;
 	ctx->calib_frames = (float)((double)frames / (double)recs.size());
 	ctx->fuse_resolve = ctx->calib_frames >= 2.0f;
 	return SSX_OK;
 }
 
-int launch_finalize(ssx_ctx* ctx, const ssx_render_params* p, float* d_out, hipStream_t stream) {
+// `spp` = the samples per pixel actually accumulated (Options::spp, or fewer after ssx_render_stop)
+int launch_finalize(ssx_ctx* ctx, const ssx_render_params* p, uint32_t spp, float* d_out, hipStream_t stream) {
 	uint32_t pixels = p->width * p->height;
 	hipLaunchKernelGGL(ssx_finalize_kernel, dim3((pixels + 255u) / 256u), dim3(256), 0, stream,
 	                   (const double*)ctx->d_accum, (float4*)d_out, p->width, p->height, (p->width + 7u) / 8u,
-	                   p->tile_first, p->tile_stride, p->spp, ctx->rgb_mode ? 1u : 0u);
+	                   p->tile_first, p->tile_stride, spp, ctx->rgb_mode ? 1u : 0u);
 	SSX_HIP(ctx, hipGetLastError());
 	return SSX_OK;
 }
@@ -523,9 +496,12 @@ void worker_main(ssx_ctx* ctx) {
 			SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 			ctx->done_spp.store(k1);
 		}
-		// like the reference's last worker (renderer.cpp:388-394) the image is produced even after
-		// a stop; pixels hold the mean over Options::spp of the samples accumulated so far.
-		int r = launch_finalize(ctx, &p, ctx->d_out, ctx->stream);
+		// like the reference's last worker (renderer.cpp:388-394) the image is produced even after a
+		// stop.  The reference then holds finished tiles next to untouched ones; here every pixel holds
+		// the mean of the samples accumulated so far (divisor = samples done, not Options::spp), i.e. a
+		// noisier image of the right brightness with alpha as after a full render.
+		const uint32_t done = ctx->done_spp.load();
+		int r = launch_finalize(ctx, &p, done ? done : p.spp, ctx->d_out, ctx->stream);
 		if (r) return r;
 		SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		return SSX_OK;
@@ -541,7 +517,13 @@ extern "C" {
 
 int ssx_abi_version(void) { return SSX_ABI_VERSION; }
 
-const char* ssx_last_error(const ssx_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+const char* ssx_last_error(const ssx_ctx* ctx) {
+	if (!ctx) return g_create_error.c_str();
+	ssx_ctx* c = const_cast<ssx_ctx*>(ctx);
+	std::lock_guard<std::mutex> g(c->error_mutex);
+	c->error_out = c->error;
+	return c->error_out.c_str();
+}
 
 int ssx_create(int device, ssx_ctx** out) {
 	if (!out) { g_create_error = "out is NULL"; return SSX_ERR_ARG; }
@@ -580,8 +562,9 @@ void ssx_destroy(ssx_ctx* ctx) {
 	if (ctx->d_accum) (void)hipFree(ctx->d_accum);
 	if (ctx->d_unit_counter) (void)hipFree(ctx->d_unit_counter);
 	if (ctx->d_samples) (void)hipFree(ctx->d_samples);
-	if (ctx->d_frames) (void)hipFree(ctx->d_frames);
+	if (ctx->ev_device_done) (void)hipEventDestroy(ctx->ev_device_done);
 	if (ctx->d_out) (void)hipFree(ctx->d_out);
+	if (ctx->d_peer) (void)hipFree(ctx->d_peer);
 	for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
 	for (hipEvent_t e : { ctx->ev_start, ctx->ev_front[0], ctx->ev_front[1], ctx->ev_back[0], ctx->ev_back[1] }) if (e) (void)hipEventDestroy(e);
 	if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
@@ -602,6 +585,7 @@ int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 	if (ctx->rendering.load()) return fail(ctx, SSX_ERR_STATE, "render in progress");
 	SSX_HIP(ctx, hipSetDevice(ctx->device));
 	SSX_HIP(ctx, hipDeviceSynchronize());
+	ctx->device_pending = false;
 	for (uint8_t* t : ctx->d_textures) (void)hipFree(t);
 	ctx->d_textures.clear();
 	ctx->have_scene = false;
@@ -671,6 +655,19 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	hipStream_t stream = (hipStream_t)hip_stream;
 	SSX_HIP(ctx, hipSetDevice(ctx->device));
 	size_t pixels = (size_t)p->width * p->height;
+	// the context's accumulators and per-sample arrays are shared by all renders: a render still queued by an
+	// earlier call (possibly on another stream) has to finish first.  Stream-ordered, no host wait -- unless
+	// a buffer has to grow, which frees the old one.
+	if (!ctx->ev_device_done) SSX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_device_done, hipEventDisableTiming));
+	if (ctx->device_pending) SSX_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_device_done, 0));
+	{
+		LaunchPlan probe = make_plan(ctx, p);
+		const size_t need = (size_t)probe.args.my_tiles * 64u * (p->spp < probe.max_spp_per_launch ? p->spp : probe.max_spp_per_launch);
+		if (ctx->device_pending && (ctx->accum_pixels < pixels || ctx->sample_slots < need)) {
+			SSX_HIP(ctx, hipEventSynchronize(ctx->ev_device_done));
+			ctx->device_pending = false;
+		}
+	}
 	if ((rc = ensure_buffers(ctx, pixels, false))) return rc;
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, pixels * 4 * sizeof(double), stream));
 	LaunchPlan pl = make_plan(ctx, p);
@@ -686,7 +683,10 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	}
 	if ((rc = ensure_samples(ctx, pl, batch * (batch < p->spp ? 2u : 1u)))) return rc;
 	if ((rc = launch_pipelined(ctx, pl, p->spp, batch, stream))) return rc;
-	return launch_finalize(ctx, p, (float*)d_xyza_out, stream);
+	if ((rc = launch_finalize(ctx, p, p->spp, (float*)d_xyza_out, stream))) return rc;
+	SSX_HIP(ctx, hipEventRecord(ctx->ev_device_done, stream));
+	ctx->device_pending = true;
+	return SSX_OK;
 }
 
 int ssx_render_start(ssx_ctx* ctx, const ssx_render_params* p) {
@@ -696,6 +696,7 @@ int ssx_render_start(ssx_ctx* ctx, const ssx_render_params* p) {
 	if (ctx->rendering.load()) return fail(ctx, SSX_ERR_STATE, "render already in progress");
 	if (ctx->worker.joinable()) ctx->worker.join();
 	SSX_HIP(ctx, hipSetDevice(ctx->device));
+	if (ctx->device_pending) { SSX_HIP(ctx, hipEventSynchronize(ctx->ev_device_done)); ctx->device_pending = false; } // a queued ssx_render_device uses the same buffers
 	if ((rc = ensure_buffers(ctx, (size_t)p->width * p->height, true))) return rc;
 	ctx->cur = *p;
 	ctx->total_spp = p->spp;
@@ -749,13 +750,104 @@ int ssx_get_timing(ssx_ctx* ctx, float stage_ms[4]) {
 	return SSX_OK;
 }
 
-#ifdef SSX_PROFILE_CANDS
-int ssx_cand_stats(unsigned long long out[4], int reset) {
-	if (reset) { unsigned long long z[4] = { 0, 0, 0, 0 }; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cand_stats), z, sizeof z); }
-	(void)hipDeviceSynchronize();
-	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cand_stats), 4 * sizeof(unsigned long long));
+int ssx_read_framebuffer(ssx_ctx* ctx, float* xyza_out) {
+	if (!ctx || !xyza_out) return SSX_ERR_ARG;
+	if (ctx->rendering.load()) return fail(ctx, SSX_ERR_STATE, "render in progress");
+	if (!ctx->d_out || ctx->cur.width == 0) return fail(ctx, SSX_ERR_STATE, "no render was started");
+	SSX_HIP(ctx, hipSetDevice(ctx->device));
+	SSX_HIP(ctx, hipMemcpy(xyza_out, ctx->d_out, (size_t)ctx->cur.width * ctx->cur.height * 4 * sizeof(float), hipMemcpyDeviceToHost));
+	return SSX_OK;
 }
-#endif
+
+void* ssx_device_framebuffer(ssx_ctx* ctx) { return ctx ? ctx->d_out : nullptr; }
+
+int ssx_device_index(ssx_ctx* ctx) { return ctx ? ctx->device : -1; }
+
+int ssx_accumulate_peer(ssx_ctx* ctx, void* d_dst, int src_device, const void* d_src, uint32_t width, uint32_t height, void* hip_stream) {
+	if (!ctx || !d_dst || !d_src || width == 0 || height == 0) return SSX_ERR_ARG;
+	hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+	SSX_HIP(ctx, hipSetDevice(ctx->device));
+	const size_t pixels = (size_t)width * height, bytes = pixels * 4 * sizeof(float);
+	if (ctx->peer_pixels < pixels) {
+		if (ctx->d_peer) (void)hipFree(ctx->d_peer);
+		ctx->d_peer = nullptr; ctx->peer_pixels = 0;
+		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_peer, bytes));
+		ctx->peer_pixels = pixels;
+	}
+	if (src_device != ctx->device) {
+		int can = 0;
+		SSX_HIP(ctx, hipDeviceCanAccessPeer(&can, ctx->device, src_device));
+		if (can) { hipError_t e = hipDeviceEnablePeerAccess(src_device, 0); if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) SSX_HIP(ctx, e); (void)hipGetLastError(); }
+	}
+	// device-to-device over xGMI (the runtime stages through the host only when peer access is unavailable)
+	SSX_HIP(ctx, hipMemcpyPeerAsync(ctx->d_peer, ctx->device, d_src, src_device, bytes, stream));
+	hipLaunchKernelGGL(ssx_sum_kernel, dim3((uint32_t)((pixels + 255u) / 256u)), dim3(256), 0, stream, (float4*)d_dst, (const float4*)ctx->d_peer, (uint32_t)pixels);
+	SSX_HIP(ctx, hipGetLastError());
+	SSX_HIP(ctx, hipStreamSynchronize(stream));
+	return SSX_OK;
+}
+
+// ---- diagnostics for the parity tests (never called during a normal render) ----------------------
+
+int ssx_debug_eval(ssx_ctx* ctx, uint32_t op, const void* in, uint32_t in_words, void* out, uint32_t out_words, uint32_t n) {
+	if (!ctx || !in || !out || in_words == 0 || out_words == 0 || out_words > 12u || n == 0) return SSX_ERR_ARG;
+	if (!ctx->have_scene) return fail(ctx, SSX_ERR_STATE, "no scene uploaded");
+	if (ctx->rendering.load()) return fail(ctx, SSX_ERR_STATE, "render in progress");
+	SSX_HIP(ctx, hipSetDevice(ctx->device));
+	uint32_t *d_in = nullptr, *d_out = nullptr;
+	SSX_HIP(ctx, hipMalloc((void**)&d_in, (size_t)n * in_words * 4));
+	SSX_HIP(ctx, hipMalloc((void**)&d_out, (size_t)n * out_words * 4));
+	int rc = SSX_OK;
+	auto run = [&]() -> int {
+		SSX_HIP(ctx, hipMemcpy(d_in, in, (size_t)n * in_words * 4, hipMemcpyHostToDevice));
+		SsxKernelArgs a{};
+		a.blob = ctx->d_blob; a.blob_words = ctx->blob_words; a.rgb_mode = ctx->rgb_mode ? 1u : 0u;
+		const size_t lds = ((size_t)ctx->blob_words + SSX_LDS_PREFIX_WORDS) * 4;
+		hipLaunchKernelGGL(ssx_debug_eval_kernel, dim3((n + 255u) / 256u), dim3(256), lds, ctx->stream, a, op, d_in, in_words, d_out, out_words, n);
+		SSX_HIP(ctx, hipGetLastError());
+		SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		SSX_HIP(ctx, hipMemcpy(out, d_out, (size_t)n * out_words * 4, hipMemcpyDeviceToHost));
+		return SSX_OK;
+	};
+	rc = run();
+	(void)hipFree(d_in); (void)hipFree(d_out);
+	return rc;
+}
+
+int ssx_debug_samples(ssx_ctx* ctx, const ssx_render_params* p, float* xyza, uint64_t* rng_state, uint32_t* levels) {
+	if (!ctx) return SSX_ERR_ARG;
+	int rc = check_params(ctx, p);
+	if (rc) return rc;
+	if (ctx->rendering.load()) return fail(ctx, SSX_ERR_STATE, "render in progress");
+	if (p->tile_first != 0 || p->tile_stride != 1) return fail(ctx, SSX_ERR_ARG, "ssx_debug_samples renders the whole image");
+	SSX_HIP(ctx, hipSetDevice(ctx->device));
+	if (ctx->device_pending) { SSX_HIP(ctx, hipEventSynchronize(ctx->ev_device_done)); ctx->device_pending = false; }
+	const size_t pixels = (size_t)p->width * p->height;
+	if ((rc = ensure_buffers(ctx, pixels, false))) return rc;
+	LaunchPlan pl = make_plan(ctx, p);
+	if (p->spp > pl.max_spp_per_launch) return fail(ctx, SSX_ERR_ARG, "ssx_debug_samples: too many samples for one launch");
+	if ((rc = ensure_samples(ctx, pl, p->spp))) return rc;
+	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, pixels * 4 * sizeof(double), ctx->stream));
+	Batch b = make_batch(ctx, pl, 0, p->spp, 0);
+	if ((rc = enqueue_front(ctx, pl, b, ctx->stream))) return rc;
+	if ((rc = enqueue_back(ctx, pl, b, ctx->stream))) return rc; // fold (if not fused) + accumulate: ray[] holds XYZA afterwards
+	SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	std::vector<float4> ray((size_t)b.n_rec);
+	std::vector<uint4> st((size_t)b.n_rec);
+	SSX_HIP(ctx, hipMemcpy(ray.data(), b.a.ray, ray.size() * sizeof(float4), hipMemcpyDeviceToHost));
+	SSX_HIP(ctx, hipMemcpy(st.data(), b.a.st, st.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+	const uint32_t spp = p->spp, tiles_x = (p->width + 7u) / 8u;
+	for (uint32_t j = 0; j < p->height; ++j) for (uint32_t i = 0; i < p->width; ++i) {
+		const uint32_t tile = (j >> 3) * tiles_x + (i >> 3), lane = (j & 7u) * 8u + (i & 7u);
+		for (uint32_t k = 0; k < spp; ++k) {
+			const size_t r = ((size_t)tile * spp + k) * 64u + lane, o = ((size_t)j * p->width + i) * spp + k;
+			if (xyza) { xyza[4 * o + 0] = ray[r].x; xyza[4 * o + 1] = ray[r].y; xyza[4 * o + 2] = ray[r].z; xyza[4 * o + 3] = ray[r].w; }
+			if (rng_state) rng_state[o] = ((uint64_t)st[r].w << 32) | st[r].z;
+			if (levels) levels[o] = st[r].y >> 8;
+		}
+	}
+	return SSX_OK;
+}
 
 int ssx_plan_info(ssx_ctx* ctx, float* frames_per_sample, int* fold_in_path_kernel) {
 	if (!ctx) return SSX_ERR_ARG;

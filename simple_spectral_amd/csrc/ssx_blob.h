@@ -7,17 +7,14 @@
 #include <stdint.h>
 #include <hip/hip_runtime.h>
 
-#define SSX_BLOB_MAX_BYTES (40u * 1024u)
 // per-wave LDS scratch of the path kernel: the queue of parked shadow rays (ShadowQ in ssx_kernels.hip),
-// 128 entries x 12 words = 6 KB; a 256-lane workgroup takes blob + 24 KB, so three fit a CU's 160 KB for
-// blobs up to 29 KB
-#if defined(SSX_MFMA_PASS1)
-#define SSX_WAVE_SCRATCH_WORDS (116u * 12u)
-#else
+// 128 entries x 12 words = 6 KB; a 256-lane workgroup takes prefix + blob + 24 KB: four fit a CU's 160 KB
+// for blobs up to 15.6 KB (CIE 1931 tables), three up to 29 KB (CIE 2006)
 #define SSX_WAVE_SCRATCH_WORDS (128u * 12u)
-#endif
 // dynamic LDS of the kernels that stage the blob: [coefficient table of ssx_fmath.h][blob][wave scratch]
 #define SSX_LDS_PREFIX_WORDS 80u
+// prefix + blob + 4 queues must fit the 64 KiB a workgroup may allocate: 65536 - 320 - 24576 = 40640
+#define SSX_BLOB_MAX_BYTES 40640u
 
 // Permuted vertex table: for quad q and axis permutation p (0..5) the 12 floats
 //   v00[kx] v00[ky]  v10[kx] v10[ky]  v11[kx] v11[ky]  v01[kx] v01[ky] | v00[kz] v10[kz] v11[kz] v01[kz]
@@ -62,9 +59,8 @@ struct SsxBlobHeader {
 	uint32_t basis_one_grid; // the three basis tables share (low, delta_recip, n)
 	// Jakob-Hanika uplift (uplift == 3): scale[jh_res] in the blob, coefficient table in HBM
 	uint32_t uplift, jh_res, off_jh_scale, jh_data_lo, jh_data_hi;
-	float pass1_tol;  // tolerance of the conservative edge-function filter: 1024 * 2^-24 * R^2
 	uint32_t observer_one_grid; // the three observer tables share (low, delta_recip, n)
-	uint32_t off_plucker;       // MFMA pass 1: Pluecker coordinates of the triangle edges, [row tile][K step][lane] (see trace())
+	uint32_t pad_[2];
 };
 static_assert(sizeof(SsxBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 
@@ -72,19 +68,21 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 	uint32_t ptr_lo, ptr_hi, w, h;
 };
 
-// One sample in flight, 32 bytes, layout [tile slot][k-k0][pixel in tile].
-//   after ssx_generate_kernel: a = {camera ray dir.xyz, lambda_0}, b = PCG32 {state, inc}
-//   after ssx_render_kernel  : a = radiance of the deepest level, b = {lambda_0 bits, hit_anything, #frames, 0}
-//   after ssx_resolve_kernel : a = {X, Y, Z, alpha}
-struct SsxSampleRecord { float4 a; uint4 b; };
-static_assert(sizeof(SsxSampleRecord) == 32, "layout");
-
-// One level of the recursion L() of one sample (48 B): direct = emission + next-event estimate,
-// and the factors of the continuation  rad_d = direct + ((rad_{d+1} * n_dot_l) * f_s) / pdf.
-// Layout [depth][record]; written by the path kernel, read once by ssx_resolve_kernel.
-struct SsxFrame { float4 direct; float4 f_s; float2 np; float2 pad; };
-static_assert(sizeof(SsxFrame) == 48, "layout");
-#define SSX_MAX_FRAMES 9u  // depths 0..MAX_DEPTH-2 can continue (MAX_DEPTH-3 with explicit light sampling)
+// Per-sample state in HBM, structure of arrays over the launch's records r = [tile slot][k-k0][pixel in
+// tile] (a wave touches 64 consecutive records, so every array is read and written in full lines):
+//   ray[r]   float4  generate: {camera ray dir.xyz, lambda_0}; the fold overwrites it with {X, Y, Z, alpha}
+//                    ({R, G, B, alpha} in RGB mode), which the accumulate pass reads
+//   st[r]    uint4   generate: PCG32 {state, inc}; at the end of the path: {lambda_0 bits, hit_anything |
+//                    #levels << 8, final PCG32 state} (the final state = draws consumed, for the per-sample tests)
+//   direct[l*n + r] float4  level l of the recursion L(): emission + next-event estimate (a parked shadow ray
+//                    adds its contribution here later); for the path's last level the level's whole radiance
+//   fs[l*n + r]     float4  f_s of the continuation       } rad_l = direct_l + ((rad_{l+1} * n_dot_l) * f_s) / pdf
+//   np[l*n + r]     float2  {n_dot_l, pdf}                }
+// Levels 0..MAX_DEPTH-2 can continue (0..MAX_DEPTH-3 with explicit light sampling), the last level of a path is
+// at most MAX_DEPTH-1: 10 levels of `direct`, 9 of `fs` / `np`.
+#define SSX_MAX_FRAMES 9u
+#define SSX_MAX_LEVELS 10u
+#define SSX_BYTES_PER_SAMPLE (16u + 16u + 16u * SSX_MAX_LEVELS + (16u + 8u) * SSX_MAX_FRAMES)
 
 struct SsxKernelArgs {
 	const uint32_t* blob;   // device copy of the scene blob
@@ -99,10 +97,12 @@ struct SsxKernelArgs {
 	uint32_t group_spp;     // samples per pixel in one wave's work unit
 	uint32_t n_groups;      // ceil((k1-k0)/group_spp)
 	uint64_t seed;
-	SsxSampleRecord* samples; // [tile slot][k-k0][64] records of this launch
-	SsxFrame* frames;         // [depth][record]
+	float4* ray;              // per-sample arrays, see above
+	uint4* st;
+	float4* direct;
+	float4* fs;
+	float2* np;
 	uint64_t n_records;       // my_tiles * (k1-k0) * 64
-	uint64_t* prof;           // region-timing builds only (NULL otherwise)
 	uint32_t* unit_counter;   // next work unit of the path kernel's persistent waves (zeroed before the launch)
 	uint32_t rgb_mode;        // 1: RENDER_MODE_RGB (scene uplift == SSX_MODE_RGB): no wavelength draw, no XYZ, plain mean
 	uint32_t fuse_resolve;    // 1: the path kernel folds each unit's samples itself; 0: ssx_resolve_kernel does

@@ -43,35 +43,9 @@ __device__ __forceinline__ uint32_t* stage_lds(const SsxKernelArgs& a) {
 	return blob;
 }
 
-// Timing-only ablations (tools/ablate.py builds separate libraries with these; results are wrong
-// by construction and such builds are never loaded by the package or the tests).
-#ifdef SSX_ABL_TRANS
-#define ssx_sinf(x) ((x) * 0.5f)
-#define ssx_cosf(x) (1.0f - (x) * 0.25f)
-#define ssx_acosf(x) (1.5707964f - (x))
-#define ssx_sincosf(x, s, c) (*(s) = (x) * 0.5f, *(c) = 1.0f - (x) * 0.25f)
-#endif
-
-// Region timing build (tools/region_profile.py): wave-level s_memtime deltas per region of the
-// megakernel iteration, summed into a.prof[region].  Compiled out of the product library.
-#ifdef SSX_PROFILE_REGIONS
-#define SSX_NREG 12
-#define SSX_MARK(r) do { uint64_t now_ = __builtin_readcyclecounter(); prof_t[(r)] += now_ - prof_last; prof_last = __builtin_readcyclecounter(); } while (0)
-#define SSX_PROF_ARGS , uint64_t* prof_t, uint64_t& prof_last
-#define SSX_PROF_PASS , prof_t, prof_last
-#else
-#define SSX_MARK(r) do {} while (0)
-#define SSX_PROF_ARGS
-#define SSX_PROF_PASS
-#endif
-
 #define SSX_EPS 0.001f          // stdafx.hpp:58
 #define SSX_MAX_DEPTH_ 10u       // stdafx.hpp:47
 #define SSX_PI_F 3.14159265358979323846f
-
-#ifdef SSX_PROFILE_CANDS
-__device__ unsigned long long g_cand_stats[4]; // traces, lanes, candidates, wave loop trips
-#endif
 
 namespace {
 
@@ -455,114 +429,11 @@ __device__ __forceinline__ SV shear_vertex(const float* pv, int v, const RaySetu
 // visiting order): finish candidates exactly -- f64 edge fallback, det, T, sign test, 1/det,
 // dist, closest-so-far with strict '<' -- and skip tri1 when tri0 of the same quad was accepted
 // (the `goto HIT` of PrimQuad::intersect).
-//
-// SSX_MFMA_PASS1: pass 1 on the matrix cores.  The sign of an edge function is the sign of the
-// Pluecker side product of the ray (d, o x d) and the directed edge (q - p, p x q):
-//     side = d . (p x q) + (o x d) . (q - p)
-// -- a [rays x 6] x [6 x edges] product.  One v_mfma_f32_32x32x2_f32 chain of three (K = 6) gives
-// 32 edges x 32 rays; the edge rows are laid out 8 per quad {tri0: ab, bc, ca, 0 | tri1: ac, cd, da, 0}
-// so that a lane's 16 accumulators of a tile are four whole triangles: lanes 0-31 get tri0 of four
-// quads for ray (lane % 32) of the column tile, lanes 32-63 tri1.  The ray operands of both column
-// tiles come from three v_permlane32_swap, the two result masks go back to the rays' own lanes with a
-// fourth.  The products are rounded differently from the reference's sheared edge functions, so this
-// is a conservative filter: a triangle is dropped only if one side value is below -tol and another
-// above +tol (tol = 1024 u R^2 covers both roundings); pass 2 decides exactly.
-// trace() must then be called by all 64 lanes (has_ray tells whether the lane traces anything).
+// has_ray = false: the lane takes part in the wave-uniform pass 1 but traces nothing.
 __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_quad, bool has_ray, HitInfo& hit) {
 	const RaySetup rs = ray_setup(orig, dir);
 	const uint32_t nq = L.hdr().n_quads;
 	uint64_t cand = 0;
-#if defined(SSX_MFMA_PASS1)
-	uint32_t m0 = 0u, m1 = 0u;
-	{
-		typedef float f16v __attribute__((ext_vector_type(16)));
-		const uint32_t lane = threadIdx.x & 63u;
-#ifndef SSX_TOL_SCALE
-#define SSX_TOL_SCALE 1.0f
-#endif
-		const float tol = L.hdr().pass1_tol * SSX_TOL_SCALE;
-		// ray in Pluecker coordinates
-		const float c[6] = { dir.x, dir.y, dir.z,
-		                     orig.y * dir.z - orig.z * dir.y, orig.z * dir.x - orig.x * dir.z, orig.x * dir.y - orig.y * dir.x };
-		float B0[3], B1[3]; // operand of column tile 0 (rays 0-31) and 1 (rays 32-63), K step s
-#pragma unroll
-		for (int st = 0; st < 3; ++st) {
-			auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[2 * st]), __float_as_uint(c[2 * st + 1]), false, false);
-			B0[st] = __uint_as_float(r[0]); B1[st] = __uint_as_float(r[1]);
-		}
-		const float* atab = reinterpret_cast<const float*>(L.w + L.hdr().off_plucker) + lane;
-		const uint32_t n_mtiles = (nq + 3u) >> 2;
-		uint32_t v1 = 0u, v2 = 0u; // "mixed" flags of the triangle groups, first group highest (one v_alignbit each), column tile 0 / 1
-		for (uint32_t t = 0; t < n_mtiles; ++t) {
-			const float a0 = atab[(3u * t + 0u) * 64u], a1 = atab[(3u * t + 1u) * 64u], a2 = atab[(3u * t + 2u) * 64u];
-			f16v z = { 0 };
-			f16v d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, B0[0], z, 0, 0, 0);
-			f16v d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, B1[0], z, 0, 0, 0);
-			d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, B0[1], d0, 0, 0, 0);
-			d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, B1[1], d1, 0, 0, 0);
-			d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, B0[2], d0, 0, 0, 0);
-			d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, B1[2], d1, 0, 0, 0);
-#pragma unroll
-			for (int j = 0; j < 4; ++j) {
-				// mixed <=> min < -tol and max > tol <=> min(-min, max) > tol <=> tol - min(-min, max) < 0
-				const float mn0 = __builtin_fminf(__builtin_fminf(d0[4 * j], d0[4 * j + 1]), d0[4 * j + 2]);
-				const float mx0 = __builtin_fmaxf(__builtin_fmaxf(d0[4 * j], d0[4 * j + 1]), d0[4 * j + 2]);
-				const float mn1 = __builtin_fminf(__builtin_fminf(d1[4 * j], d1[4 * j + 1]), d1[4 * j + 2]);
-				const float mx1 = __builtin_fmaxf(__builtin_fmaxf(d1[4 * j], d1[4 * j + 1]), d1[4 * j + 2]);
-				v1 = __builtin_amdgcn_alignbit(v1, __float_as_uint(tol - __builtin_fminf(-mn0, mx0)), 31u);
-				v2 = __builtin_amdgcn_alignbit(v2, __float_as_uint(tol - __builtin_fminf(-mn1, mx1)), 31u);
-			}
-		}
-		// flag k = 4t+j sits at bit (4*n_mtiles - 1 - k): reverse, align, invert (1 = candidate)
-		const uint32_t sh = 32u - 4u * n_mtiles;
-		v1 = ~(__builtin_bitreverse32(v1) >> sh);
-		v2 = ~(__builtin_bitreverse32(v2) >> sh);
-		// v1: lanes 0-31 tri0 of ray lane, lanes 32-63 tri1 of ray lane-32; v2: lanes 0-31 tri0 of ray lane+32, lanes 32-63 tri1 of ray lane
-		auto r = __builtin_amdgcn_permlane32_swap(v1, v2, false, false);
-		const uint32_t valid = nq >= 32u ? 0xFFFFFFFFu : ((1u << nq) - 1u);
-		m0 = r[0] & valid; m1 = r[1] & valid; // tri0 / tri1 candidates of this lane's own ray, one bit per quad
-	}
-#elif defined(SSX_CONSERVATIVE_PASS1)
-	// Experimental (measured +0.7 % only, so not the default): conservative filter.  The edge functions are evaluated in a cheaper, differently rounded form
-	// (x'' = fma(-Sx, v[kz], v[kx]) - (o[kx] - Sx*o[kz]), fused products) and a triangle is dropped
-	// only if one of them is below -tol and another above +tol.  tol = 1024 u R^2 (u = 2^-24, R =
-	// largest coordinate magnitude of the scene, set by the host) exceeds the worst-case distance
-	// 496 u R^2 between these values and the reference's float edge functions (|Sx|,|Sy| <= 1, all
-	// coordinates <= R; derivation in DESIGN.md), so whatever is dropped has, in the reference's own
-	// arithmetic, one strictly negative and one strictly positive edge value -- exactly the
-	// triangles src/geometry.cpp:55-67 rejects.  Everything else is finished exactly in pass 2.
-	typedef float f2 __attribute__((ext_vector_type(2)));
-	const float tol = L.hdr().pass1_tol;
-	const f2 nS = { -rs.Sx, -rs.Sy };
-	const f2 cxy = { rs.okx - rs.Sx * rs.okz, rs.oky - rs.Sy * rs.okz };
-	for (uint32_t q = 0; q < nq; ++q) {
-		float pv[12];
-		load_perm(L.perm(q, rs.perm), pv);
-		f2 xy[4]; // packed: one v_pk_fma_f32 + one v_pk_add_f32 per vertex
-#pragma unroll
-		for (int v = 0; v < 4; ++v) {
-			const f2 P = { pv[2 * v], pv[2 * v + 1] }, Z = { pv[8 + v], pv[8 + v] };
-			xy[v] = __builtin_elementwise_fma(nS, Z, P) - cxy;
-		}
-		// tri0 = (a,b,c) = vertices 0,1,2; tri1 = (a,c,d) = vertices 0,2,3; W1 = -V0
-		float U0 = __builtin_fmaf(xy[1].y, xy[2].x, -(xy[1].x * xy[2].y));
-		float V0 = __builtin_fmaf(xy[2].y, xy[0].x, -(xy[2].x * xy[0].y));
-		float W0 = __builtin_fmaf(xy[0].y, xy[1].x, -(xy[0].x * xy[1].y));
-		float U1 = __builtin_fmaf(xy[2].y, xy[3].x, -(xy[2].x * xy[3].y));
-		float V1 = __builtin_fmaf(xy[3].y, xy[0].x, -(xy[3].x * xy[0].y));
-		float W1 = -V0;
-		float mn0 = __builtin_fminf(__builtin_fminf(U0, V0), W0), mx0 = __builtin_fmaxf(__builtin_fmaxf(U0, V0), W0);
-		float mn1 = __builtin_fminf(__builtin_fminf(U1, V1), W1), mx1 = __builtin_fmaxf(__builtin_fmaxf(U1, V1), W1);
-		uint32_t bits = ((mn0 < -tol && mx0 > tol) ? 0u : 1u) | ((mn1 < -tol && mx1 > tol) ? 0u : 2u);
-		cand |= (uint64_t)bits << (2u * q);
-	}
-#else
-#ifdef SSX_DUP_PASS1 // timing-only: the pass-1 loop runs twice (same result), the time difference is its cost
-	for (int dup_rep = 0; dup_rep < 2; ++dup_rep) {
-	RaySetup rs_dup = rs;
-	asm volatile("" : "+v"(rs_dup.Sx), "+v"(rs_dup.okx));
-#define rs rs_dup
-#endif
 	for (uint32_t q = 0; q < nq; ++q) {
 		float pv[12];
 		load_perm(L.perm(q, rs.perm), pv);
@@ -580,59 +451,16 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		uint32_t bits = ((mn0 < 0.0f && mx0 > 0.0f) ? 0u : 1u) | ((mn1 < 0.0f && mx1 > 0.0f) ? 0u : 2u);
 		cand |= (uint64_t)bits << (2u * q);
 	}
-#ifdef SSX_DUP_PASS1
-#undef rs
-	}
-#endif
-#endif
-#if defined(SSX_MFMA_PASS1)
-	if (ignore_quad >= 0) { m0 &= ~(1u << (uint32_t)ignore_quad); m1 &= ~(1u << (uint32_t)ignore_quad); }
-	if (!has_ray) { m0 = 0u; m1 = 0u; }
-	(void)cand;
-#else
 	if (ignore_quad >= 0) cand &= ~(3ull << (2u * (uint32_t)ignore_quad));
 	if (!has_ray) cand = 0ull;
-#endif
 
 	hit.tri = -1;
 	hit.dist = __builtin_inff();
 	hit.U = hit.V = hit.W = hit.det_recip = 0.0f;
-#ifdef SSX_PROFILE_CANDS
-	{ // pass-2 statistics: lanes with a ray, candidates over lanes, wave-level loop trips (max over lanes)
-		const uint64_t act = __ballot(1);
-		uint32_t mine = (uint32_t)__popcll(cand), mx = mine, sum = mine;
-		for (int o = 32; o > 0; o >>= 1) { mx = max(mx, (uint32_t)__shfl_xor((int)mx, o)); sum += (uint32_t)__shfl_xor((int)sum, o); }
-		if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(act)) {
-			atomicAdd((unsigned long long*)&g_cand_stats[0], 1ull);
-			atomicAdd((unsigned long long*)&g_cand_stats[1], (unsigned long long)__popcll(act));
-			atomicAdd((unsigned long long*)&g_cand_stats[2], (unsigned long long)sum);
-			atomicAdd((unsigned long long*)&g_cand_stats[3], (unsigned long long)mx);
-		}
-	}
-#endif
-#ifdef SSX_DUP_PASS2 // timing-only: the candidate loop runs twice
-	const uint64_t cand_saved = cand;
-	for (int dup2 = 0; dup2 < 2; ++dup2) {
-	cand = cand_saved;
-	asm volatile("" : "+v"(cand));
-	hit.tri = -1; hit.dist = __builtin_inff();
-#endif
-#if defined(SSX_MFMA_PASS1)
-	while (m0 | m1) { // ascending triangle order: tri0 of quad q (bit 2q) before tri1 (bit 2q+1)
-		const uint32_t q0 = m0 ? (uint32_t)__builtin_ctz(m0) : 32u, q1 = m1 ? (uint32_t)__builtin_ctz(m1) : 32u;
-		const uint32_t which = q1 < q0 ? 1u : 0u, q = which ? q1 : q0;
-		if (which) m1 &= m1 - 1u; else m0 &= m0 - 1u;
-		const uint32_t bit = 2u * q + which;
-#else
-#ifdef SSX_ABL_ONETRIP   // timing-only ablation: finish the first candidate only (wrong image)
-	for (int only_once = 0; only_once < 1 && cand; ++only_once) {
-#else
 	while (cand) {
-#endif
 		uint32_t bit = (uint32_t)__builtin_ctzll(cand);
 		cand &= cand - 1ull;
 		uint32_t q = bit >> 1, which = bit & 1u;
-#endif
 		float pv[12];
 		load_perm(L.perm(q, rs.perm), pv);
 		SV A = shear_vertex(pv, 0, rs);
@@ -662,16 +490,9 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		if (dist >= SSX_EPS && dist < hit.dist) {
 			hit.tri = (int)bit; hit.dist = dist;
 			hit.U = U; hit.V = V; hit.W = W; hit.det_recip = det_recip;
-#if defined(SSX_MFMA_PASS1)
-			if (which == 0u) m1 &= ~(1u << q); // PrimQuad::intersect: tri0 hit -> tri1 not tested
-#else
 			if (which == 0u) cand &= ~(1ull << (bit + 1u)); // PrimQuad::intersect: tri0 hit -> tri1 not tested
-#endif
 		}
 	}
-#ifdef SSX_DUP_PASS2
-	}
-#endif
 }
 
 // ------------------------------------------------------------------ light sampling ----
@@ -811,7 +632,6 @@ __device__ __forceinline__ V3 reflect3(V3 vec, V3 n) { // math-helpers.hpp:40-42
 
 // ------------------------------------------------------------------ one path ----
 
-
 // Per-lane state of the path a lane is working on.  A lane always holds one (pixel, k) item of
 // its wave's work unit; when the path ends the lane writes the result and takes the next item.
 struct Path {
@@ -820,14 +640,14 @@ struct Path {
 	float lambda_0;
 	int ignore;        // quad the ray starts on (-1: camera)
 	uint32_t depth;
-	uint32_t rec_index; // record of this sample in the sample buffer
+	uint32_t rec_index; // record of this sample in the per-sample arrays
 	bool hit_anything;
 };
 
 // renderer.cpp:113-138: camera ray (f64, as the reference) and hero wavelength of sample k of
 // pixel (i,j), from its own PCG32 stream (the seeding contract of include/ssx.h).  Runs in
 // ssx_generate_kernel with every lane busy; the record carries the stream on to the path kernel.
-__device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const SsxKernelArgs& a, uint32_t i, uint32_t j, uint32_t k, SsxSampleRecord& rec) {
+__device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const SsxKernelArgs& a, uint32_t i, uint32_t j, uint32_t k, float4& ray, uint4& st) {
 	const uint64_t pixel = (uint64_t)j * (uint64_t)a.width + (uint64_t)i;
 	const uint64_t pa = mix64(a.seed + 0x9E3779B97F4A7C15ull * (pixel + 1ull));
 	const uint64_t b = mix64(pa + 0x9E3779B97F4A7C15ull * ((uint64_t)k + 1ull));
@@ -851,8 +671,8 @@ __device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const Ss
 	// :138 exists #ifdef RENDER_MODE_SPECTRAL only: the RGB build draws no wavelength (its "spectra" are
 	// 4-sample tables {r,g,b,0} on the grid 0,1,2,3 and lambda_0 = 0, lambda_step = 1 pick them out exactly)
 	const float lambda_0 = a.rgb_mode ? 0.0f : h.lambda_min + rand_1f(rng) * h.lambda_step;
-	rec.a = make_float4((float)(dx * inv), (float)(dy * inv), (float)(dz * inv), lambda_0);
-	rec.b = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), (uint32_t)rng.inc, (uint32_t)(rng.inc >> 32));
+	ray = make_float4((float)(dx * inv), (float)(dy * inv), (float)(dz * inv), lambda_0);
+	st = make_uint4((uint32_t)rng.state, (uint32_t)(rng.state >> 32), (uint32_t)rng.inc, (uint32_t)(rng.inc >> 32));
 }
 
 // Deferred shadow rays.  Only about half of the lanes that shade a hit have a shadow ray
@@ -861,36 +681,36 @@ __device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const Ss
 // quad to ignore, light, and the contribution ((emitted*n_dot_l)*f_s)/pdf it adds if the light
 // is visible (renderer.cpp:216) -- in a per-wave LDS queue, and whenever 64 have gathered the
 // wave traces them with every lane busy (any lane takes any entry) and adds the contributions of
-// the visible ones to where that level's direct light lives by then: the level's frame, or the
-// sample's record if the path ended there.  `direct` + contribution is one float addition either
-// way, with the same operands as `direct += ...` in place, so the bits do not change; the RNG
-// stream is untouched (the shadow test draws nothing).
+// the visible ones to that level's `direct` (direct[level*n + record], written by path_step before
+// the ray can be flushed).  `direct` + contribution is one float addition with the same operands
+// as `radiance += ...` in place, so the bits do not change; the RNG stream is untouched (the
+// shadow test draws nothing).
 //   entry = 3 x float4: {orig.xyz, dir.x} {dir.y, dir.z, c0, c1} {c2, c3, light<<8|ignore, target}
-//   target: frame index depth*n_records+record, or 0x80000000|record for the record's radiance
-#if defined(SSX_MFMA_PASS1)
-#define SSX_SQ_FLUSH_AT 52u
-#define SSX_SQ_CAPACITY 116u // <= 51 left over + 64 new per iteration (smaller queue: the edge table needs the LDS)
-#else
 #define SSX_SQ_FLUSH_AT 64u
 #define SSX_SQ_CAPACITY 128u // < 64 left over + 64 new per iteration
-#endif
 struct ShadowQ {
 	float4* e;
 	uint32_t count; // wave-uniform
 };
-#define SSX_SQ_NONE 0xFFFFFFFFu
-__device__ __forceinline__ void sq_set_target(const ShadowQ& q, uint32_t slot, uint32_t target) {
-	if (slot != SSX_SQ_NONE) reinterpret_cast<uint32_t*>(q.e + 3u * slot + 2u)[3] = target;
+
+// hitrec.st of the accepted triangle (geometry.cpp:91-95): bary = UVW * det_recip, st = (bary.x*st0 + bary.y*st1) + bary.z*st2
+__device__ __forceinline__ void hit_st(const SsxBlobQuad& Q, uint32_t which, const HitInfo& hit, float& st_x, float& st_y) {
+	float bx = hit.U * hit.det_recip, by = hit.V * hit.det_recip, bz = hit.W * hit.det_recip;
+	const float* s0 = Q.st[0];
+	const float* s1 = which ? Q.st[2] : Q.st[1];
+	const float* s2 = which ? Q.st[3] : Q.st[2];
+	st_x = (bx * s0[0] + by * s1[0]) + bz * s2[0];
+	st_y = (bx * s0[1] + by * s1[1]) + bz * s2[1];
 }
 
 // One level of the recursion L() (renderer.cpp:147-255) for the lane's current ray: closest hit,
-// emission (camera ray only), next-event estimation with its shadow ray, BSDF sample.  Returns
-// true when the path continues (a Frame was pushed and p holds the next ray); otherwise `rad`
-// holds the radiance of this deepest level.
-__device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const SsxKernelArgs& a, Path& p, const HitInfo& hit, float rad[4], bool& pushed SSX_PROF_ARGS) {
+// emission (camera ray only), next-event estimation with its shadow ray, BSDF sample.  Writes the
+// level's `direct` (its whole radiance when the path ends here) and, when the path continues, the
+// factors of the continuation; returns true when it continues (p then holds the next ray).
+__device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const SsxKernelArgs& a, Path& p, const HitInfo& hit, bool& pushed) {
 	const SsxBlobHeader& h = L.hdr();
-	SSX_MARK(1);
-	if (hit.tri < 0) { rad[0] = rad[1] = rad[2] = rad[3] = 0.0f; return false; }
+	const uint32_t level_index = p.depth * (uint32_t)a.n_records + p.rec_index; // < 2^32 per launch (host budget)
+	if (hit.tri < 0) { a.direct[level_index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); return false; }
 	p.hit_anything = true;
 	const uint32_t hq = (uint32_t)hit.tri >> 1, which = (uint32_t)hit.tri & 1u;
 	const SsxBlobQuad& Q = L.quad(hq);
@@ -911,46 +731,25 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	// :178 `if (depth+1u<MAX_DEPTH)`: with ELS a ray at depth MAX_DEPTH-1 is never started (below);
 	// without it that ray exists (its hit may emit) and ends here
 	if (p.depth + 1u >= SSX_MAX_DEPTH_) {
-#pragma unroll
-		for (int k = 0; k < 4; ++k) rad[k] = direct[k];
+		a.direct[level_index] = make_float4(direct[0], direct[1], direct[2], direct[3]);
 		return false;
 	}
 	V3 hit_pos = add(p.orig, scl(hit.dist, p.dir)); // Ray::at
 	// hitrec.st (geometry.cpp:91-95) is read only by textured albedo
 	float st_x = 0.0f, st_y = 0.0f;
-	if (M.albedo_mode != 0u) {
-		float bx = hit.U * hit.det_recip, by = hit.V * hit.det_recip, bz = hit.W * hit.det_recip;
-		const float* s0 = Q.st[0];
-		const float* s1 = which ? Q.st[2] : Q.st[1];
-		const float* s2 = which ? Q.st[3] : Q.st[2];
-		st_x = (bx * s0[0] + by * s1[0]) + bz * s2[0];
-		st_y = (bx * s0[1] + by * s1[1]) + bz * s2[1];
-	}
+	if (M.albedo_mode != 0u) hit_st(Q, which, hit, st_x, st_y);
 	// albedo(lambda) is shared by evaluate_bsdf and interact_bsdf (material.cpp:120-143)
-#ifdef SSX_DUP_ALBEDO // timing-only: the albedo lookup runs twice
-	{ float sx = st_x; asm volatile("" : "+v"(sx)); Hero a2 = material_albedo(L, Q, sx, st_y, p.lambda_0); asm volatile("" :: "v"(a2.v[0]), "v"(a2.v[1]), "v"(a2.v[2]), "v"(a2.v[3])); }
-#endif
 	Hero alb = material_albedo(L, Q, st_x, st_y, p.lambda_0);
 	float f_lamb[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) f_lamb[k] = alb.v[k] / SSX_PI_F;
-	SSX_MARK(2);
 
 	// direct lighting (:182-219): sample the light; the shadow ray is parked (see ShadowQ)
-	uint32_t sq_slot = SSX_SQ_NONE;
-#ifndef SSX_ABL_NONEE
 	if (els && (!a.indirect_only || p.depth > 0u)) {
 		V3 sdir; uint32_t light; float spdf;
-#ifdef SSX_DUP_SAMPLELIGHT // timing-only: light sampling runs twice (first on a copy of the stream)
-		{ Rng rng_dup = p.rng; V3 hp = hit_pos; asm volatile("" : "+v"(hp.x)); sample_light(L, rng_dup, hp, sdir, light, spdf); asm volatile("" :: "v"(sdir.x), "v"(spdf), "v"(light), "v"(rng_dup.state)); }
-#endif
 		sample_light(L, p.rng, hit_pos, sdir, light, spdf);
 		float n_dot_l = dot3(sdir, N);
-		SSX_MARK(3);
 		if (n_dot_l > 0.0f) {
-#ifdef SSX_DUP_CONTRIB // timing-only: emission lookup + contribution computed twice
-			{ float l2 = p.lambda_0; asm volatile("" : "+v"(l2)); Hero e2 = spectrum_hero(L, L.quad(light).emission, l2, h.lambda_step); float acc = 0; for (int k = 0; k < 4; ++k) acc += ((e2.v[k] * n_dot_l) * f_lamb[k]) / spdf; asm volatile("" :: "v"(acc)); }
-#endif
 			Hero emitted = spectrum_hero(L, L.quad(light).emission, p.lambda_0, h.lambda_step);
 			float c[4];
 #pragma unroll
@@ -959,24 +758,18 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 				c[k] = ((emitted.v[k] * n_dot_l) * fs) / spdf;
 			}
 			const uint64_t pushing = __ballot(1);
-			sq_slot = q.count + __builtin_amdgcn_mbcnt_hi((uint32_t)(pushing >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushing, 0u));
-			float4* E = q.e + 3u * sq_slot;
+			const uint32_t slot = q.count + __builtin_amdgcn_mbcnt_hi((uint32_t)(pushing >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushing, 0u));
+			float4* E = q.e + 3u * slot;
 			E[0] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, sdir.x);
 			E[1] = make_float4(sdir.y, sdir.z, c[0], c[1]);
-			E[2] = make_float4(c[2], c[3], __uint_as_float((light << 8) | hq), 0.0f);
+			E[2] = make_float4(c[2], c[3], __uint_as_float((light << 8) | hq), __uint_as_float(level_index));
 			pushed = true;
-			SSX_MARK(4);
 		}
 	}
-#endif
 
-	SSX_MARK(5);
 	// indirect lighting (:222-250)
 	V3 w_i; float pdf_w_i; float f_s[4];
 	if (M.kind == 0u) {
-#ifdef SSX_DUP_BSDF // timing-only: the BSDF sample runs twice (first on a copy of the stream)
-		{ Rng r2 = p.rng; V3 n2 = N; asm volatile("" : "+v"(n2.x)); float pd; V3 w2 = get_rotated_to(rand_coshemi(r2, pd), n2); asm volatile("" :: "v"(w2.x), "v"(w2.y), "v"(w2.z), "v"(pd), "v"(r2.state)); }
-#endif
 		w_i = rand_coshemi(p.rng, pdf_w_i);
 		w_i = get_rotated_to(w_i, N);
 #pragma unroll
@@ -987,7 +780,6 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 #pragma unroll
 		for (int k = 0; k < 4; ++k) f_s[k] = alb.v[k];
 	}
-	SSX_MARK(6);
 	bool cont = false;
 	float n_dot_l = 0.0f;
 	float dotfs = (f_s[0] * f_s[0] + f_s[1] * f_s[1]) + (f_s[2] * f_s[2] + f_s[3] * f_s[3]);
@@ -996,44 +788,41 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 		else { n_dot_l = 1.0f; pdf_w_i = 1.0f; }
 		cont = n_dot_l > 0.0f;
 	}
+	// this level's direct light: the level's radiance if the path ends here, else the first term of the fold
+	a.direct[level_index] = make_float4(direct[0], direct[1], direct[2], direct[3]);
 	// A ray at depth MAX_DEPTH-1 can add nothing (no emission: last_was_delta is false; no further
 	// bounce: depth+1 == MAX_DEPTH) and hit_anything is already set, so it is not traced: its L()
 	// is exactly 0 and the parent adds ((0*n)*f)/p.
 	// In that case direct + ((0*n_dot_l)*f_s)/pdf == direct exactly: n_dot_l, f_s (finite table
 	// values / pi) and pdf (in (EPS/pi, 1/pi], or 1 for a mirror) are finite and pdf > 0.
-	if (!cont || (els && p.depth + 2u >= SSX_MAX_DEPTH_)) {
-#pragma unroll
-		for (int k = 0; k < 4; ++k) rad[k] = direct[k];
-		sq_set_target(q, sq_slot, 0x80000000u | p.rec_index); // this level's direct light ends up in the record
-		return false;
-	}
-	// record this level for the backward fold (resolve_records, at the end of the wave's unit): [depth][record] so that
-	// the 64 lanes of a wave, which hold (mostly) consecutive records, store contiguously
-#ifndef SSX_ABL_NOSTORES
-	{
-		SsxFrame* F = a.frames + (p.depth * (uint32_t)a.n_records + p.rec_index); // < 2^32 frames per launch (host budget)
-		F->direct = make_float4(direct[0], direct[1], direct[2], direct[3]);
-		F->f_s = make_float4(f_s[0], f_s[1], f_s[2], f_s[3]);
-		F->np = make_float2(n_dot_l, pdf_w_i);
-	}
-#else
-	if (n_dot_l == 123.456f) a.frames[p.rec_index].np = make_float2(direct[0] + f_s[1], pdf_w_i);
-#endif
-	sq_set_target(q, sq_slot, p.depth * (uint32_t)a.n_records + p.rec_index); // ... or in the frame just written
+	if (!cont || (els && p.depth + 2u >= SSX_MAX_DEPTH_)) return false;
+	// the factors of the continuation for the backward fold (resolve_record, when the wave's unit is complete)
+	a.fs[level_index] = make_float4(f_s[0], f_s[1], f_s[2], f_s[3]);
+	a.np[level_index] = make_float2(n_dot_l, pdf_w_i);
 	p.orig = hit_pos; p.dir = w_i; p.ignore = (int)hq;
 	++p.depth;
-	SSX_MARK(7);
 	return true;
 }
 
+// Memory-ordering contract of the two readers below (shadow_flush, unit_fold).  They read `direct`,
+// `fs`, `np` and `st` entries that OTHER LANES OF THE SAME WAVE stored earlier in the wave's single
+// instruction stream (lanes trade items at the refill, so the storing lane is in general not the
+// reading lane), and nothing that another wave wrote.  On gfx950 a wave's vector-memory operations
+// are issued in program order and its stores go through the (write-through) L1 to the L2; what a
+// reader has to exclude is (1) the compiler moving the access across the stores -- the
+// workgroup-scope fences -- and (2) a stale L1 line left by an earlier read of the same address:
+// shadow_flush therefore loads with agent scope (served by the L2), unit_fold invalidates the L1
+// with an agent-scope acquire fence.  This is below what the HIP memory model promises for
+// cross-lane communication (no release/acquire pair on an atomic), i.e. it relies on documented
+// gfx9 behaviour; an agent-scope release (L2 write-back) before every flush measured 4x slower.
+// simple_spectral_amd/build.py therefore pins the target to gfx950 and refuses an untested ROCm
+// major version, and the bit-exact GPU parity tests (tests/test_gpu_parity.py, incl. the
+// many-units-per-wave stress case) are the guard.
+//
 // Traces the parked shadow rays [first, first+n), n <= 64, one per lane, and adds the contribution
 // of every visible one to its target.  Called in uniform control flow.
 __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& a, const ShadowQ& q, uint32_t first, uint32_t n) {
 	const uint32_t lane = threadIdx.x & 63u;
-	// The targets were written by whichever lane ran that sample, earlier in this wave's own
-	// instruction stream: a workgroup-scope fence (no cache maintenance, unlike __threadfence) orders the
-	// compiler and waits for those stores; the loads below bypass the CU's L1 (agent-scope atomics),
-	// which may still hold a record line from before the sample's last store.
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 	const bool have = lane < n;
 	float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = make_float4(1.0f, 0.0f, 0.0f, 0.0f), e2 = e0, old = e0;
@@ -1041,8 +830,7 @@ __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& 
 	if (have) {
 		const float4* E = q.e + 3u * (first + lane);
 		e0 = E[0]; e1 = E[1]; e2 = E[2];
-		const uint32_t target = __float_as_uint(e2.w);
-		dst = (target & 0x80000000u) ? &a.samples[target & 0x7FFFFFFFu].a : &a.frames[target].direct;
+		dst = a.direct + __float_as_uint(e2.w);
 		float* d = reinterpret_cast<float*>(dst); // in flight during the trace
 		old.x = __hip_atomic_load(d + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		old.y = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1057,16 +845,17 @@ __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& 
 }
 
 // Backward fold of the recursion for finished samples (renderer.cpp:247: radiance += L(next) *
-// n_dot_l * f_s / pdf, evaluated innermost first = the reference's post-order) over the frames the
+// n_dot_l * f_s / pdf, evaluated innermost first = the reference's post-order) over the levels the
 // path recorded, then flux -> CIE XYZ (util/color.hpp:115-139; FLAT_FIELD_CORRECTION: flux =
-// radiance, renderer.cpp:262-263).  A record becomes {X, Y, Z, alpha} ({R, G, B, alpha} in RGB mode).
-// Four records of the lane (consecutive k of its pixel) are folded side by side so that the frame
-// loads of a level are four independent requests instead of a chain of dependent round trips.
+// radiance, renderer.cpp:262-263).  ray[r] becomes {X, Y, Z, alpha} ({R, G, B, alpha} in RGB mode).
+// Four records of the lane (consecutive k of its pixel) are folded side by side so that the loads
+// of a level are four independent requests instead of a chain of dependent round trips.
 #ifndef SSX_RESOLVE_WAYS
 #define SSX_RESOLVE_WAYS 4u
 #endif
 template <uint32_t WAYS>
 __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count) {
+	const uint32_t n = (uint32_t)a.n_records;
 	float rad[WAYS][4];
 	uint32_t depth[WAYS], lam[WAYS], hitf[WAYS];
 	uint32_t top = 0;
@@ -1075,24 +864,25 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 		depth[s] = 0; lam[s] = 0; hitf[s] = 0;
 		rad[s][0] = rad[s][1] = rad[s][2] = rad[s][3] = 0.0f;
 		if (s < count) {
-			const SsxSampleRecord rec = a.samples[r0 + s * stride];
-			rad[s][0] = rec.a.x; rad[s][1] = rec.a.y; rad[s][2] = rec.a.z; rad[s][3] = rec.a.w;
-			lam[s] = rec.b.x; hitf[s] = rec.b.y; depth[s] = rec.b.z;
+			const uint4 st = a.st[r0 + s * stride];
+			lam[s] = st.x; hitf[s] = st.y & 1u; depth[s] = st.y >> 8;
+			const float4 last = a.direct[depth[s] * n + r0 + s * stride]; // the last level's radiance
+			rad[s][0] = last.x; rad[s][1] = last.y; rad[s][2] = last.z; rad[s][3] = last.w;
 		}
 		top = max(top, depth[s]);
 	}
 	for (uint32_t d = top; d-- > 0u;) {
-		SsxFrame F[WAYS];
+		float4 D[WAYS], F[WAYS]; float2 NP[WAYS];
 #pragma unroll
 		for (uint32_t s = 0; s < WAYS; ++s)
-			if (d < depth[s]) F[s] = a.frames[d * (uint32_t)a.n_records + r0 + s * stride];
+			if (d < depth[s]) { const uint32_t i = d * n + r0 + s * stride; D[s] = a.direct[i]; F[s] = a.fs[i]; NP[s] = a.np[i]; }
 #pragma unroll
 		for (uint32_t s = 0; s < WAYS; ++s)
 			if (d < depth[s]) {
-				rad[s][0] = F[s].direct.x + ((rad[s][0] * F[s].np.x) * F[s].f_s.x) / F[s].np.y;
-				rad[s][1] = F[s].direct.y + ((rad[s][1] * F[s].np.x) * F[s].f_s.y) / F[s].np.y;
-				rad[s][2] = F[s].direct.z + ((rad[s][2] * F[s].np.x) * F[s].f_s.z) / F[s].np.y;
-				rad[s][3] = F[s].direct.w + ((rad[s][3] * F[s].np.x) * F[s].f_s.w) / F[s].np.y;
+				rad[s][0] = D[s].x + ((rad[s][0] * NP[s].x) * F[s].x) / NP[s].y;
+				rad[s][1] = D[s].y + ((rad[s][1] * NP[s].x) * F[s].y) / NP[s].y;
+				rad[s][2] = D[s].z + ((rad[s][2] * NP[s].x) * F[s].z) / NP[s].y;
+				rad[s][3] = D[s].w + ((rad[s][3] * NP[s].x) * F[s].w) / NP[s].y;
 			}
 	}
 #pragma unroll
@@ -1101,22 +891,20 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 			Hero flux; flux.v[0] = rad[s][0]; flux.v[1] = rad[s][1]; flux.v[2] = rad[s][2]; flux.v[3] = rad[s][3];
 			float xyz[3];
 			if (a.rgb_mode) { xyz[0] = rad[s][0]; xyz[1] = rad[s][1]; xyz[2] = rad[s][2]; } // renderer.cpp:274-276: lRGB_A_F32(pixel_flux_est, hit)
-			else
-			flux_to_xyz(L, flux, __uint_as_float(lam[s]), xyz);
-			a.samples[r0 + s * stride].a = make_float4(xyz[0], xyz[1], xyz[2], hitf[s] ? 1.0f : 0.0f);
+			else flux_to_xyz(L, flux, __uint_as_float(lam[s]), xyz);
+			a.ray[r0 + s * stride] = make_float4(xyz[0], xyz[1], xyz[2], hitf[s] ? 1.0f : 0.0f);
 		}
 }
 
 } // namespace
 
 // Stage 1 of 3: one lane per sample.  Camera ray + hero wavelength (f64 camera maths of
-// renderer.cpp:113-138) for every (owned pixel, k in [k0,k1)) into the sample buffer,
-// layout [tile slot][k-k0][pixel in tile] so a wave writes 64 consecutive 32-byte records.
+// renderer.cpp:113-138) for every (owned pixel, k in [k0,k1)) into ray[] / st[],
+// record order [tile slot][k-k0][pixel in tile] so a wave writes 64 consecutive records.
 extern "C" __global__ void __launch_bounds__(256) ssx_generate_kernel(SsxKernelArgs a) {
 	const SsxBlobHeader& h = *reinterpret_cast<const SsxBlobHeader*>(a.blob); // uniform: scalar loads
 	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t n_k = a.k1 - a.k0;
-	const uint64_t rec_index = gid;
 	const uint32_t lane = (uint32_t)(gid & 63u);
 	const uint64_t sk = gid >> 6;
 	const uint32_t slot = (uint32_t)(sk / n_k), kk = a.k0 + (uint32_t)(sk % n_k);
@@ -1124,9 +912,10 @@ extern "C" __global__ void __launch_bounds__(256) ssx_generate_kernel(SsxKernelA
 	const uint32_t tile = a.tile_first + slot * a.tile_stride;
 	const uint32_t i = (tile % a.tiles_x) * 8u + (lane & 7u), j = (tile / a.tiles_x) * 8u + (lane >> 3);
 	if (i >= a.width || j >= a.height) return;
-	SsxSampleRecord rec;
-	generate_sample(h, a, i, j, kk, rec);
-	a.samples[rec_index] = rec;
+	float4 ray; uint4 st;
+	generate_sample(h, a, i, j, kk, ray, st);
+	a.ray[gid] = ray;
+	a.st[gid] = st;
 }
 
 // Stage 2 of 3: the path megakernel.  Work unit of one wave64 = one 8x8 tile (Framebuffer::Tile,
@@ -1136,7 +925,7 @@ extern "C" __global__ void __launch_bounds__(256) ssx_generate_kernel(SsxKernelA
 // all 64 lanes trace a ray in (almost) every iteration although path lengths differ (26 % of
 // Cornell paths end after one interaction, 24 % run all nine).  The recursion L() of the
 // reference is evaluated as a forward pass here (each level's direct light and continuation
-// factors go to the frame buffer) and a backward fold over them when the wave has finished its unit.
+// factors go to the per-level arrays) and a backward fold over them when the wave has finished its unit.
 struct WorkUnit { // wave-uniform description of one work unit: 8x8 tile x a group of consecutive samples
 	uint32_t rec_base, n_kq, tw, th, npx, n_items;
 };
@@ -1152,15 +941,13 @@ __device__ __forceinline__ void unit_setup(const SsxKernelArgs& a, uint32_t unit
 	u.n_items = u.npx * u.n_kq;
 	u.rec_base = (slot * (a.k1 - a.k0) + (ka - a.k0)) * 64u;
 }
-// Every lane folds the records of its own pixel of a finished unit.  The loads (frames and records
+// Every lane folds the records of its own pixel of a finished unit.  The loads (levels and records
 // this wave wrote during the unit) overlap with the arithmetic of the other waves on the SIMD, which
 // a separate HBM-bound pass after the kernel could not.  (For scenes with very short paths --
-// plane-srgb: one frame per sample -- the fold is a large share of the arithmetic and the separate
-// streaming kernel is faster; the host picks, see ssx_api.hip.)
+// plane-srgb: one continued level per sample -- the fold is a large share of the arithmetic and the
+// separate streaming kernel is faster; the host picks, see ssx_api.hip.)
 __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, const WorkUnit& u) {
-	// the records and frames were written by whichever lane ran the sample, in this wave's own
-	// instruction stream: wait for those stores, then drop the CU's L1 lines (a record line may date
-	// from before its last store); no L2 write-back is needed, nobody else reads this unit's data
+	// see "Memory-ordering contract" above: wait for this wave's stores, drop the CU's L1 lines
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	const uint32_t lane = threadIdx.x & 63u;
@@ -1194,12 +981,6 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	bool cur_valid = false, old_pending = false, more = true;
 	uint32_t cur_tag = 0, old_tag = 0;
 	uint32_t next_item = 0; // wave-uniform
-#ifdef SSX_PROFILE_REGIONS
-	uint64_t prof_t[SSX_NREG] = {};
-	uint64_t prof_last = __builtin_readcyclecounter();
-	const uint64_t prof_start = prof_last;
-	uint64_t prof_iters = 0, prof_lanes = 0;
-#endif
 	for (;;) {
 		// rotate: the current unit has no items left and the previous one is folded
 		if (cur_valid && next_item >= cur.n_items && !old_pending) {
@@ -1223,11 +1004,12 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 					if (cur.npx == 64u) { in_tile = item & 63u; kq = item >> 6; }              // full tile (wave-uniform branch)
 					else { const uint32_t r = item % cur.npx; kq = item / cur.npx; in_tile = (r / cur.tw) * 8u + r % cur.tw; }
 					p.rec_index = cur.rec_base + kq * 64u + in_tile;
-					const SsxSampleRecord rec = a.samples[p.rec_index];
-					p.dir = mk(rec.a.x, rec.a.y, rec.a.z);
-					p.lambda_0 = rec.a.w;
-					p.rng.state = ((uint64_t)rec.b.y << 32) | rec.b.x;
-					p.rng.inc = ((uint64_t)rec.b.w << 32) | rec.b.z;
+					const float4 ray = a.ray[p.rec_index];
+					const uint4 st = a.st[p.rec_index];
+					p.dir = mk(ray.x, ray.y, ray.z);
+					p.lambda_0 = ray.w;
+					p.rng.state = ((uint64_t)st.y << 32) | st.x;
+					p.rng.inc = ((uint64_t)st.w << 32) | st.z;
 					p.orig = cam;
 					p.ignore = -1;
 					p.depth = 0;
@@ -1245,22 +1027,16 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			if (!cur_valid && !more) break;
 			continue;
 		}
-		SSX_MARK(0);
-#ifdef SSX_PROFILE_REGIONS
-		prof_iters += 1; prof_lanes += (uint64_t)__popcll(__ballot(active));
-#endif
 		bool pushed = false;
-		HitInfo hit; // the primary rays of all lanes: traced in uniform control flow (idle lanes help out in the MFMA pass 1)
+		HitInfo hit; // the primary rays of all lanes: traced in uniform control flow
 		trace(L, p.orig, p.dir, p.ignore, active, hit);
 		if (active) {
-			float rad[4];
-			if (!path_step(L, sq, a, p, hit, rad, pushed SSX_PROF_PASS)) {
-				// deepest level reached: its radiance, the number of recorded frames, lambda_0 and the
-				// hit flag replace the sample's record; the fold happens when its unit is complete
-				SsxSampleRecord out;
-				out.a = make_float4(rad[0], rad[1], rad[2], rad[3]);
-				out.b = make_uint4(__float_as_uint(p.lambda_0), p.hit_anything ? 1u : 0u, p.depth, 0u);
-				a.samples[p.rec_index] = out;
+			if (!path_step(L, sq, a, p, hit, pushed)) {
+				// last level reached (its radiance is in direct[depth]): lambda_0, the hit flag, the number of
+				// continued levels and the final PCG32 state replace the sample's stream; the fold happens
+				// when its unit is complete
+				a.st[p.rec_index] = make_uint4(__float_as_uint(p.lambda_0), (p.hit_anything ? 1u : 0u) | (p.depth << 8),
+				                               (uint32_t)p.rng.state, (uint32_t)(p.rng.state >> 32));
 				active = false;
 			}
 		}
@@ -1276,22 +1052,13 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			unit_fold(L, a, old);
 			old_pending = false;
 		}
-		SSX_MARK(8);
 	}
-#ifdef SSX_PROFILE_REGIONS
-	if (lane == 0u && a.prof) {
-		for (int r = 0; r < SSX_NREG - 3; ++r) atomicAdd((unsigned long long*)&a.prof[r], (unsigned long long)prof_t[r]);
-		atomicAdd((unsigned long long*)&a.prof[SSX_NREG - 3], (unsigned long long)(__builtin_readcyclecounter() - prof_start));
-		atomicAdd((unsigned long long*)&a.prof[SSX_NREG - 2], (unsigned long long)prof_iters);
-		atomicAdd((unsigned long long*)&a.prof[SSX_NREG - 1], (unsigned long long)prof_lanes);
-	}
-#endif
 }
 
 #ifndef SSX_WAVES_PER_EU
 #define SSX_WAVES_PER_EU 4
 #endif
-// 3 waves per SIMD (168 VGPRs): the register allocator otherwise settles one register above that
+// 4 waves per SIMD (128 VGPRs): four 256-lane workgroups per CU with the CIE 1931 tables
 extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SSX_WAVES_PER_EU))) ssx_render_kernel(SsxKernelArgs a) { render_body(a); }
 // The same kernel under another name for the calibration render of ssx_upload_scene, so that
 // kernel traces and statistics of ssx_render_kernel contain real launches only.
@@ -1316,7 +1083,7 @@ extern "C" __global__ void __launch_bounds__(256) ssx_resolve_kernel(SsxKernelAr
 
 // Stage 3 of 3: one lane per pixel.  renderer.cpp:292-295: avg += sample*0.001f (float multiply,
 // widened) in ascending k -- the reference's accumulation order, whichever lane of the path
-// kernel produced the sample.  Consecutive lanes read consecutive records.
+// kernel produced the sample.  Consecutive lanes read consecutive 16-byte results.
 extern "C" __global__ void __launch_bounds__(256) ssx_accumulate_kernel(SsxKernelArgs a, double* accum) {
 	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t slot = gid >> 6, lane = gid & 63u;
@@ -1327,15 +1094,15 @@ extern "C" __global__ void __launch_bounds__(256) ssx_accumulate_kernel(SsxKerne
 	const uint32_t n_k = a.k1 - a.k0;
 	double* acc_p = accum + 4u * ((size_t)j * a.width + i);
 	double acc[4] = { acc_p[0], acc_p[1], acc_p[2], acc_p[3] };
-	const SsxSampleRecord* s = a.samples + (size_t)slot * n_k * 64u + lane;
+	const float4* s = a.ray + (size_t)slot * n_k * 64u + lane;
 	if (a.rgb_mode) { // renderer.cpp:301-303: avg += _render_sample(...), no pre-scaling
 		for (uint32_t k = 0; k < n_k; ++k) {
-			const float4 v = s[(size_t)k * 64u].a;
+			const float4 v = s[(size_t)k * 64u];
 			acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
 		}
 	} else
 	for (uint32_t k = 0; k < n_k; ++k) {
-		const float4 v = s[(size_t)k * 64u].a;
+		const float4 v = s[(size_t)k * 64u];
 		acc[0] += (double)(v.x * 0.001f);
 		acc[1] += (double)(v.y * 0.001f);
 		acc[2] += (double)(v.z * 0.001f);
@@ -1345,7 +1112,7 @@ extern "C" __global__ void __launch_bounds__(256) ssx_accumulate_kernel(SsxKerne
 }
 
 // renderer.cpp:296,298: avg *= 1000.0/spp, then the float conversion of CIEXYZ_32F(avg) / avg.a.
-// Pixels of tiles this device does not own are written as 0 (x+0 is exact in the RCCL sum).
+// Pixels of tiles this device does not own are written as 0 (x+0 is exact in the framebuffer sum).
 extern "C" __global__ void __launch_bounds__(256) ssx_finalize_kernel(const double* accum, float4* out, uint32_t width, uint32_t height,
                                                   uint32_t tiles_x, uint32_t tile_first, uint32_t tile_stride, uint32_t spp, uint32_t rgb_mode) {
 	uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1367,4 +1134,13 @@ extern "C" __global__ void __launch_bounds__(256) ssx_finalize_kernel(const doub
 		o.w = (float)(accum[4u * p + 3] * sc);
 	}
 	out[p] = o;
+}
+
+// Sum of the per-device framebuffers on one device (the C++ host's multi-GPU combine: peers' buffers
+// arrive by hipMemcpyPeerAsync over xGMI; every pixel is nonzero in exactly one of them, x + 0 is exact).
+extern "C" __global__ void __launch_bounds__(256) ssx_sum_kernel(float4* dst, const float4* src, uint32_t n) {
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= n) return;
+	const float4 a = dst[p], b = src[p];
+	dst[p] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }

@@ -63,7 +63,7 @@ int ssh_scene_create_ex(const char* scene_name, const char* data_dir, int observ
 			tex.rgb.assign(tex_rgb, tex_rgb + (size_t)3 * tex_w * tex_h);
 			texp = &tex;
 		} else if (texture_path && *texture_path) {
-			tex = ssx::load_png_rgb8(texture_path);
+			tex = ssx::load_texture(texture_path);
 			texp = &tex;
 		}
 		s->scene = std::make_unique<ssx::Scene>(*s->color, scene_name, data_dir, texp, light_scale, s->jh.get(), els, s->meng.get(), rgb_mode);

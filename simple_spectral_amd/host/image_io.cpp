@@ -35,6 +35,29 @@ void write_chunk(std::vector<uint8_t>& out, const char type[4], const std::vecto
 
 } // namespace
 
+Texture procedural_texture(uint32_t n, uint32_t seed) {
+	Texture t;
+	t.width = t.height = n;
+	t.rgb.resize((size_t)3 * n * n);
+	for (uint32_t y = 0; y < n; ++y) for (uint32_t x = 0; x < n; ++x) {
+		uint32_t h = x * 0x9E3779B1u ^ y * 0x85EBCA77u ^ seed * 0xC2B2AE3Du;
+		h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+		const uint32_t base = (((x >> 5) ^ (y >> 5)) & 1u) ? 200u : 60u; // 32-texel checker under the noise
+		uint8_t* px = &t.rgb[(size_t)3 * ((size_t)y * n + x)];
+		for (uint32_t c = 0; c < 3; ++c) px[c] = (uint8_t)((3u * base + ((h >> (8u * c)) & 0xFFu)) >> 2);
+	}
+	return t;
+}
+
+Texture load_texture(const std::string& path) {
+	if (path.rfind("procedural:", 0) == 0) {
+		unsigned n = 0, seed = 1;
+		if (std::sscanf(path.c_str() + 11, "%u:%u", &n, &seed) < 1 || n == 0 || n > 16384) throw HostError{ -1, "Could not load texture \"" + path + "\" (procedural:N[:SEED], N <= 16384)" };
+		return procedural_texture(n, seed);
+	}
+	return load_png_rgb8(path);
+}
+
 // PNG -> RGB8, every standard variant: colour types 0/2/3/4/6, bit depths 1/2/4/8/16, Adam7
 // interlacing; alpha and tRNS do not affect RGB.  Conversion rules are those of
 // lodepng::decode(..., LCT_RGB) (src/material.cpp:11-14): sub-byte grey scaled by 255/(2^d-1),

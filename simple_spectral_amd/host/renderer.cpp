@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 
@@ -33,6 +34,10 @@ struct Renderer::Api {
 	float (*progress)(ssx_ctx*) = nullptr;
 	int (*render_wait)(ssx_ctx*, float*) = nullptr;
 	const char* (*last_error)(const ssx_ctx*) = nullptr;
+	void* (*device_framebuffer)(ssx_ctx*) = nullptr;
+	int (*device_index)(ssx_ctx*) = nullptr;
+	int (*read_framebuffer)(ssx_ctx*, float*) = nullptr;
+	int (*accumulate_peer)(ssx_ctx*, void*, int, const void*, uint32_t, uint32_t, void*) = nullptr;
 
 	explicit Api(const std::string& path) {
 		handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
@@ -51,6 +56,10 @@ struct Renderer::Api {
 		progress = reinterpret_cast<decltype(progress)>(sym("ssx_progress"));
 		render_wait = reinterpret_cast<decltype(render_wait)>(sym("ssx_render_wait"));
 		last_error = reinterpret_cast<decltype(last_error)>(sym("ssx_last_error"));
+		device_framebuffer = reinterpret_cast<decltype(device_framebuffer)>(sym("ssx_device_framebuffer"));
+		device_index = reinterpret_cast<decltype(device_index)>(sym("ssx_device_index"));
+		read_framebuffer = reinterpret_cast<decltype(read_framebuffer)>(sym("ssx_read_framebuffer"));
+		accumulate_peer = reinterpret_cast<decltype(accumulate_peer)>(sym("ssx_accumulate_peer"));
 	}
 	~Api() { if (handle) dlclose(handle); }
 };
@@ -87,7 +96,7 @@ Renderer::Renderer(const Options& opts) : options(opts), framebuffer(opts.res), 
 			path = options.data_dir + "/scenes/crystal-lizard-4096.png";
 			if (!file_exists(path)) path = options.data_dir + "/scenes/crystal-lizard-512.png";
 		}
-		tex = load_png_rgb8(path);
+		tex = load_texture(path);
 		texp = &tex;
 	}
 	if (options.rgb_mode) {
@@ -110,9 +119,11 @@ Renderer::Renderer(const Options& opts) : options(opts), framebuffer(opts.res), 
 
 	api_ = std::make_unique<Api>(options.hip_library.empty() ? default_hip_library() : options.hip_library);
 	const int n = options.gpus < 1 ? 1 : options.gpus;
+	// SSX_TEST_ONE_GPU=1: plumbing test of the multi-device path on a 1-GPU box (all contexts on device 0)
+	const char* one_gpu = std::getenv("SSX_TEST_ONE_GPU");
 	for (int d = 0; d < n; ++d) {
 		ssx_ctx* ctx = nullptr;
-		int rc = api_->create(d, &ctx);
+		int rc = api_->create((one_gpu && *one_gpu == '1') ? 0 : d, &ctx);
 		if (rc) throw HostError{ rc, std::string("ssx_create: ") + api_->last_error(nullptr) };
 		ctxs_.push_back(ctx);
 		rc = api_->upload_scene(ctx, &scene->desc());
@@ -183,15 +194,24 @@ void Renderer::print_progress() const {
 
 void Renderer::render_wait() {
 	if (!started_) return;
-	const size_t n = 4 * options.res[0] * options.res[1];
-	std::vector<float> part(n);
-	std::fill(xyza.begin(), xyza.end(), 0.0f);
+	// Every device's share stays in its own HBM (ssx_render_wait without a host buffer).  The combine is
+	// the path's one exchange step (north_star: reduce of the per-GPU framebuffers over xGMI): device 0
+	// pulls each peer's framebuffer with a device-to-device copy and adds it with a kernel.  Every pixel
+	// is nonzero in exactly one device's buffer and x + 0 is exact, so the sum is bit for bit the image
+	// a single device produces (the multi-process path, bench.py, does the same with one RCCL reduce).
 	for (ssx_ctx* c : ctxs_) {
-		int rc = api_->render_wait(c, part.data());
+		int rc = api_->render_wait(c, nullptr);
 		if (rc) throw HostError{ rc, std::string("ssx_render_wait: ") + api_->last_error(c) };
-		// every pixel is nonzero in exactly one device's buffer: x + 0 is exact, so this sum is the
-		// same image a single device produces (the multi-process path does it with one RCCL reduce)
-		for (size_t k = 0; k < n; ++k) xyza[k] += part[k];
+	}
+	ssx_ctx* root = ctxs_[0];
+	for (size_t d = 1; d < ctxs_.size(); ++d) {
+		int rc = api_->accumulate_peer(root, api_->device_framebuffer(root), api_->device_index(ctxs_[d]), api_->device_framebuffer(ctxs_[d]),
+		                               static_cast<uint32_t>(options.res[0]), static_cast<uint32_t>(options.res[1]), nullptr);
+		if (rc) throw HostError{ rc, std::string("ssx_accumulate_peer: ") + api_->last_error(root) };
+	}
+	{
+		int rc = api_->read_framebuffer(root, xyza.data());
+		if (rc) throw HostError{ rc, std::string("ssx_read_framebuffer: ") + api_->last_error(root) };
 	}
 	started_ = false;
 	// framebuffer(i,j) = sRGB_A_F32(ciexyz_to_srgb(XYZ), alpha)  (src/renderer.cpp:298)

@@ -82,7 +82,7 @@ class Scene:
                 self._tex = np.ascontiguousarray(texture, dtype=np.uint8)
             else:
                 tex_path = texture or default_texture(data_dir)
-                if tex_path and not os.path.isabs(tex_path) and not os.path.exists(tex_path):
+                if tex_path and not tex_path.startswith("procedural:") and not os.path.isabs(tex_path) and not os.path.exists(tex_path):
                     tex_path = os.path.join(data_dir, "scenes", tex_path)
         tp, tw, th = (self._tex.ctypes.data, self._tex.shape[1], self._tex.shape[0]) if self._tex is not None else (None, 0, 0)
         if uplift not in ("ours", "meng", "jh"):
@@ -199,6 +199,28 @@ class Renderer:
         """Enqueue the render on `stream` into the device buffer at d_ptr (W*H float4)."""
         p = self.params(**over)
         self._check(self._lib.ssx_render_device(self._ctx, C.byref(p), C.c_void_p(d_ptr), C.c_void_p(stream)))
+
+    def upload_scene_desc(self, desc):
+        """Replace the scene by an arbitrary ssx_scene_desc (the flat description the C ABI takes)."""
+        self._check(self._lib.ssx_upload_scene(self._ctx, C.byref(desc) if not hasattr(desc, "contents") else desc))
+
+    def debug_eval(self, op, inputs, out_words):
+        """ssx_debug_eval: `inputs` is an [n, in_words] array of 32-bit words (float32 or uint32 views);
+        returns a uint32 array [n, out_words] (view it as float32 where the op returns floats)."""
+        x = np.ascontiguousarray(inputs)
+        assert x.ndim == 2 and x.dtype.itemsize == 4
+        out = np.zeros((x.shape[0], out_words), dtype=np.uint32)
+        self._check(self._lib.ssx_debug_eval(self._ctx, op, x.ctypes.data, x.shape[1], out.ctypes.data, out_words, x.shape[0]))
+        return out
+
+    def debug_samples(self, **over):
+        """ssx_debug_samples: per-sample (xyza [H, W, spp, 4], final PCG32 state [H, W, spp] uint64, levels [H, W, spp])."""
+        p = self.params(**over)
+        xyza = np.zeros((p.height, p.width, p.spp, 4), dtype=np.float32)
+        state = np.zeros((p.height, p.width, p.spp), dtype=np.uint64)
+        levels = np.zeros((p.height, p.width, p.spp), dtype=np.uint32)
+        self._check(self._lib.ssx_debug_samples(self._ctx, C.byref(p), xyza.ctypes.data, state.ctypes.data, levels.ctypes.data))
+        return xyza, state, levels
 
     def set_timing(self, enable=True):
         self._check(self._lib.ssx_set_timing(self._ctx, int(enable)))

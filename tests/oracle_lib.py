@@ -56,7 +56,31 @@ class Stats(C.Structure):
     _fields_ = [
         (n, C.c_uint64)
         for n in "rays tri_tests tri_edge_pass tri_f64 interactions spectrum_lookups tex_samples".split()
-    ] + [("path_len_hist", C.c_uint64 * 11), ("samples", C.c_uint64), ("hits", C.c_uint64)]
+    ] + [("path_len_hist", C.c_uint64 * 11), ("samples", C.c_uint64), ("hits", C.c_uint64)] + [
+        (n, C.c_uint64)
+        for n in ("sphtri_regular sphtri_half_pi sphtri_only_a sphtri_nan light_pdf_inf arvo_denom_zero "
+                  "arvo_sin_alpha_le0 funcbar_zero coshemi_retries lemire_redraws nee_front nee_visible draws").split()
+    ]
+
+    def as_dict(self):
+        return {n: (list(getattr(self, n)) if n == "path_len_hist" else int(getattr(self, n))) for n, _ in self._fields_}
+
+
+class QuadIn(C.Structure):
+    _fields_ = [("pos", (C.c_float * 3) * 4), ("st", (C.c_float * 2) * 4), ("material", C.c_int)]
+
+
+class MaterialIn(C.Structure):
+    _fields_ = [("kind", C.c_int), ("albedo_mode", C.c_int), ("albedo_spectrum", C.c_int), ("texture", C.c_int),
+                ("emission_spectrum", C.c_int)]
+
+
+class SpectrumIn(C.Structure):
+    _fields_ = [("n", C.c_int), ("low", C.c_float), ("high", C.c_float), ("data", C.POINTER(C.c_float))]
+
+
+class TextureIn(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("rgb", C.POINTER(C.c_uint8))]
 
 
 def build(force=False):
@@ -100,6 +124,11 @@ def load(variant=""):
     lib.orc_scene_create.restype = vp
     lib.orc_scene_create.argtypes = [vp, C.c_char_p, C.c_char_p, vp, C.c_int, C.c_int, C.c_float]
     lib.orc_scene_destroy.argtypes = [vp]
+    lib.orc_scene_create_custom.restype = vp
+    lib.orc_scene_create_custom.argtypes = [vp, C.POINTER(C.c_double), f32p, C.POINTER(SpectrumIn), C.c_int, C.POINTER(MaterialIn), C.c_int,
+                                            C.POINTER(TextureIn), C.c_int, C.POINTER(QuadIn), C.c_int]
+    lib.orc_scene_quad_normals.argtypes = [vp, C.c_int, f32p]
+    lib.orc_scene_light.argtypes = [vp, C.c_int]
     lib.orc_scene_set_material_kind.argtypes = [vp, C.c_int, C.c_int]
     lib.orc_scene_quad_material.argtypes = [vp, C.c_int]
     lib.orc_scene_material_rgb.argtypes = [vp, C.c_int, f32p]
@@ -109,6 +138,7 @@ def load(variant=""):
     lib.orc_render.restype = C.c_int
     lib.orc_render.argtypes = [vp, vp, C.c_uint64] + [C.c_size_t] * 7 + [C.c_int, C.c_int, vp, C.POINTER(Stats)]
     lib.orc_xyza_to_srgba.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.orc_debug_set_stats.argtypes = [C.POINTER(Stats)]
     lib.orc_rng_seed_u32.argtypes = [C.POINTER(Rng), C.c_uint32]
     lib.orc_rng_next.restype = C.c_uint32
     lib.orc_rng_next.argtypes = [C.POINTER(Rng)]
@@ -172,7 +202,7 @@ class Oracle:
     """Colour tables + one scene, with render helpers.  observer: 1931 | 2006."""
 
     def __init__(self, scene="cornell-srgb", observer=1931, texture="test-img.png", light_scale=30.0,
-                 variant="", data_dir=DATA_DIR, jh=None, meng=None, rgb=False):
+                 variant="", data_dir=DATA_DIR, jh=None, meng=None, rgb=False, custom=None):
         """jh: (res, scale, data) Jakob-Hanika model -> RENDER_MODE_SPECTRAL_JH; meng: grid dict as
         returned by ref_lib.meng_table() / simple_spectral_amd.meng.load_table -> RENDER_MODE_SPECTRAL_MENG;
         neither -> "ours".  rgb=True -> RENDER_MODE_RGB (no spectra; renders return lRGB+A)."""
@@ -194,6 +224,14 @@ class Oracle:
                                            C.c_float(meng["sample_min"]), C.c_float(meng["sample_max"]), m.ctypes.data,
                                            cells.ctypes.data, points.ctypes.data) != 0:
                 raise RuntimeError(self.lib.orc_last_error().decode())
+        if custom is not None:
+            # custom(lib, color) -> scene handle (tests/custom_scene.py: orc_scene_create_custom)
+            self.texture = None
+            self.scene = custom(self.lib, self.color)
+            if not self.scene:
+                raise RuntimeError(self.lib.orc_last_error().decode())
+            self.scene_name = "custom"
+            return
         tex = None
         if texture is not None and scene != "cornell":
             tex = texture if isinstance(texture, np.ndarray) else load_texture(
@@ -235,6 +273,25 @@ class Oracle:
         out = (C.c_float * 4)()
         self.lib.orc_render_sample(self.color, self.scene, C.byref(rng), i, j, W, H, int(indirect_only), out, None)
         return np.array(out[:], dtype=np.float32)
+
+    def samples(self, W, H, spp, seed=0, rect=None, indirect_only=False, els=True):
+        """Per-sample results for the pixel rectangle: (xyza [h, w, spp, 4] float32, final PCG32 state
+        [h, w, spp] uint64 -- i.e. the draws consumed -- and the summed stats)."""
+        i0, j0, i1, j1 = rect if rect else (0, 0, W, H)
+        xyza = np.zeros((j1 - j0, i1 - i0, spp, 4), dtype=np.float32)
+        state = np.zeros((j1 - j0, i1 - i0, spp), dtype=np.uint64)
+        st = Stats()
+        rng = Rng()
+        out = (C.c_float * 4)()
+        flags = int(indirect_only) | (0 if els else 2)
+        for j in range(j0, j1):
+            for i in range(i0, i1):
+                for k in range(spp):
+                    self.lib.orc_seed_sample(seed, j * W + i, k, C.byref(rng))
+                    self.lib.orc_render_sample(self.color, self.scene, C.byref(rng), i, j, W, H, flags, out, C.byref(st))
+                    xyza[j - j0, i - i0, k] = out[:]
+                    state[j - j0, i - i0, k] = rng.state
+        return xyza, state, st
 
     def to_srgba(self, xyza):
         xyza = np.ascontiguousarray(xyza, dtype=np.float32)

@@ -99,3 +99,35 @@ def test_cli_abort_saves_the_partial_render(cli, tmp_path):
     assert "Aborting: saving the partial render" in se and "Render completed in" in so
     data = np.fromfile(out, dtype="<f4", offset=len("PF\n2048 2048\n-1.0\n")).reshape(2048, 2048, 3)
     assert np.isfinite(data).all() and data.max() > 0.0
+
+
+def _png_of(srgba):
+    return np.floor(np.clip(np.float32(255.0) * srgba, 0, 255) + np.float32(0.5)).astype(np.uint8)[::-1]   # std::round, src/framebuffer.cpp:141-165
+
+
+@pytest.mark.gpu
+def test_cli_multi_device_combine_on_the_device(cli, tmp_path):
+    """`--gpus=N`: every device renders its tiles into its own HBM, device 0 pulls the peers' framebuffers
+    device-to-device and adds them with a kernel (ssx_accumulate_peer; the reference's worker threads
+    share one framebuffer instead, src/renderer.cpp:340-379).  SSX_TEST_ONE_GPU=1 puts all contexts on
+    device 0, so the whole path -- tile split, peer copy, add, read-back -- runs on a 1-GPU box; the image
+    must be the oracle's (= the single-device image)."""
+    from PIL import Image
+    out = str(tmp_path / "m.png")
+    env = dict(os.environ, SSX_TEST_ONE_GPU="1")
+    r = subprocess.run([cli, "-s=cornell-srgb", "-w=72", "-h=40", "-spp=5", "-o=" + out, "--texture=data/scenes/test-img.png", "--seed=4", "--gpus=3"],
+                       cwd=ROOT, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr
+    o = ol.Oracle("cornell-srgb", texture="test-img.png")
+    assert np.array_equal(np.asarray(Image.open(out)), _png_of(o.to_srgba(o.render(72, 40, 5, seed=4))))
+
+
+@pytest.mark.gpu
+def test_cli_procedural_texture(cli, tmp_path):
+    from PIL import Image
+    from simple_spectral_amd import textures
+    out = str(tmp_path / "p.png")
+    r = run(cli, "-s=plane-srgb", "-w=48", "-h=48", "-spp=3", "-o=" + out, "--texture=procedural:1024:3")
+    assert r.returncode == 0, r.stderr
+    o = ol.Oracle("plane-srgb", texture=textures.procedural_texture(1024, 3))
+    assert np.array_equal(np.asarray(Image.open(out)), _png_of(o.to_srgba(o.render(48, 48, 3))))

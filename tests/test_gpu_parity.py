@@ -146,6 +146,12 @@ def test_async_interface_progress_and_stop():
     assert not r.is_rendering()
     assert 0.0 < r.progress() < 1.0
     assert np.isfinite(r.xyza).all()
+    # the partial image is the mean over the samples DONE (not dimmed by done/total): alpha = hit fraction,
+    # and it equals a complete render of that many samples bit for bit
+    done = int(round(r.progress() * 4096))
+    assert done % 8 == 0 and abs(float(r.xyza[..., 3].mean()) - 0.947) < 0.01
+    full, _ = gpu_render(scene_name="cornell-srgb", res=(256, 256), spp=done, texture="test-img.png")
+    assert np.array_equal(bits(r.xyza), bits(full))
 
 
 def test_error_codes():
@@ -186,6 +192,72 @@ def test_jakob_hanika_uplift_bit_exact(scene):
     assert np.isfinite(ref).mean() > 0.9
     ours = ol.Oracle(scene, texture="test-img.png").render(48, 40, 5, seed=4)
     assert not np.array_equal(bits(ours), bits(ref))        # the variant really changes textured pixels
+
+
+def test_config3_named_combination_cornell_with_jakob_hanika():
+    """BASELINE configs[2] as named: scene "cornell" (spectral materials, no texture) built with the
+    Jakob-Hanika uplift -- arithmetically a no-op there, but the JH blob layout (scale[] in LDS, table
+    pointer) runs on that scene; small image against the oracle, then the full 512x512 spp=1024 size with
+    oracle spot tiles at full spp."""
+    r = Renderer(Options(scene_name="cornell", res=(48, 40), spp=5, seed=4, uplift="jh", jh_res=16))
+    r.render_start(); r.render_wait()
+    o = ol.Oracle("cornell", jh=r.scene.jh_model())
+    assert np.array_equal(bits(r.xyza), bits(o.render(48, 40, 5, seed=4)))
+    assert np.array_equal(bits(r.xyza), bits(ol.Oracle("cornell").render(48, 40, 5, seed=4)))   # no textured surface: same image
+    a, _ = gpu_render(scene_name="cornell", res=(512, 512), spp=1024, uplift="jh", jh_res=16)
+    for (i0, j0) in ((248, 248), (40, 464)):
+        ref = o.render(512, 512, 1024, rect=(i0, j0, i0 + 8, j0 + 8))
+        assert np.array_equal(bits(a[j0:j0 + 8, i0:i0 + 8]), bits(ref[j0:j0 + 8, i0:i0 + 8])), (i0, j0)
+    assert np.isfinite(a).all()
+
+
+def test_config4_per_gpu_share_plane_srgb_1024_spp4096_tile_split():
+    """BASELINE configs[3]: plane-srgb 1024x1024 spp=4096 on 4 GPUs = every rank renders the tiles
+    t % 4 == rank at spp 4096.  One rank's share at full size: foreign tiles exactly zero, two of its own
+    tiles against the oracle at full spp."""
+    W = H = 1024
+    rank, world = 1, 4
+    a, _ = gpu_render(scene_name="plane-srgb", res=(W, H), spp=4096, texture="crystal-lizard-512.png", tile_first=rank, tile_stride=world)
+    mask = sdist.tile_owner_mask(W, H, rank, world)
+    assert not a[~mask].any() and np.isfinite(a).all()
+    assert abs(float(a[mask][:, 3].mean()) - 1.0) < 1e-6      # every camera ray hits the plane or the light box
+    o = ol.Oracle("plane-srgb", texture="crystal-lizard-512.png")
+    for tile in (1 + 4 * 1000, 1 + 4 * 3000):                  # tiles of this rank (tile % 4 == 1)
+        tx, ty = tile % (W // 8), tile // (W // 8)
+        i0, j0 = tx * 8, ty * 8
+        ref = o.render(W, H, 4096, rect=(i0, j0, i0 + 8, j0 + 8))
+        assert np.array_equal(bits(a[j0:j0 + 8, i0:i0 + 8]), bits(ref[j0:j0 + 8, i0:i0 + 8])), tile
+
+
+def test_config5_per_gpu_share_cornell_srgb_2048_cie2006():
+    """BASELINE configs[4]: cornell-srgb 2048x2048 spp=16384, CIE 2006 observer, on 8 GPUs = every rank
+    renders the tiles t % 8 == rank at spp 16384 (8.6 G samples per GPU).  One rank's share at full size."""
+    W = H = 2048
+    rank, world = 5, 8
+    a, _ = gpu_render(scene_name="cornell-srgb", observer=2006, res=(W, H), spp=16384, texture="crystal-lizard-512.png", tile_first=rank, tile_stride=world)
+    mask = sdist.tile_owner_mask(W, H, rank, world)
+    assert not a[~mask].any() and np.isfinite(a).all()
+    assert abs(float(a[mask][:, 3].mean()) - 0.947) < 0.004
+    o = ol.Oracle("cornell-srgb", observer=2006, texture="crystal-lizard-512.png")
+    tile = rank + 8 * 4100
+    tx, ty = tile % (W // 8), tile // (W // 8)
+    i0, j0 = tx * 8, ty * 8
+    ref = o.render(W, H, 16384, rect=(i0, j0, i0 + 8, j0 + 8), nthreads=1)
+    assert np.array_equal(bits(a[j0:j0 + 8, i0:i0 + 8]), bits(ref[j0:j0 + 8, i0:i0 + 8]))
+
+
+@pytest.mark.parametrize("scene,W,H,spp", [("cornell-srgb", 128, 128, 16), ("plane-srgb", 192, 192, 4)])
+def test_4096_texture_footprint(scene, W, H, spp):
+    """The reference's -srgb scenes open a 4096x4096 texture (src/scene.cpp:292,357; 48 MiB of RGB8, beyond
+    the 32 MiB of aggregate L2); its blob is missing from the repository, so a seeded procedural texture of
+    that size stands in (SURVEY.md section 8(d) iii)."""
+    from simple_spectral_amd import textures
+    tex = textures.procedural_texture(4096, 1)
+    got, r = gpu_render(scene_name=scene, res=(W, H), spp=spp, seed=2, texture="procedural:4096")   # the host library's generator
+    ref = ol.Oracle(scene, texture=tex).render(W, H, spp, seed=2)                                    # the numpy generator
+    assert np.array_equal(bits(got), bits(ref))
+    small = ol.Oracle(scene, texture="crystal-lizard-512.png").render(W, H, spp, seed=2)
+    assert not np.array_equal(bits(small), bits(ref))
 
 
 def test_jakob_hanika_lizard_texture_config1_shape():

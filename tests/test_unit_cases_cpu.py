@@ -1,0 +1,71 @@
+"""CPU side of the per-function and crafted-scene parity tests: the inputs really reach the rare
+branches (oracle branch counters), and the custom-scene path of the oracle equals its built-in
+scenes.  The GPU side (tests/test_gpu_units.py) compares the HIP functions with these results."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import crafted
+import custom_scene as cs
+import oracle_lib as ol
+import unit_cases as uc
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("scene", ["cornell", "cornell-srgb", "plane-srgb"])
+def test_custom_scene_description_reproduces_the_builtin_scene(scene):
+    c = cs.CustomScene(scene)
+    o = c.oracle()
+    assert np.array_equal(bits(o.render(40, 32, 3, seed=5)), bits(ol.Oracle(scene).render(40, 32, 3, seed=5)))
+    d = c.desc(o)
+    assert d.n_quads == (7 if scene == "plane-srgb" else 19) and d.n_lights == (6 if scene == "plane-srgb" else 1)
+
+
+@pytest.mark.parametrize("view,need", [
+    ("edge_ab", ("sphtri_half_pi", "sphtri_nan", "light_pdf_inf", "arvo_sin_alpha_le0", "tri_f64")),
+    ("edge_bc", ("sphtri_only_a", "sphtri_nan", "light_pdf_inf", "tri_f64")),
+    ("far", ("sphtri_nan", "light_pdf_inf")),
+    ("room", ("sphtri_regular", "sphtri_half_pi", "sphtri_only_a", "sphtri_nan", "light_pdf_inf", "nee_visible")),
+])
+def test_degenerate_light_scene_reaches_the_ladder(view, need):
+    """src/util/spherical-tri.cpp:74-123, src/geometry.cpp:115"""
+    o = crafted.degenerate_light_scene(view).oracle()
+    img, st = o.render(24, 24, 4, seed=1, stats=True)
+    d = st.as_dict()
+    for k in need:
+        assert d[k] > 50, (k, d[k])
+    assert np.isfinite(img).all()  # the NaN directions never pass `n_dot_l > 0` (src/renderer.cpp:193)
+
+
+def test_shared_edge_scene_reaches_the_f64_fallback():
+    """src/geometry.cpp:56-67"""
+    o = crafted.shared_edge_scene().oracle()
+    img, st = o.render(24, 24, 4, seed=1, stats=True)
+    assert st.tri_f64 > 2000 and st.hits == st.samples
+
+
+def test_unit_inputs_cover_the_branches():
+    lib = ol.load()
+    st = ol.Stats()
+    lib.orc_debug_set_stats(C.byref(st))
+    try:
+        tri = uc.sphtri_inputs()
+        uc.oracle_sphtri(lib, tri)
+        assert st.sphtri_regular > 3000 and st.sphtri_half_pi > 100 and st.sphtri_only_a > 100 and st.sphtri_nan > 100
+        words = uc.arvo_inputs(lib)
+        uc.oracle_arvo(lib, words)
+        assert st.arvo_denom_zero >= 4 and st.arvo_sin_alpha_le0 > 100 and st.funcbar_zero > 10
+        w = uc.coshemi_inputs()
+        before = st.coshemi_retries
+        uc.oracle_coshemi(lib, w)
+        assert st.coshemi_retries - before >= 40 == int(uc.coshemi_draws(w).sum())
+        w = uc.rand_choice_inputs()
+        before = st.lemire_redraws
+        uc.oracle_rand_choice(lib, w)
+        assert st.lemire_redraws - before >= int(uc.lemire_redraws(w).sum()) > 300
+    finally:
+        lib.orc_debug_set_stats(None)
