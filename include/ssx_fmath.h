@@ -216,4 +216,66 @@ SSX_FM_FN float ssx_acosf(float xf) {
 	return (float)r;
 }
 
+/* ---- device variants over the LDS coefficient table (HIP kernels that define SSX_FM_TABLE) -------------
+ * Same definition, same operations on the same operands -- hence the same bits as the functions above --
+ * arranged for a wave whose lanes need different cases at once: instead of evaluating both kernels
+ * (ksin and kcos) or both range forms of acos and selecting, every lane fetches ITS coefficients /
+ * constants from the table at a per-lane offset and runs one evaluation.  The table order above is part
+ * of this: S8..S1 and C9..C2 are two runs of eight, {PIO2_HI, PIO2_LO}, {PI_HI, PI_LO} two pairs.
+ * tests/test_gpu_units.py sweeps all 2^32 inputs against the functions above on the device. */
+#ifdef SSX_FM_TABLE
+/* sin(r) if !odd, cos(r) if odd, |r| <= pi/4: one Horner chain over the lane's coefficient run */
+SSX_FM_FN double ssx_fm_ksincos_sel(double r, int odd) {
+	const double* c = SSX_FM_TABLE + (odd ? SSX_FM_I_C9 : SSX_FM_I_S8);
+	const double z = r * r;
+	double p = c[0];
+	p = SSX_FMA(p, z, c[1]);
+	p = SSX_FMA(p, z, c[2]);
+	p = SSX_FMA(p, z, c[3]);
+	p = SSX_FMA(p, z, c[4]);
+	p = SSX_FMA(p, z, c[5]);
+	p = SSX_FMA(p, z, c[6]);
+	p = SSX_FMA(p, z, c[7]);
+	/* ksin: fma(r*z, p, r);  kcos: fma(z*z, p, 1 - 0.5*z)   (1 - 0.5*z == fma(-0.5, z, 1): 0.5*z is exact) */
+	const double m = z * (odd ? z : r);
+	const double t = odd ? SSX_FMA(-0.5, z, 1.0) : r;
+	return SSX_FMA(m, p, t);
+}
+SSX_FM_FN float ssx_sinf_lds(float xf) {
+	double x = (double)xf;
+	double ax = x < 0.0 ? -x : x;
+	if (!(ax <= 1048576.0)) return SSX_FM_NAN;
+	double r;
+	int n = ssx_fm_reduce(x, &r);
+	double v = ssx_fm_ksincos_sel(r, n & 1);
+	if (n & 2) v = -v;
+	return (float)v;
+}
+SSX_FM_FN float ssx_cosf_lds(float xf) {
+	double x = (double)xf;
+	double ax = x < 0.0 ? -x : x;
+	if (!(ax <= 1048576.0)) return SSX_FM_NAN;
+	double r;
+	int n = ssx_fm_reduce(x, &r);
+	double v = ssx_fm_ksincos_sel(r, (n + 1) & 1);
+	if ((n + 1) & 2) v = -v;
+	return (float)v;
+}
+/* acos: the range constants {c_hi, c_lo} come from the table by case instead of through selects */
+SSX_FM_FN float ssx_acosf_lds(float xf) {
+	double x = (double)xf;
+	double ax = x < 0.0 ? -x : x;
+	if (!(ax <= 1.0)) return SSX_FM_NAN;
+	const int big = ax > 0.5;
+	double z = big ? SSX_FMA(-0.5, ax, 0.5) : x * x;   /* (1-|x|)*0.5: both steps exact, so is the fused form */
+	double s = big ? __builtin_sqrt(z) : x;
+	double t = SSX_FMA(s * z, ssx_fm_asin_poly(z), s);
+	double m = big ? t + t : t;
+	const double* c = SSX_FM_TABLE + (big ? SSX_FM_I_PI_HI : SSX_FM_I_PIO2_HI);
+	double r = c[0] - (m - c[1]);
+	if (big && !(x < 0.0)) r = m;
+	return (float)r;
+}
+#endif
+
 #endif /* SSX_FMATH_H */

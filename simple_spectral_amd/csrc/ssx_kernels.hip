@@ -511,10 +511,10 @@ __device__ __forceinline__ void sphtri_make(V3 A, V3 B, V3 C, SphTri& t) {
 	float cos_a = clamp_glm(dot3(B, C), -1.0f, 1.0f);
 	float cos_b = clamp_glm(dot3(A, C), -1.0f, 1.0f);
 	float cos_c = clamp_glm(dot3(A, B), -1.0f, 1.0f);
-	float a = clamp_glm(ssx_acosf(cos_a), 0.0f, under_pi);
-	float b = clamp_glm(ssx_acosf(cos_b), 0.0f, under_pi);
-	float c = clamp_glm(ssx_acosf(cos_c), 0.0f, under_pi);
-	float sin_a = ssx_sinf(a), sin_b = ssx_sinf(b), sin_c = ssx_sinf(c);
+	float a = clamp_glm(ssx_acosf_lds(cos_a), 0.0f, under_pi);
+	float b = clamp_glm(ssx_acosf_lds(cos_b), 0.0f, under_pi);
+	float c = clamp_glm(ssx_acosf_lds(cos_c), 0.0f, under_pi);
+	float sin_a = ssx_sinf_lds(a), sin_b = ssx_sinf_lds(b), sin_c = ssx_sinf_lds(c);
 	float numer0 = cos_a - cos_b * cos_c;
 	float numer1 = cos_b - cos_c * cos_a;
 	float numer2 = cos_c - cos_a * cos_b;
@@ -528,13 +528,13 @@ __device__ __forceinline__ void sphtri_make(V3 A, V3 B, V3 C, SphTri& t) {
 	// cos_alpha = clamp(numer0/denom0) and acos of it are shared by the regular case (:64,:67) and
 	// the "only a is 0 or pi" case (:111-112)
 	const float cos_alpha0 = clamp_glm(numer0 / denom0, -1.0f, 1.0f);
-	const float alpha_raw = ssx_acosf(cos_alpha0);
+	const float alpha_raw = ssx_acosf_lds(cos_alpha0);
 	float alpha = clamp_glm(alpha_raw, 0.0f, under_pi), cos_alpha = cos_alpha0, area = 0.0f;
 	if (regular) {
 		float cos_beta  = clamp_glm(numer1 / denom1, -1.0f, 1.0f);
 		float cos_gamma = clamp_glm(numer2 / denom2, -1.0f, 1.0f);
-		float beta  = clamp_glm(ssx_acosf(cos_beta ), 0.0f, under_pi);
-		float gamma = clamp_glm(ssx_acosf(cos_gamma), 0.0f, under_pi);
+		float beta  = clamp_glm(ssx_acosf_lds(cos_beta ), 0.0f, under_pi);
+		float gamma = clamp_glm(ssx_acosf_lds(cos_gamma), 0.0f, under_pi);
 		area = alpha + beta + gamma - SSX_PI_F;
 		if (area >= 0); else area = 0;
 	} else {
@@ -560,7 +560,7 @@ __device__ __forceinline__ V3 func_bar(V3 x, V3 y) { // util/random.cpp:139-144
 __device__ __forceinline__ V3 rand_toward_sphericaltri(Rng& rng, const SphTri& tri) {
 	float r0 = rand_1f(rng);
 	float r1 = rand_1f(rng);
-	float sin_alpha = ssx_sinf(tri.alpha);
+	float sin_alpha = ssx_sinf_lds(tri.alpha);
 	float q;
 	if (sin_alpha > 0) {
 		float random_area = r0 * tri.area;
@@ -573,7 +573,7 @@ __device__ __forceinline__ V3 rand_toward_sphericaltri(Rng& rng, const SphTri& t
 		if (denom != 0.0f) q = ((v * t - u * s) * tri.cos_alpha - v) / denom;
 		else q = tri.cos_c;
 	} else {
-		q = ssx_cosf(tri.b * r0); // random.cpp:134 (double cos of a float, rounded back)
+		q = ssx_cosf_lds(tri.b * r0); // random.cpp:134 (double cos of a float, rounded back)
 	}
 	q = clamp_glm(q, -1.0f, 1.0f);
 	V3 C_hat = add(scl(q, tri.A), scl(__builtin_sqrtf(1 - q * q), func_bar(tri.C, tri.A)));

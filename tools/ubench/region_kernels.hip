@@ -29,8 +29,8 @@ extern "C" __global__ void k_arvo(SsxKernelArgs a, float* in, float* out) {
 	V3 d = rand_toward_sphericaltri(r, st);
 	SINK(out, d.x + d.y + d.z + (float)r.state);
 }
-extern "C" __global__ void k_acos(SsxKernelArgs a, float* in, float* out) { Lds L; L.w = stage_lds(a); SINK(out, ssx_acosf(in[threadIdx.x])); }
-extern "C" __global__ void k_sin(SsxKernelArgs a, float* in, float* out) { Lds L; L.w = stage_lds(a); SINK(out, ssx_sinf(in[threadIdx.x])); }
+extern "C" __global__ void k_acos(SsxKernelArgs a, float* in, float* out) { Lds L; L.w = stage_lds(a); SINK(out, ssx_acosf_lds(in[threadIdx.x])); }
+extern "C" __global__ void k_sin(SsxKernelArgs a, float* in, float* out) { Lds L; L.w = stage_lds(a); SINK(out, ssx_sinf_lds(in[threadIdx.x])); }
 extern "C" __global__ void k_sincos(SsxKernelArgs a, float* in, float* out) { Lds L; L.w = stage_lds(a); float s, c; ssx_sincosf(in[threadIdx.x], &s, &c); SINK(out, s + c); }
 extern "C" __global__ void k_stage_only(SsxKernelArgs a, float* in, float* out) { Lds L; L.w = stage_lds(a); SINK(out, in[threadIdx.x]); }
 extern "C" __global__ void k_ray_setup(SsxKernelArgs a, float* in, float* out) {
