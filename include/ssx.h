@@ -227,6 +227,22 @@ enum {
 	SSX_DBG_RAND_1F = 10      /* in: rng[4]                             out: rand_1f, rng state lo, hi (src/util/random.hpp:68-70) */
 };
 /* rng[4] = PCG32 {state lo, state hi, inc lo, inc hi} */
+/* ssx_debug_sweep: device-side comparison of a cheaper device function with the function that DEFINES the
+ * result, over the 32-bit patterns [lo, lo+count) (count up to 2^32 = every float): result[0] = number of
+ * inputs with a different result (NaN matches NaN), result[1] = op-specific maximum, result[2] = examples
+ * stored, result[3..10] = mismatching inputs. */
+enum {
+	SSX_SWEEP_RCP = 1,         /* ssx_exact::rcp(x) vs 1.0f / x */
+	SSX_SWEEP_SQRT = 2,        /* ssx_exact::sqrt_normal(x) vs sqrtf(x) */
+	SSX_SWEEP_INVERSESQRT = 3, /* the kernel's inversesqrt vs 1.0f / sqrtf(x) (glm::inversesqrt) */
+	SSX_SWEEP_SIN = 4,         /* kernel variant of ssx_sinf vs include/ssx_fmath.h */
+	SSX_SWEEP_COS = 5,
+	SSX_SWEEP_ACOS = 6,
+	SSX_SWEEP_DIV_PI = 7,      /* x / pi_f through the binary64 reciprocal constant vs IEEE division */
+	SSX_SWEEP_RCP64 = 8,       /* binary64 reciprocal of a float: result[1] = largest error in ulps of 1.0 / (double)x */
+	SSX_SWEEP_DIV_PAIRS = 9    /* x / hash(x), x / (hash with x's exponent), hash(x) / x through div64 vs IEEE division */
+};
+int ssx_debug_sweep(ssx_ctx* ctx, uint32_t op, uint32_t lo, uint64_t count, uint64_t result[11]);
 int ssx_debug_eval(ssx_ctx* ctx, uint32_t op, const void* in, uint32_t in_words, void* out, uint32_t out_words, uint32_t n);
 /* One launch of the whole image (tile_first 0, tile_stride 1), per-sample results in [j][i][k] order:
  * xyza = what Renderer::_render_sample returns (float4), rng_state = the sample's PCG32 state after its

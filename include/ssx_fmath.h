@@ -261,19 +261,29 @@ SSX_FM_FN float ssx_cosf_lds(float xf) {
 	if ((n + 1) & 2) v = -v;
 	return (float)v;
 }
-/* acos: the range constants {c_hi, c_lo} come from the table by case instead of through selects */
+/* acos: the range constants {c_hi, c_lo} come from the table by case instead of through selects, and the
+ * correctly rounded binary64 sqrt of the upper range -- the compiler's expansion is 19 instructions around
+ * v_rsq_f64 -- is replaced by a binary32 reciprocal-square-root seed (z = (1-|x|)/2 is a float there) and
+ * two Newton steps in binary64.  Whether that gives the same float for every input is not argued but
+ * checked: the device sweep compares this function with ssx_acosf on all 2^32 inputs. */
 SSX_FM_FN float ssx_acosf_lds(float xf) {
-	double x = (double)xf;
-	double ax = x < 0.0 ? -x : x;
-	if (!(ax <= 1.0)) return SSX_FM_NAN;
-	const int big = ax > 0.5;
-	double z = big ? SSX_FMA(-0.5, ax, 0.5) : x * x;   /* (1-|x|)*0.5: both steps exact, so is the fused form */
-	double s = big ? __builtin_sqrt(z) : x;
-	double t = SSX_FMA(s * z, ssx_fm_asin_poly(z), s);
-	double m = big ? t + t : t;
+	const float axf = __builtin_fabsf(xf);
+	if (!(axf <= 1.0f)) return SSX_FM_NAN;
+	const int big = axf > 0.5f;
+	const float zf = __builtin_fmaf(-0.5f, axf, 0.5f);   /* (1-|x|)/2, exact in binary32 for |x| in (0.5, 1] */
+	const double x = (double)xf;
+	const double z = big ? (double)zf : x * x;
+	const double y = (double)__builtin_amdgcn_rsqf(__builtin_fmaxf(zf, 0x1p-126f)); /* z = 0 (|x| = 1): sq stays 0 */
+	const double h = 0.5 * y;
+	double sq = z * y;
+	sq = SSX_FMA(SSX_FMA(-sq, sq, z), h, sq);
+	sq = SSX_FMA(SSX_FMA(-sq, sq, z), h, sq);
+	const double s = big ? sq : x;
+	const double t = SSX_FMA(s * z, ssx_fm_asin_poly(z), s);
+	const double m = t * (big ? 2.0 : 1.0);            /* t + t == 2*t */
 	const double* c = SSX_FM_TABLE + (big ? SSX_FM_I_PI_HI : SSX_FM_I_PIO2_HI);
 	double r = c[0] - (m - c[1]);
-	if (big && !(x < 0.0)) r = m;
+	if (big && !(xf < 0.0f)) r = m;
 	return (float)r;
 }
 #endif

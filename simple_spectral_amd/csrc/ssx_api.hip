@@ -133,6 +133,7 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	h.spec_xbar = s->spec_xbar; h.spec_ybar = s->spec_ybar; h.spec_zbar = s->spec_zbar;
 	h.spec_basis_r = s->spec_basis_r; h.spec_basis_g = s->spec_basis_g; h.spec_basis_b = s->spec_basis_b;
 	h.n_textures = s->n_textures;
+	h.n_lights_recip = 1.0 / (double)(float)s->n_lights;
 	{
 		const ssx_spectrum &r = s->spectra[s->spec_basis_r], &g = s->spectra[s->spec_basis_g], &b = s->spectra[s->spec_basis_b];
 		const ssx_spectrum &ox = s->spectra[s->spec_xbar], &oy = s->spectra[s->spec_ybar], &oz = s->spectra[s->spec_zbar];
@@ -145,7 +146,31 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	h.off_quads = off;     off = align4(off + s->n_quads * (uint32_t)(sizeof(SsxBlobQuad) / 4));
 	h.off_lights = off;    off = align4(off + s->n_lights);
 	h.off_spectra = off;   off = align4(off + s->n_spectra * (uint32_t)(sizeof(SsxBlobSpectrum) / 4));
-	const uint32_t off_samples = off; off = align4(off + s->n_samples);
+	// every table gets one zero sample in front and one behind (hero_index in ssx_kernels.hip)
+	// A table gets LDS space only if the kernels read it as a table of its own: a material's emission /
+	// constant albedo, or a basis / observer table that is not covered by its interleaved copy below.
+	std::vector<uint8_t> table_needed(s->n_spectra, 0);
+	for (uint32_t i = 0; i < s->n_materials; ++i) {
+		table_needed[s->materials[i].emission_spectrum] = 1;
+		if (s->materials[i].albedo_mode == SSX_ALBEDO_CONSTANT) table_needed[s->materials[i].albedo_spectrum] = 1;
+	}
+	if (!h.basis_one_grid) table_needed[s->spec_basis_r] = table_needed[s->spec_basis_g] = table_needed[s->spec_basis_b] = 1;
+	if (!h.observer_one_grid) table_needed[s->spec_xbar] = table_needed[s->spec_ybar] = table_needed[s->spec_zbar] = 1;
+	std::vector<uint32_t> sample_pos(s->n_spectra);
+	const uint32_t off_samples = off;
+	for (uint32_t i = 0; i < s->n_spectra; ++i) {
+		if (!table_needed[i]) { sample_pos[i] = 0u; continue; } // descriptor keeps (low, delta_recip, n) for the shared index; no samples
+		sample_pos[i] = off + 1u; off += s->spectra[i].n + 2u;
+	}
+	off = align4(off);
+	auto one_grid4 = [&](uint32_t ia, uint32_t flag) -> uint32_t { // interleaved float4 copy of three tables on one grid
+		if (!flag) return 0u;
+		const uint32_t at = off + 4u; // element -1 sits at `off`
+		off = align4(off + 4u * (s->spectra[ia].n + 2u));
+		return at;
+	};
+	h.off_basis4 = one_grid4(s->spec_basis_r, h.basis_one_grid);
+	h.off_observer4 = one_grid4(s->spec_xbar, h.observer_one_grid);
 	h.off_lut = off;       off = align4(off + 256u);
 	h.off_tex = off;       off = align4(off + s->n_textures * (uint32_t)(sizeof(SsxBlobTexture) / 4));
 	h.uplift = s->uplift;
@@ -184,7 +209,7 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 		bq[q].kind = m.kind; bq[q].albedo_mode = m.albedo_mode; bq[q].albedo_tex = m.albedo_texture;
 		auto desc = [&](uint32_t id) {
 			SsxBlobSpectrum d;
-			d.offset = off_samples + s->spectra[id].offset; d.n = s->spectra[id].n;
+			d.offset = sample_pos[id]; d.n = s->spectra[id].n;
 			d.low = s->spectra[id].low; d.delta_recip = s->spectra[id].delta_recip;
 			return d;
 		};
@@ -198,12 +223,24 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	memcpy(blob.data() + h.off_lights, s->lights, 4 * s->n_lights);
 	SsxBlobSpectrum* bs = reinterpret_cast<SsxBlobSpectrum*>(blob.data() + h.off_spectra);
 	for (uint32_t i = 0; i < s->n_spectra; ++i) {
-		bs[i].offset = off_samples + s->spectra[i].offset;
+		bs[i].offset = sample_pos[i];
 		bs[i].n = s->spectra[i].n;
 		bs[i].low = s->spectra[i].low;
 		bs[i].delta_recip = s->spectra[i].delta_recip;
+		if (sample_pos[i]) memcpy(blob.data() + sample_pos[i], s->samples + s->spectra[i].offset, 4 * (size_t)s->spectra[i].n); // blob is zero-filled: the guards stay 0
 	}
-	memcpy(blob.data() + off_samples, s->samples, 4 * (size_t)s->n_samples);
+	(void)off_samples;
+	auto fill4 = [&](uint32_t at, uint32_t ia, uint32_t ib, uint32_t ic) {
+		if (!at) return;
+		float* dst = reinterpret_cast<float*>(blob.data() + at);
+		for (uint32_t k = 0; k < s->spectra[ia].n; ++k) {
+			dst[4 * k + 0] = s->samples[s->spectra[ia].offset + k];
+			dst[4 * k + 1] = s->samples[s->spectra[ib].offset + k];
+			dst[4 * k + 2] = s->samples[s->spectra[ic].offset + k];
+		}
+	};
+	fill4(h.off_basis4, s->spec_basis_r, s->spec_basis_g, s->spec_basis_b);
+	fill4(h.off_observer4, s->spec_xbar, s->spec_ybar, s->spec_zbar);
 	memcpy(blob.data() + h.off_lut, s->srgb_to_linear, 4 * 256);
 	if (s->uplift == SSX_UPLIFT_JH) memcpy(blob.data() + h.off_jh_scale, s->jh_scale, 4 * (size_t)s->jh_res);
 	SsxBlobTexture* bt = reinterpret_cast<SsxBlobTexture*>(blob.data() + h.off_tex);
@@ -814,6 +851,29 @@ int ssx_debug_eval(ssx_ctx* ctx, uint32_t op, const void* in, uint32_t in_words,
 	return rc;
 }
 
+int ssx_debug_sweep(ssx_ctx* ctx, uint32_t op, uint32_t lo, uint64_t count, uint64_t result[11]) {
+	if (!ctx || !result || count == 0 || count > (1ull << 32)) return SSX_ERR_ARG;
+	if (!ctx->have_scene) return fail(ctx, SSX_ERR_STATE, "no scene uploaded");
+	if (ctx->rendering.load()) return fail(ctx, SSX_ERR_STATE, "render in progress");
+	SSX_HIP(ctx, hipSetDevice(ctx->device));
+	unsigned long long* d_res = nullptr;
+	SSX_HIP(ctx, hipMalloc((void**)&d_res, 11 * sizeof(unsigned long long)));
+	auto run = [&]() -> int {
+		SSX_HIP(ctx, hipMemsetAsync(d_res, 0, 11 * sizeof(unsigned long long), ctx->stream));
+		SsxKernelArgs a{};
+		a.blob = ctx->d_blob; a.blob_words = ctx->blob_words;
+		const size_t lds = ((size_t)ctx->blob_words + SSX_LDS_PREFIX_WORDS) * 4;
+		hipLaunchKernelGGL(ssx_debug_sweep_kernel, dim3(256 * 16), dim3(256), lds, ctx->stream, a, op, lo, (uint64_t)count, d_res);
+		SSX_HIP(ctx, hipGetLastError());
+		SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		SSX_HIP(ctx, hipMemcpy(result, d_res, 11 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+		return SSX_OK;
+	};
+	int rc = run();
+	(void)hipFree(d_res);
+	return rc;
+}
+
 int ssx_debug_samples(ssx_ctx* ctx, const ssx_render_params* p, float* xyza, uint64_t* rng_state, uint32_t* levels) {
 	if (!ctx) return SSX_ERR_ARG;
 	int rc = check_params(ctx, p);
@@ -848,6 +908,14 @@ int ssx_debug_samples(ssx_ctx* ctx, const ssx_render_params* p, float* xyza, uin
 	}
 	return SSX_OK;
 }
+
+#ifdef SSX_LANESTAT // profiling build only (tools/lanestat.py)
+int ssx_lanestat(unsigned long long* out, int reset) {
+	if (reset) { unsigned long long z[2 * SSX_NSTAT] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lanestat), z, sizeof z); }
+	(void)hipDeviceSynchronize();
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lanestat), 2 * SSX_NSTAT * sizeof(unsigned long long));
+}
+#endif
 
 int ssx_plan_info(ssx_ctx* ctx, float* frames_per_sample, int* fold_in_path_kernel) {
 	if (!ctx) return SSX_ERR_ARG;

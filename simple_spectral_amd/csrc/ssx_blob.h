@@ -26,7 +26,7 @@
 #define SSX_PERM_WORDS_PER_QUAD (6u * 12u)
 
 struct SsxBlobSpectrum { // 4 words
-	uint32_t offset; // word offset of the first sample from the blob start
+	uint32_t offset; // word offset of the first sample from the blob start; the words at offset-1 and offset+n are 0
 	uint32_t n;
 	float low, delta_recip;
 };
@@ -60,7 +60,11 @@ struct SsxBlobHeader {
 	// Jakob-Hanika uplift (uplift == 3): scale[jh_res] in the blob, coefficient table in HBM
 	uint32_t uplift, jh_res, off_jh_scale, jh_data_lo, jh_data_hi;
 	uint32_t observer_one_grid; // the three observer tables share (low, delta_recip, n)
-	uint32_t pad_[2];
+	// tables on one grid, interleaved as float4 {a, b, c, 0} with one zero element in front and one behind
+	// (word offset of element 0, 16-byte aligned; valid when the *_one_grid flag is set)
+	uint32_t off_basis4, off_observer4;
+	double n_lights_recip;      // RN64(1 / (double)(float)n_lights): `pdf /= float(lights.size())` (scene.cpp:430) as one multiply (ssx_exact.h)
+	double pad2_;
 };
 static_assert(sizeof(SsxBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 

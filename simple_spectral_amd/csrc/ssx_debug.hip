@@ -19,6 +19,61 @@ __device__ __forceinline__ uint32_t u(float x) { return __float_as_uint(x); }
 
 } // namespace
 
+// Exhaustive / hashed sweeps on the device: for every 32-bit pattern x in [lo, lo + count) compare a cheaper
+// function with the function that defines the result.  res[0] = mismatches, res[1] = a per-op maximum
+// (rcp64: largest error in ulps), res[2] = stored examples, res[3..] = up to 8 mismatching inputs.
+__device__ __forceinline__ uint32_t sweep_hash(uint32_t h) {
+	h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+	return h;
+}
+__device__ __forceinline__ bool same_float(float a, float b) { return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b); }
+extern "C" __global__ void __launch_bounds__(256) ssx_debug_sweep_kernel(SsxKernelArgs a, uint32_t op, uint32_t lo, uint64_t count, unsigned long long* res) {
+	Lds L; L.w = stage_lds(a);
+	(void)L;
+	unsigned long long bad = 0, mx = 0;
+	uint32_t example = 0; bool have_example = false;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint32_t bits = lo + (uint32_t)i;
+		const float x = __uint_as_float(bits);
+		bool ok = true;
+		switch (op) {
+		case SSX_SWEEP_RCP: ok = same_float(ssx_exact::rcp(x), 1.0f / x); break;
+		case SSX_SWEEP_SQRT: ok = same_float(ssx_exact::sqrt_normal(x), __builtin_sqrtf(x)); break;
+		case SSX_SWEEP_INVERSESQRT: ok = same_float(inversesqrt_(x), 1.0f / __builtin_sqrtf(x)); break;
+		case SSX_SWEEP_SIN: ok = same_float(ssx_sinf_lds(x), ssx_sinf(x)); break;
+		case SSX_SWEEP_COS: ok = same_float(ssx_cosf_lds(x), ssx_cosf(x)); break;
+		case SSX_SWEEP_ACOS: ok = same_float(ssx_acosf_lds(x), ssx_acosf(x)); break;
+		case SSX_SWEEP_DIV_PI: ok = same_float(SSX_DIV_CONST(x, SSX_PI_F), x / SSX_PI_F); break;
+		case SSX_SWEEP_RCP64: { // accuracy of the binary64 reciprocal behind div64_*: error in ulps of the correctly rounded 1/x
+			const double r = ssx_exact::div64_rcp_any(x), t = 1.0 / (double)x;
+			if (r != r || t != t) { ok = (r != r) == (t != t); break; }
+			const long long d = (long long)__double_as_longlong(r) - (long long)__double_as_longlong(t);
+			const unsigned long long ad = (unsigned long long)(d < 0 ? -d : d);
+			mx = ad > mx ? ad : mx;
+			ok = ad <= 1ull;
+			break;
+		}
+		case SSX_SWEEP_DIV_PAIRS: { // a = this pattern, b = hashes of it (arbitrary patterns, and the same exponent range as a)
+			const uint32_t h = sweep_hash(bits ^ 0x9E3779B9u);
+			const float b1 = __uint_as_float(h);
+			const float b2 = __uint_as_float((bits & 0x7F800000u) | (h & 0x807FFFFFu)); // same exponent: quotients in [0.5, 2)
+			const double r1 = ssx_exact::div64_rcp_any(b1), r2 = ssx_exact::div64_rcp_any(b2);
+			ok = same_float(ssx_exact::div64_by(x, r1), x / b1) && same_float(ssx_exact::div64_by(x, r2), x / b2) &&
+			     same_float(ssx_exact::div64_by(b1, ssx_exact::div64_rcp_any(x)), b1 / x);
+			break;
+		}
+		default: break;
+		}
+		if (!ok) { ++bad; if (!have_example) { example = bits; have_example = true; } }
+	}
+	if (bad) {
+		atomicAdd(&res[0], bad);
+		const unsigned long long slot = atomicAdd(&res[2], 1ull);
+		if (slot < 8ull) res[3 + slot] = example;
+	}
+	if (mx) atomicMax(&res[1], mx);
+}
+
 extern "C" __global__ void __launch_bounds__(256) ssx_debug_eval_kernel(SsxKernelArgs a, uint32_t op, const uint32_t* in, uint32_t in_words,
                                                                        uint32_t* out, uint32_t out_words, uint32_t n) {
 	Lds L; L.w = stage_lds(a);

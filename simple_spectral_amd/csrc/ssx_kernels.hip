@@ -25,6 +25,8 @@
 #include <stdint.h>
 
 #include "ssx_blob.h"
+#include "ssx_exact.h"
+#include "ssx_lanestat.h"
 // The polynomial coefficients of ssx_fmath.h are read from LDS, filled at kernel start from the
 // header's own list: as literals the compiler hoists these loop-invariant 64-bit constants into ~20
 // VGPRs for the whole path kernel.  They sit at the start of the dynamic LDS area, in front of the
@@ -56,7 +58,8 @@ __device__ __forceinline__ V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, 
 __device__ __forceinline__ V3 scl(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
 // GLM order: dot = t.x+t.y+t.z, cross, normalize = v*(1/sqrt(dot))
 __device__ __forceinline__ float dot3(V3 a, V3 b) { float tx = a.x * b.x, ty = a.y * b.y, tz = a.z * b.z; return tx + ty + tz; }
-__device__ __forceinline__ float inversesqrt_(float x) { return 1.0f / __builtin_sqrtf(x); }
+// glm::inversesqrt(x) = 1/sqrt(x): two roundings, each reproduced exactly (ssx_exact.h) in 11 instead of 28 instructions
+__device__ __forceinline__ float inversesqrt_(float x) { return ssx_exact::rcp(ssx_exact::sqrt_normal(x)); }
 __device__ __forceinline__ V3 normalize3(V3 v) { float s = inversesqrt_(dot3(v, v)); return mk(v.x * s, v.y * s, v.z * s); }
 __device__ __forceinline__ float fmax_glm(float a, float b) { return (a < b) ? b : a; }
 __device__ __forceinline__ float fmin_glm(float a, float b) { return (b < a) ? b : a; }
@@ -126,25 +129,25 @@ struct Lds {
 struct Hero { float v[4]; };
 
 // spectrum.cpp:39-67: linear reconstruction, zero outside the table; lambda_i = l0 + float(i)*STEP.
-// Branch-free: both table reads of all four wavelengths are issued together at clamped indices and
-// the out-of-range ones replaced by 0 afterwards (same values as the reference's guarded reads).
-// The index/fraction part depends only on the table's grid (low, delta_recip, n), so tables on one
-// grid (the three basis spectra) share it.
-struct HeroIndex { uint32_t c0[4], c1[4]; float frac[4]; bool ok0[4], ok1[4]; };
+// Every table in the blob carries one zero sample in front of its first and one behind its last sample, so
+// the reference's guarded reads (`i0>=0&&i0<size ? data[i0] : 0`) are plain reads at the index clamped to
+// [-1, n] (one v_med3_i32) -- the same values, no compare/select.  The index/fraction part depends only on
+// the table's grid (low, delta_recip, n), so tables on one grid (the three basis spectra, the three observer
+// curves) share it; for those the blob also holds the three tables interleaved as float4 {a, b, c, 0}, so
+// that one 16-byte LDS read fetches a sample of all three.
+struct HeroIndex { int c0[4], c1[4]; float frac[4]; };
 __device__ __forceinline__ HeroIndex hero_index(const SsxBlobSpectrum sp, float lambda_0, float step) {
 	HeroIndex h;
+	const int n = (int)sp.n;
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		float lambda = lambda_0 + (float)i * step;
 		float x = (lambda - sp.low) * sp.delta_recip;
 		float i0f = __builtin_floorf(x);
 		h.frac[i] = x - i0f;
-		int i0 = (int)i0f;
-		int i1 = i0 + 1;
-		h.ok0[i] = (uint32_t)i0 < sp.n; // i0 >= 0 && i0 < n
-		h.ok1[i] = (uint32_t)i1 < sp.n;
-		h.c0[i] = min((uint32_t)max(i0, 0), sp.n - 1u);
-		h.c1[i] = min((uint32_t)max(i1, 0), sp.n - 1u);
+		int i0 = (int)i0f; // v_cvt_i32_f32 saturates; lambda stays within a few steps of the tables anyway
+		h.c0[i] = min(max(i0, -1), n);
+		h.c1[i] = min(max(i0 + 1, -1), n);
 	}
 	return h;
 }
@@ -155,11 +158,22 @@ __device__ __forceinline__ Hero hero_gather(const Lds& L, uint32_t offset, const
 	for (int i = 0; i < 4; ++i) { v0[i] = data[h.c0[i]]; v1[i] = data[h.c1[i]]; }
 	Hero out;
 #pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		float val0 = h.ok0[i] ? v0[i] : 0.0f, val1 = h.ok1[i] ? v1[i] : 0.0f;
-		out.v[i] = val0 * (1.0f - h.frac[i]) + val1 * h.frac[i]; // math-helpers.hpp:10-12
-	}
+	for (int i = 0; i < 4; ++i) out.v[i] = v0[i] * (1.0f - h.frac[i]) + v1[i] * h.frac[i]; // math-helpers.hpp:10-12
 	return out;
+}
+// three tables on one grid, interleaved {a, b, c, 0} at word offset `offset4` (16-byte aligned)
+__device__ __forceinline__ void hero_gather3(const Lds& L, uint32_t offset4, const HeroIndex& h, Hero& a, Hero& b, Hero& c) {
+	const float4* data = reinterpret_cast<const float4*>(L.w + offset4);
+	float4 v0[4], v1[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) { v0[i] = data[h.c0[i]]; v1[i] = data[h.c1[i]]; }
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const float w0 = 1.0f - h.frac[i], w1 = h.frac[i];
+		a.v[i] = v0[i].x * w0 + v1[i].x * w1;
+		b.v[i] = v0[i].y * w0 + v1[i].y * w1;
+		c.v[i] = v0[i].z * w0 + v1[i].z * w1;
+	}
 }
 __device__ __forceinline__ Hero spectrum_hero(const Lds& L, const SsxBlobSpectrum sp, float lambda_0, float step) {
 	return hero_gather(L, sp.offset, hero_index(sp, lambda_0, step));
@@ -331,8 +345,7 @@ __device__ __forceinline__ Hero texture_sample(const Lds& L, uint32_t tex_index,
 	Hero br, bg, bb;
 	const SsxBlobSpectrum sr = L.spectrum(h.spec_basis_r), sg = L.spectrum(h.spec_basis_g), sb = L.spectrum(h.spec_basis_b);
 	if (h.basis_one_grid) { // wave-uniform: r, g, b tables have the same (low, delta_recip, n)
-		const HeroIndex hi = hero_index(sr, lambda_0, h.lambda_step);
-		br = hero_gather(L, sr.offset, hi); bg = hero_gather(L, sg.offset, hi); bb = hero_gather(L, sb.offset, hi);
+		hero_gather3(L, h.off_basis4, hero_index(sr, lambda_0, h.lambda_step), br, bg, bb);
 	} else {
 		br = spectrum_hero(L, sr, lambda_0, h.lambda_step);
 		bg = spectrum_hero(L, sg, lambda_0, h.lambda_step);
@@ -352,16 +365,19 @@ __device__ __forceinline__ Hero material_albedo(const Lds& L, const SsxBlobQuad&
 // util/color.hpp:115-139
 __device__ __forceinline__ void flux_to_xyz(const Lds& L, const Hero& flux, float lambda_0, float out[3]) {
 	const SsxBlobHeader& h = L.hdr();
-	const uint32_t ids[3] = { h.spec_xbar, h.spec_ybar, h.spec_zbar };
-	const SsxBlobSpectrum sx = L.spectrum(ids[0]);
-	const HeroIndex shared = hero_index(sx, lambda_0, h.lambda_step); // the CIE tables share one grid (wave-uniform flag)
+	Hero bar[3];
+	if (h.observer_one_grid) { // wave-uniform: the CIE tables share one grid
+		hero_gather3(L, h.off_observer4, hero_index(L.spectrum(h.spec_xbar), lambda_0, h.lambda_step), bar[0], bar[1], bar[2]);
+	} else {
+		bar[0] = spectrum_hero(L, h.spec_xbar, lambda_0, h.lambda_step);
+		bar[1] = spectrum_hero(L, h.spec_ybar, lambda_0, h.lambda_step);
+		bar[2] = spectrum_hero(L, h.spec_zbar, lambda_0, h.lambda_step);
+	}
 #pragma unroll
 	for (int ch = 0; ch < 3; ++ch) {
-		const SsxBlobSpectrum sp = L.spectrum(ids[ch]);
-		Hero bar = h.observer_one_grid ? hero_gather(L, sp.offset, shared) : spectrum_hero(L, sp, lambda_0, h.lambda_step);
 		float acc = 0.0f;
 #pragma unroll
-		for (int i = 0; i < 4; ++i) acc += (bar.v[i] * flux.v[i]) * h.lambda_step;
+		for (int i = 0; i < 4; ++i) acc += (bar[ch].v[i] * flux.v[i]) * h.lambda_step;
 		out[ch] = acc;
 	}
 }
@@ -386,9 +402,11 @@ __device__ __forceinline__ RaySetup ray_setup(V3 orig, V3 dir) {
 	if (swapped) { uint32_t t = kx; kx = ky; ky = t; }
 	RaySetup rs;
 	float dkz = comp(dir, kz);
-	rs.Sx = comp(dir, kx) / dkz;
-	rs.Sy = comp(dir, ky) / dkz;
-	rs.Sz = 1.0f / dkz;
+	// three IEEE divisions by one divisor: one binary64 reciprocal, one multiply each (exact: ssx_exact.h)
+	const double dkz_recip = ssx_exact::div64_rcp_any(dkz);
+	rs.Sx = ssx_exact::div64_by(comp(dir, kx), dkz_recip);
+	rs.Sy = ssx_exact::div64_by(comp(dir, ky), dkz_recip);
+	rs.Sz = ssx_exact::div64_by(1.0f, dkz_recip);
 	rs.okx = comp(orig, kx); rs.oky = comp(orig, ky); rs.okz = comp(orig, kz);
 	rs.perm = 2u * kz + swapped;
 	return rs;
@@ -421,6 +439,15 @@ __device__ __forceinline__ SV shear_vertex(const float* pv, int v, const RaySetu
 	return s;
 }
 
+__device__ __forceinline__ SV shear_xyz(float x, float y, float z, const RaySetup& rs) {
+	float rx = x - rs.okx, ry = y - rs.oky, rz = z - rs.okz;
+	SV s;
+	s.x = rx - rs.Sx * rz;
+	s.y = ry - rs.Sy * rz;
+	s.z = rz;
+	return s;
+}
+
 // scene.cpp:433-445 + geometry.cpp:128-139 + geometry.cpp:12-101.
 // Pass 1 (all quads, uniform loop): edge functions U,V,W of both triangles from the four shared
 // sheared vertices; a triangle whose nonzero edge values have mixed signs can never be accepted
@@ -430,7 +457,7 @@ __device__ __forceinline__ SV shear_vertex(const float* pv, int v, const RaySetu
 // dist, closest-so-far with strict '<' -- and skip tri1 when tri0 of the same quad was accepted
 // (the `goto HIT` of PrimQuad::intersect).
 // has_ray = false: the lane takes part in the wave-uniform pass 1 but traces nothing.
-__device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_quad, bool has_ray, HitInfo& hit) {
+__device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_quad, bool has_ray, HitInfo& hit, int stat_base = 0) {
 	const RaySetup rs = ray_setup(orig, dir);
 	const uint32_t nq = L.hdr().n_quads;
 	uint64_t cand = 0;
@@ -457,16 +484,20 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 	hit.tri = -1;
 	hit.dist = __builtin_inff();
 	hit.U = hit.V = hit.W = hit.det_recip = 0.0f;
+	SSX_STAT(stat_base); // lanes holding a ray (of the lanes that called)
 	while (cand) {
+		SSX_STAT(stat_base + 1); // pass-2 trips x lanes with a candidate
 		uint32_t bit = (uint32_t)__builtin_ctzll(cand);
 		cand &= cand - 1ull;
 		uint32_t q = bit >> 1, which = bit & 1u;
-		float pv[12];
-		load_perm(L.perm(q, rs.perm), pv);
-		SV A = shear_vertex(pv, 0, rs);
-		SV v1 = shear_vertex(pv, 1, rs), v2 = shear_vertex(pv, 2, rs), v3 = shear_vertex(pv, 3, rs);
-		SV B = which ? v2 : v1;
-		SV C = which ? v3 : v2;
+		// the candidate's three vertices only: A = vertex 0, B = vertex 1 + which, C = vertex 2 + which of
+		// { x0 y0 x1 y1 x2 y2 x3 y3 | z0 z1 z2 z3 }
+		const float* pq = L.perm(q, rs.perm);
+		const float2 Axy = *reinterpret_cast<const float2*>(pq);
+		const float2 Bxy = *reinterpret_cast<const float2*>(pq + 2u + 2u * which);
+		const float2 Cxy = *reinterpret_cast<const float2*>(pq + 4u + 2u * which);
+		const float pv3[9] = { Axy.x, Axy.y, pq[8], Bxy.x, Bxy.y, pq[9u + which], Cxy.x, Cxy.y, pq[10u + which] };
+		SV A = shear_xyz(pv3[0], pv3[1], pv3[2], rs), B = shear_xyz(pv3[3], pv3[4], pv3[5], rs), C = shear_xyz(pv3[6], pv3[7], pv3[8], rs);
 		float U = B.y * C.x - B.x * C.y;
 		float V = C.y * A.x - C.x * A.y;
 		float W = A.y * B.x - A.x * B.y;
@@ -485,7 +516,7 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		float Az = rs.Sz * A.z, Bz = rs.Sz * B.z, Cz = rs.Sz * C.z;
 		float T = U * Az + V * Bz + W * Cz;
 		if ((__float_as_uint(det) ^ __float_as_uint(T)) & 0x80000000u) continue;
-		float det_recip = 1.0f / det;
+		float det_recip = ssx_exact::rcp(det);
 		float dist = T * det_recip;
 		if (dist >= SSX_EPS && dist < hit.dist) {
 			hit.tri = (int)bit; hit.dist = dist;
@@ -576,10 +607,10 @@ __device__ __forceinline__ V3 rand_toward_sphericaltri(Rng& rng, const SphTri& t
 		q = ssx_cosf_lds(tri.b * r0); // random.cpp:134 (double cos of a float, rounded back)
 	}
 	q = clamp_glm(q, -1.0f, 1.0f);
-	V3 C_hat = add(scl(q, tri.A), scl(__builtin_sqrtf(1 - q * q), func_bar(tri.C, tri.A)));
+	V3 C_hat = add(scl(q, tri.A), scl(ssx_exact::sqrt_normal(1 - q * q), func_bar(tri.C, tri.A)));
 	float z = 1.0f - r1 * (1.0f - dot3(C_hat, tri.B));
 	z = clamp_glm(z, -1.0f, 1.0f);
-	return add(scl(z, tri.B), scl(__builtin_sqrtf(1 - z * z), func_bar(C_hat, tri.B)));
+	return add(scl(z, tri.B), scl(ssx_exact::sqrt_normal(1 - z * z), func_bar(C_hat, tri.B)));
 }
 
 // scene.cpp:417-431 -> geometry.cpp:141-145 -> geometry.cpp:103-116
@@ -596,9 +627,9 @@ __device__ __forceinline__ void sample_light(const Lds& L, Rng& rng, V3 from, V3
 	            normalize3(sub(mk(p1[0], p1[1], p1[2]), from)),
 	            normalize3(sub(mk(p2[0], p2[1], p2[2]), from)), st);
 	dir = rand_toward_sphericaltri(rng, st);
-	pdf = 1.0f / st.area;
+	pdf = ssx_exact::rcp(st.area);
 	pdf *= 0.5f;
-	pdf /= (float)nl;
+	pdf = ssx_exact::div64_by(pdf, L.hdr().n_lights_recip); // pdf /= float(n_lights): the divisor's binary64 reciprocal comes with the scene
 }
 
 // ------------------------------------------------------------------ BSDF sampling ----
@@ -610,8 +641,8 @@ __device__ __forceinline__ V3 rand_coshemi(Rng& rng, float& pdf) {
 		float s, c;
 		ssx_sincosf(angle, &s, &c);
 		float radius_sq = rand_1f(rng);
-		float radius = __builtin_sqrtf(radius_sq);
-		result = mk(radius * c, __builtin_sqrtf(1 - radius_sq), radius * s);
+		float radius = ssx_exact::sqrt_normal(radius_sq);
+		result = mk(radius * c, ssx_exact::sqrt_normal(1 - radius_sq), radius * s);
 		pdf = result.y;
 	} while (pdf <= SSX_EPS);
 	pdf *= 1.0f / SSX_PI_F;
@@ -620,7 +651,7 @@ __device__ __forceinline__ V3 rand_coshemi(Rng& rng, float& pdf) {
 // util/math-helpers.hpp:14-39
 __device__ __forceinline__ V3 get_rotated_to(V3 dir, V3 n) {
 	float sign = __builtin_copysignf(1.0f, n.z);
-	float a = -1.0f / (sign + n.z);
+	float a = -ssx_exact::rcp(sign + n.z); // -1.0f / x == -(1.0f / x)
 	float b = n.x * n.y * a;
 	V3 bx = mk(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
 	V3 bz = mk(b, sign + n.y * n.y * a, -n.y);
@@ -711,6 +742,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	const SsxBlobHeader& h = L.hdr();
 	const uint32_t level_index = p.depth * (uint32_t)a.n_records + p.rec_index; // < 2^32 per launch (host budget)
 	if (hit.tri < 0) { a.direct[level_index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); return false; }
+	SSX_STAT(4); // lanes with a hit
 	p.hit_anything = true;
 	const uint32_t hq = (uint32_t)hit.tri >> 1, which = (uint32_t)hit.tri & 1u;
 	const SsxBlobQuad& Q = L.quad(hq);
@@ -724,6 +756,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	// stdafx.hpp:44) every hit adds its emission unconditionally (:166-175).
 	const bool els = a.no_els == 0u;
 	if ((els ? (p.depth == 0u && !a.indirect_only) : true) && M.is_emissive != 0u) {
+		SSX_STAT(5); // emission lookup
 		Hero em = spectrum_hero(L, M.emission, p.lambda_0, h.lambda_step);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) direct[k] += em.v[k];
@@ -737,39 +770,49 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	V3 hit_pos = add(p.orig, scl(hit.dist, p.dir)); // Ray::at
 	// hitrec.st (geometry.cpp:91-95) is read only by textured albedo
 	float st_x = 0.0f, st_y = 0.0f;
-	if (M.albedo_mode != 0u) hit_st(Q, which, hit, st_x, st_y);
+	if (M.albedo_mode != 0u) { SSX_STAT(6); hit_st(Q, which, hit, st_x, st_y); } else { SSX_STAT(7); } // textured / constant albedo
 	// albedo(lambda) is shared by evaluate_bsdf and interact_bsdf (material.cpp:120-143)
 	Hero alb = material_albedo(L, Q, st_x, st_y, p.lambda_0);
 	float f_lamb[4];
 #pragma unroll
-	for (int k = 0; k < 4; ++k) f_lamb[k] = alb.v[k] / SSX_PI_F;
+	for (int k = 0; k < 4; ++k) f_lamb[k] = SSX_DIV_CONST(alb.v[k], SSX_PI_F);
 
 	// direct lighting (:182-219): sample the light; the shadow ray is parked (see ShadowQ)
 	if (els && (!a.indirect_only || p.depth > 0u)) {
 		V3 sdir; uint32_t light; float spdf;
+		SSX_STAT(8); // light sampling
 		sample_light(L, p.rng, hit_pos, sdir, light, spdf);
 		float n_dot_l = dot3(sdir, N);
 		if (n_dot_l > 0.0f) {
+			SSX_STAT(9); // next-event contribution
 			Hero emitted = spectrum_hero(L, L.quad(light).emission, p.lambda_0, h.lambda_step);
 			float c[4];
+			const double spdf_recip = ssx_exact::div64_rcp_any(spdf); // spdf may be +inf (zero-area light triangle)
 #pragma unroll
 			for (int k = 0; k < 4; ++k) {
 				float fs = (M.kind == 0u) ? f_lamb[k] : 0.0f; // Mirror::evaluate_bsdf -> 0
-				c[k] = ((emitted.v[k] * n_dot_l) * fs) / spdf;
+				c[k] = ssx_exact::div64_by((emitted.v[k] * n_dot_l) * fs, spdf_recip);
 			}
-			const uint64_t pushing = __ballot(1);
-			const uint32_t slot = q.count + __builtin_amdgcn_mbcnt_hi((uint32_t)(pushing >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushing, 0u));
-			float4* E = q.e + 3u * slot;
-			E[0] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, sdir.x);
-			E[1] = make_float4(sdir.y, sdir.z, c[0], c[1]);
-			E[2] = make_float4(c[2], c[3], __uint_as_float((light << 8) | hq), __uint_as_float(level_index));
-			pushed = true;
+			// A contribution of four zeros (zero-area light triangle: pdf = +inf, src/geometry.cpp:115; black or mirror
+			// surface) cannot change `direct`, which is a sum of non-negative terms starting from +0 (x + 0 == x), so
+			// its shadow ray is not traced.  NaN != 0: NaN contributions are parked and added like any other.
+			if (c[0] != 0.0f || c[1] != 0.0f || c[2] != 0.0f || c[3] != 0.0f) {
+				SSX_STAT(10); // shadow rays parked
+				const uint64_t pushing = __ballot(1);
+				const uint32_t slot = q.count + __builtin_amdgcn_mbcnt_hi((uint32_t)(pushing >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushing, 0u));
+				float4* E = q.e + 3u * slot;
+				E[0] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, sdir.x);
+				E[1] = make_float4(sdir.y, sdir.z, c[0], c[1]);
+				E[2] = make_float4(c[2], c[3], __uint_as_float((light << 8) | hq), __uint_as_float(level_index));
+				pushed = true;
+			}
 		}
 	}
 
 	// indirect lighting (:222-250)
 	V3 w_i; float pdf_w_i; float f_s[4];
 	if (M.kind == 0u) {
+		SSX_STAT(11); // BSDF sample
 		w_i = rand_coshemi(p.rng, pdf_w_i);
 		w_i = get_rotated_to(w_i, N);
 #pragma unroll
@@ -797,6 +840,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	// values / pi) and pdf (in (EPS/pi, 1/pi], or 1 for a mirror) are finite and pdf > 0.
 	if (!cont || (els && p.depth + 2u >= SSX_MAX_DEPTH_)) return false;
 	// the factors of the continuation for the backward fold (resolve_record, when the wave's unit is complete)
+	SSX_STAT(12); // continuing lanes
 	a.fs[level_index] = make_float4(f_s[0], f_s[1], f_s[2], f_s[3]);
 	a.np[level_index] = make_float2(n_dot_l, pdf_w_i);
 	p.orig = hit_pos; p.dir = w_i; p.ignore = (int)hq;
@@ -839,7 +883,7 @@ __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& 
 	}
 	const uint32_t tag = __float_as_uint(e2.z);
 	HitInfo sh;
-	trace(L, mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y), (int)(tag & 0xFFu), have, sh);
+	trace(L, mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y), (int)(tag & 0xFFu), have, sh, 2);
 	if (have && sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == (tag >> 8))
 		*dst = make_float4(old.x + e1.z, old.y + e1.w, old.z + e2.x, old.w + e2.y);
 }
@@ -879,15 +923,18 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 #pragma unroll
 		for (uint32_t s = 0; s < WAYS; ++s)
 			if (d < depth[s]) {
-				rad[s][0] = D[s].x + ((rad[s][0] * NP[s].x) * F[s].x) / NP[s].y;
-				rad[s][1] = D[s].y + ((rad[s][1] * NP[s].x) * F[s].y) / NP[s].y;
-				rad[s][2] = D[s].z + ((rad[s][2] * NP[s].x) * F[s].z) / NP[s].y;
-				rad[s][3] = D[s].w + ((rad[s][3] * NP[s].x) * F[s].w) / NP[s].y;
+				SSX_STAT(14); // fold: level x way x lanes
+				const double pdf_recip = ssx_exact::div64_rcp_any(NP[s].y);
+				rad[s][0] = D[s].x + ssx_exact::div64_by((rad[s][0] * NP[s].x) * F[s].x, pdf_recip);
+				rad[s][1] = D[s].y + ssx_exact::div64_by((rad[s][1] * NP[s].x) * F[s].y, pdf_recip);
+				rad[s][2] = D[s].z + ssx_exact::div64_by((rad[s][2] * NP[s].x) * F[s].z, pdf_recip);
+				rad[s][3] = D[s].w + ssx_exact::div64_by((rad[s][3] * NP[s].x) * F[s].w, pdf_recip);
 			}
 	}
 #pragma unroll
 	for (uint32_t s = 0; s < WAYS; ++s)
 		if (s < count) {
+			SSX_STAT(15); // flux -> XYZ
 			Hero flux; flux.v[0] = rad[s][0]; flux.v[1] = rad[s][1]; flux.v[2] = rad[s][2]; flux.v[3] = rad[s][3];
 			float xyz[3];
 			if (a.rgb_mode) { xyz[0] = rad[s][0]; xyz[1] = rad[s][1]; xyz[2] = rad[s][2]; } // renderer.cpp:274-276: lRGB_A_F32(pixel_flux_est, hit)
@@ -1029,7 +1076,8 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		}
 		bool pushed = false;
 		HitInfo hit; // the primary rays of all lanes: traced in uniform control flow
-		trace(L, p.orig, p.dir, p.ignore, active, hit);
+		if (active) SSX_STAT(13); // lanes with a path, per iteration
+		trace(L, p.orig, p.dir, p.ignore, active, hit, 0);
 		if (active) {
 			if (!path_step(L, sq, a, p, hit, pushed)) {
 				// last level reached (its radiance is in direct[depth]): lambda_0, the hit flag, the number of

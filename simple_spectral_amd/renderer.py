@@ -213,6 +213,12 @@ class Renderer:
         self._check(self._lib.ssx_debug_eval(self._ctx, op, x.ctypes.data, x.shape[1], out.ctypes.data, out_words, x.shape[0]))
         return out
 
+    def debug_sweep(self, op, lo=0, count=1 << 32):
+        """ssx_debug_sweep -> (mismatches, op-specific maximum, [mismatching input bit patterns])"""
+        res = (C.c_uint64 * 11)()
+        self._check(self._lib.ssx_debug_sweep(self._ctx, op, lo, count, res))
+        return int(res[0]), int(res[1]), [int(res[3 + k]) for k in range(min(int(res[2]), 8))]
+
     def debug_samples(self, **over):
         """ssx_debug_samples: per-sample (xyza [H, W, spp, 4], final PCG32 state [H, W, spp] uint64, levels [H, W, spp])."""
         p = self.params(**over)

@@ -198,3 +198,35 @@ def test_per_sample_xyza_and_draws(scene, observer, io, els):
     hist = np.bincount(levels.ravel(), minlength=10)
     assert hist.sum() == W * H * spp
     assert int((levels.astype(np.int64)).sum()) <= st.interactions
+
+
+@pytest.mark.parametrize("op,name", [
+    (_capi.SSX_SWEEP_RCP, "1.0f/x"), (_capi.SSX_SWEEP_SQRT, "sqrt"), (_capi.SSX_SWEEP_INVERSESQRT, "inversesqrt"),
+    (_capi.SSX_SWEEP_SIN, "sin"), (_capi.SSX_SWEEP_COS, "cos"), (_capi.SSX_SWEEP_ACOS, "acos"), (_capi.SSX_SWEEP_DIV_PI, "x/pi"),
+    (_capi.SSX_SWEEP_RCP64, "binary64 reciprocal"), (_capi.SSX_SWEEP_DIV_PAIRS, "division pairs")])
+def test_exhaustive_sweeps_of_the_cheaper_exact_arithmetic(cornell, op, name):
+    """Every one of the 2^32 float inputs, on the device: the kernel's cheaper forms of 1/x, sqrt, 1/sqrt,
+    x/pi, sin, cos, acos against the operation / the include/ssx_fmath.h function that DEFINES the result
+    (simple_spectral_amd/csrc/ssx_exact.h states why they are exact; this is the check), the binary64
+    reciprocal behind the shared-divisor divisions (error <= 1 ulp for every float divisor, which the
+    exactness argument needs), and 3 x 2^32 hashed (numerator, divisor) pairs through that division."""
+    r, _ = cornell
+    bad, mx, examples = r.debug_sweep(op)
+    if op in (_capi.SSX_SWEEP_SQRT, _capi.SSX_SWEEP_INVERSESQRT, _capi.SSX_SWEEP_RCP) and bad:
+        # specified domains (ssx_exact.h): sqrt_normal for x >= 2^-100, +-0, +inf, NaN and negative normal x;
+        # rcp for 2^-126 <= |x| <= 2^126 (normal input, normal result), +-0, +-inf, NaN
+        f32 = lambda v: int(np.array([v], dtype=np.float32).view(np.uint32)[0])
+        if op == _capi.SSX_SWEEP_RCP:
+            parts = [(f32(2.0 ** -126), f32(2.0 ** 126)), (f32(-2.0 ** -126), f32(-2.0 ** 126)), (0, 0), (0x80000000, 0x80000000), (0x7F800000, 0x7FFFFFFF), (0xFF800000, 0xFFFFFFFF)]
+        else:
+            parts = [(f32(2.0 ** -100), 0x7FFFFFFF), (0, 0), (0x80000000, 0x80000000), (f32(-2.0 ** -126), 0xFFFFFFFF)]
+        report = []
+        for lo, hi in parts:
+            b, _, ex = r.debug_sweep(op, lo=lo, count=hi - lo + 1)
+            report.append((hex(lo), hex(hi), b, [hex(e) for e in ex[:4]]))
+        assert all(p[2] == 0 for p in report), (name, report)
+        print("%s: exact on its specified domain; %d inputs outside it differ, e.g. %s" % (name, bad, [hex(e) for e in examples[:4]]))
+        return
+    assert bad == 0, (name, bad, [hex(e) for e in examples])
+    if op == _capi.SSX_SWEEP_RCP64:
+        assert mx <= 1
