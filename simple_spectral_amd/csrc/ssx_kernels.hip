@@ -460,8 +460,12 @@ __device__ __forceinline__ SV shear_xyz(float x, float y, float z, const RaySetu
 __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_quad, bool has_ray, HitInfo& hit, int stat_base = 0) {
 	const RaySetup rs = ray_setup(orig, dir);
 	const uint32_t nq = L.hdr().n_quads;
-	uint64_t cand = 0;
-	for (uint32_t q = 0; q < nq; ++q) {
+	// "Mixed" flag of a triangle = sign bit of fma(min3, max3, +0): negative iff min < 0 < max strictly (a zero
+	// edge value gives -0 + +0 = +0, an underflowing product keeps its sign) -- one v_fma instead of two
+	// compares and a select.  The flags are shifted into two 32-bit accumulators (16 quads each) with one
+	// v_alignbit per triangle; the filter's own arithmetic is not part of the reference's, only its verdicts are.
+	uint32_t acc0 = 0u, acc1 = 0u;
+	auto quad_flags = [&](uint32_t q, uint32_t& acc) {
 		float pv[12];
 		load_perm(L.perm(q, rs.perm), pv);
 		SV a = shear_vertex(pv, 0, rs), b = shear_vertex(pv, 1, rs), c = shear_vertex(pv, 2, rs), d = shear_vertex(pv, 3, rs);
@@ -469,15 +473,23 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		float U0 = b.y * c.x - b.x * c.y;
 		float V0 = c.y * a.x - c.x * a.y;
 		float W0 = a.y * b.x - a.x * b.y;
-		// tri1 = (A=a,B=c,C=d)
+		// tri1 = (A=a,B=c,C=d): W1 = a.y*c.x - a.x*c.y = -V0 exactly (same two products)
 		float U1 = c.y * d.x - c.x * d.y;
 		float V1 = d.y * a.x - d.x * a.y;
-		float W1 = a.y * c.x - a.x * c.y;
+		float W1 = -V0;
 		float mn0 = __builtin_fminf(__builtin_fminf(U0, V0), W0), mx0 = __builtin_fmaxf(__builtin_fmaxf(U0, V0), W0);
 		float mn1 = __builtin_fminf(__builtin_fminf(U1, V1), W1), mx1 = __builtin_fmaxf(__builtin_fmaxf(U1, V1), W1);
-		uint32_t bits = ((mn0 < 0.0f && mx0 > 0.0f) ? 0u : 1u) | ((mn1 < 0.0f && mx1 > 0.0f) ? 0u : 2u);
-		cand |= (uint64_t)bits << (2u * q);
-	}
+		acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(__builtin_fmaf(mn0, mx0, 0.0f)), 31u); // acc = acc << 1 | sign
+		acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(__builtin_fmaf(mn1, mx1, 0.0f)), 31u);
+	};
+	const uint32_t n0 = min(nq, 16u), n1 = nq - n0;
+	for (uint32_t q = 0; q < n0; ++q) quad_flags(q, acc0);
+	for (uint32_t q = 16u; q < nq; ++q) quad_flags(q, acc1);
+	// triangle k of an accumulator (k-th shifted in) sits at bit (count - 1 - k): reverse and align
+	const uint32_t mixed0 = __builtin_bitreverse32(acc0) >> (32u - 2u * n0);
+	const uint32_t mixed1 = n1 ? __builtin_bitreverse32(acc1) >> (32u - 2u * n1) : 0u;
+	const uint64_t valid = nq >= 32u ? ~0ull : ((1ull << (2u * nq)) - 1ull);
+	uint64_t cand = ~(((uint64_t)mixed1 << 32) | (uint64_t)mixed0) & valid;
 	if (ignore_quad >= 0) cand &= ~(3ull << (2u * (uint32_t)ignore_quad));
 	if (!has_ray) cand = 0ull;
 
