@@ -240,7 +240,8 @@ enum {
 	SSX_SWEEP_ACOS = 6,
 	SSX_SWEEP_DIV_PI = 7,      /* x / pi_f through the binary64 reciprocal constant vs IEEE division */
 	SSX_SWEEP_RCP64 = 8,       /* binary64 reciprocal of a float: result[1] = largest error in ulps of 1.0 / (double)x */
-	SSX_SWEEP_DIV_PAIRS = 9    /* x / hash(x), x / (hash with x's exponent), hash(x) / x through div64 vs IEEE division */
+	SSX_SWEEP_DIV_PAIRS = 9,   /* x / hash(x), x / (hash with x's exponent), hash(x) / x through div64 vs IEEE division */
+	SSX_SWEEP_ACOS_SIN = 10    /* |x| <= 1: fused {min(acos x, under_pi), its sine} vs ssx_acosf / ssx_sinf; result[1] = inputs sent to the fallback */
 };
 int ssx_debug_sweep(ssx_ctx* ctx, uint32_t op, uint32_t lo, uint64_t count, uint64_t result[11]);
 int ssx_debug_eval(ssx_ctx* ctx, uint32_t op, const void* in, uint32_t in_words, void* out, uint32_t out_words, uint32_t n);

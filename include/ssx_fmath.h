@@ -286,6 +286,52 @@ SSX_FM_FN float ssx_acosf_lds(float xf) {
 	if (big && !(xf < 0.0f)) r = m;
 	return (float)r;
 }
+/* a = min(acos(x), amax) -- the spherical-triangle code's clamp of an arc to [0, pi) -- together with
+ * sin(a), for -1 <= x <= 1 (no NaN).  sin(a) is NOT evaluated as ssx_sinf(a) would (range reduction + one
+ * of two degree-17 polynomials); with r the binary64 value of acos(x) before its rounding to a and
+ * d = a - r (|d| <= half an ulp of a, or the clamp's step),
+ *     sin(a) = sin(r) cos(d) + cos(r) sin(d) = sqrt(1 - x*x) + x*d + O(d^2),
+ * one binary64 sqrt of the exactly representable 1 - x*x (f32 rsqrt seed + two Newton steps) and one fma.
+ * Both this value and the one ssx_sinf(a) rounds are within 2^-42 (relative) of sin(a) when 1 - x*x >= 2^-10
+ * (error budget in DESIGN.md), so whenever this value lies further than 2^-36 from every binary32 rounding
+ * boundary the two round to the same float.  Otherwise -- and for |x| ~ 1 -- *sin_ok = 0 and the caller
+ * evaluates ssx_sinf_lds(a) instead (probability ~2^-11).  The device sweep checks all 2^32 inputs against
+ * ssx_sinf(min(ssx_acosf(x), amax)). */
+SSX_FM_FN float ssx_acos_sin_lds(float xf, float amax, float* sin_a, int* sin_ok) {
+	const float axf = __builtin_fabsf(xf);
+	const int big = axf > 0.5f;
+	const float zf = __builtin_fmaf(-0.5f, axf, 0.5f);
+	const double x = (double)xf;
+	const double z = big ? (double)zf : x * x;
+	const double y = (double)__builtin_amdgcn_rsqf(__builtin_fmaxf(zf, 0x1p-126f));
+	const double h = 0.5 * y;
+	double sq = z * y;
+	sq = SSX_FMA(SSX_FMA(-sq, sq, z), h, sq);
+	sq = SSX_FMA(SSX_FMA(-sq, sq, z), h, sq);
+	const double s = big ? sq : x;
+	const double t = SSX_FMA(s * z, ssx_fm_asin_poly(z), s);
+	const double m = t * (big ? 2.0 : 1.0);
+	const double* c = SSX_FM_TABLE + (big ? SSX_FM_I_PI_HI : SSX_FM_I_PIO2_HI);
+	double r = c[0] - (m - c[1]);
+	if (big && !(xf < 0.0f)) r = m;
+	const float a_raw = (float)r;
+	const float a = a_raw > amax ? amax : a_raw;
+	/* sin(a) */
+	const double w = SSX_FMA(-x, x, 1.0);               /* 1 - x*x: exact in binary64 (48 significant bits) */
+	const float wf = (float)w;
+	const double yw = (double)__builtin_amdgcn_rsqf(__builtin_fmaxf(wf, 0x1p-126f));
+	const double hw = 0.5 * yw;
+	double sw = w * yw;
+	sw = SSX_FMA(SSX_FMA(-sw, sw, w), hw, sw);
+	sw = SSX_FMA(SSX_FMA(-sw, sw, w), hw, sw);
+	const double v = SSX_FMA(x, (double)a - r, sw);
+	*sin_a = (float)v;
+	/* distance of v from a binary32 rounding boundary, in units of 2^-52 of its binade: the 29 mantissa
+	 * bits below float precision against their midpoint 2^28; 2^-36 relative = 2^16 units */
+	const unsigned lo = (unsigned)__double_as_longlong(v) & 0x1FFFFFFFu;
+	*sin_ok = (lo - (0x10000000u - 0x10000u) >= 0x20000u) && (wf >= 0x1p-10f);
+	return a;
+}
 #endif
 
 #endif /* SSX_FMATH_H */

@@ -72,7 +72,7 @@ HIP_SYMBOLS = ["ssx_create", "ssx_destroy", "ssx_upload_scene", "ssx_render_star
                "ssx_device_framebuffer", "ssx_device_index", "ssx_read_framebuffer", "ssx_accumulate_peer",
                "ssx_debug_eval", "ssx_debug_samples", "ssx_debug_sweep"]
 (SSX_SWEEP_RCP, SSX_SWEEP_SQRT, SSX_SWEEP_INVERSESQRT, SSX_SWEEP_SIN, SSX_SWEEP_COS, SSX_SWEEP_ACOS, SSX_SWEEP_DIV_PI,
- SSX_SWEEP_RCP64, SSX_SWEEP_DIV_PAIRS) = range(1, 10)
+ SSX_SWEEP_RCP64, SSX_SWEEP_DIV_PAIRS, SSX_SWEEP_ACOS_SIN) = range(1, 11)
 # ssx_debug_eval ops (include/ssx.h)
 (SSX_DBG_FMATH, SSX_DBG_SPHTRI, SSX_DBG_ARVO, SSX_DBG_SAMPLE_LIGHT, SSX_DBG_COSHEMI, SSX_DBG_TRACE, SSX_DBG_RAND_CHOICE,
  SSX_DBG_ALBEDO, SSX_DBG_FLUX_TO_XYZ, SSX_DBG_RAND_1F) = range(1, 11)

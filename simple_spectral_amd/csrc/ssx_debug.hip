@@ -44,6 +44,16 @@ extern "C" __global__ void __launch_bounds__(256) ssx_debug_sweep_kernel(SsxKern
 		case SSX_SWEEP_COS: ok = same_float(ssx_cosf_lds(x), ssx_cosf(x)); break;
 		case SSX_SWEEP_ACOS: ok = same_float(ssx_acosf_lds(x), ssx_acosf(x)); break;
 		case SSX_SWEEP_DIV_PI: ok = same_float(SSX_DIV_CONST(x, SSX_PI_F), x / SSX_PI_F); break;
+		case SSX_SWEEP_ACOS_SIN: { // the fused arc + sine of the spherical-triangle code, on its domain |x| <= 1
+			if (!(__builtin_fabsf(x) <= 1.0f)) break;
+			const float amax = __uint_as_float(0x40490FDAu);
+			float sn; int sn_ok;
+			const float arc = ssx_acos_sin_lds(x, amax, &sn, &sn_ok);
+			const float arc_ref = clamp_glm(ssx_acosf(x), 0.0f, amax);
+			ok = same_float(arc, arc_ref) && (!sn_ok || same_float(sn, ssx_sinf(arc_ref)));
+			if (!sn_ok) mx += 1; // fallbacks (per thread; summed below)
+			break;
+		}
 		case SSX_SWEEP_RCP64: { // accuracy of the binary64 reciprocal behind div64_*: error in ulps of the correctly rounded 1/x
 			const double r = ssx_exact::div64_rcp_any(x), t = 1.0 / (double)x;
 			if (r != r || t != t) { ok = (r != r) == (t != t); break; }
@@ -71,7 +81,7 @@ extern "C" __global__ void __launch_bounds__(256) ssx_debug_sweep_kernel(SsxKern
 		const unsigned long long slot = atomicAdd(&res[2], 1ull);
 		if (slot < 8ull) res[3 + slot] = example;
 	}
-	if (mx) atomicMax(&res[1], mx);
+	if (mx) { if (op == SSX_SWEEP_ACOS_SIN) atomicAdd(&res[1], mx); else atomicMax(&res[1], mx); }
 }
 
 extern "C" __global__ void __launch_bounds__(256) ssx_debug_eval_kernel(SsxKernelArgs a, uint32_t op, const uint32_t* in, uint32_t in_words,
@@ -101,6 +111,7 @@ extern "C" __global__ void __launch_bounds__(256) ssx_debug_eval_kernel(SsxKerne
 		SphTri t;
 		t.A = mk(f(x[0]), f(x[1]), f(x[2])); t.B = mk(f(x[3]), f(x[4]), f(x[5])); t.C = mk(f(x[6]), f(x[7]), f(x[8]));
 		t.b = f(x[9]); t.cos_c = f(x[10]); t.alpha = f(x[11]); t.cos_alpha = f(x[12]); t.area = f(x[13]);
+		t.sin_alpha = ssx_sinf_lds(t.alpha);
 		Rng r = load_rng(x + 14);
 		V3 d = rand_toward_sphericaltri(r, t);
 		o[0] = u(d.x); o[1] = u(d.y); o[2] = u(d.z); o[3] = (uint32_t)r.state; o[4] = (uint32_t)(r.state >> 32);

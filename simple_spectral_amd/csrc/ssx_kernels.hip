@@ -542,15 +542,16 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 struct SphTri {
 	V3 A, B, C;
 	float b, cos_c;
-	float alpha, cos_alpha;
+	float alpha, cos_alpha, sin_alpha; // sin_alpha = sin(alpha), what rand_toward_sphericaltri evaluates first (random.cpp:108)
 	float area;
 };
 
-// util/spherical-tri.cpp:18-124 (only the members rand_toward_sphericaltri and the pdf read)
-__device__ __forceinline__ void sphtri_make(V3 A, V3 B, V3 C, SphTri& t) {
+// util/spherical-tri.cpp:18-124 as written (only the members rand_toward_sphericaltri and the pdf read): every
+// clamp with glm's NaN behaviour, the degenerate ladder.  sphtri_make runs it only for the lanes its fast path
+// does not cover (a NaN vertex, or a side of 0 / pi).
+__device__ __forceinline__ void sphtri_make_general(V3 A, V3 B, V3 C, SphTri& t) {
 	const float under_pi = __uint_as_float(0x40490FDAu);
 	const float nanv = __uint_as_float(0x7FC00000u);
-	t.A = A; t.B = B; t.C = C;
 	float cos_a = clamp_glm(dot3(B, C), -1.0f, 1.0f);
 	float cos_b = clamp_glm(dot3(A, C), -1.0f, 1.0f);
 	float cos_c = clamp_glm(dot3(A, B), -1.0f, 1.0f);
@@ -564,9 +565,6 @@ __device__ __forceinline__ void sphtri_make(V3 A, V3 B, V3 C, SphTri& t) {
 	float denom0 = sin_b * sin_c;
 	float denom1 = sin_c * sin_a;
 	float denom2 = sin_a * sin_b;
-	t.b = b; t.cos_c = cos_c;
-	// results are kept in scalars and selected, never stored through the struct in branches (that
-	// made the compiler spill them to scratch)
 	const bool regular = denom0 > 0 && denom1 > 0 && denom2 > 0;
 	// cos_alpha = clamp(numer0/denom0) and acos of it are shared by the regular case (:64,:67) and
 	// the "only a is 0 or pi" case (:111-112)
@@ -588,7 +586,53 @@ __device__ __forceinline__ void sphtri_make(V3 A, V3 B, V3 C, SphTri& t) {
 		alpha = half_pi ? SSX_PI_F * 0.5f : (only_a ? alpha_raw : nanv);
 		cos_alpha = half_pi ? 1.0f : (only_a ? cos_alpha0 : nanv);
 	}
+	t.b = b; t.cos_c = cos_c;
 	t.alpha = alpha; t.cos_alpha = cos_alpha; t.area = area;
+	t.sin_alpha = ssx_sinf_lds(alpha);
+}
+
+// The same results for the case every lane is in almost always (no NaN in the vertices, all three sides
+// strictly between 0 and pi, i.e. the reference's regular branch), in about two thirds of the instructions:
+//   * without NaN, glm::clamp(x, lo, hi) is the median of the three -- one v_med3_f32 instead of two
+//     compare/select pairs -- and clamp(acos(.), 0, under_pi) is min(acos(.), under_pi) (acos >= +0);
+//   * the four sines the reference takes of arcs it has just computed with acos (sin a, sin b, sin c, and
+//     sin alpha in rand_toward_sphericaltri) come from ssx_acos_sin_lds: sqrt(1 - x^2) plus a first-order
+//     correction for the arc's rounding, with a rounding test that sends the rare ambiguous case to ssx_sinf_lds.
+// Every value is the float the general code produces; lanes that leave the case are redone by the general code.
+__device__ __forceinline__ void sphtri_make(V3 A, V3 B, V3 C, SphTri& t) {
+	const float under_pi = __uint_as_float(0x40490FDAu);
+	t.A = A; t.B = B; t.C = C;
+	const float da = dot3(B, C), db = dot3(A, C), dc = dot3(A, B);
+	const float cos_a = __builtin_amdgcn_fmed3f(da, -1.0f, 1.0f);
+	const float cos_b = __builtin_amdgcn_fmed3f(db, -1.0f, 1.0f);
+	const float cos_c = __builtin_amdgcn_fmed3f(dc, -1.0f, 1.0f);
+	float sin_a, sin_b, sin_c, sin_alpha; int ok_a, ok_b, ok_c, ok_al;
+	const float a = ssx_acos_sin_lds(cos_a, under_pi, &sin_a, &ok_a);
+	const float b = ssx_acos_sin_lds(cos_b, under_pi, &sin_b, &ok_b);
+	const float c = ssx_acos_sin_lds(cos_c, under_pi, &sin_c, &ok_c);
+	if (!ok_a) sin_a = ssx_sinf_lds(a);
+	if (!ok_b) sin_b = ssx_sinf_lds(b);
+	if (!ok_c) sin_c = ssx_sinf_lds(c);
+	const float numer0 = cos_a - cos_b * cos_c;
+	const float numer1 = cos_b - cos_c * cos_a;
+	const float numer2 = cos_c - cos_a * cos_b;
+	const float denom0 = sin_b * sin_c;
+	const float denom1 = sin_c * sin_a;
+	const float denom2 = sin_a * sin_b;
+	const float dsum = (da + db) + dc; // NaN iff a vertex holds a NaN (components of normalized vectors are finite otherwise)
+	const bool fast = (dsum == dsum) && denom0 > 0 && denom1 > 0 && denom2 > 0;
+	const float cos_alpha = __builtin_amdgcn_fmed3f(numer0 / denom0, -1.0f, 1.0f);
+	const float cos_beta  = __builtin_amdgcn_fmed3f(numer1 / denom1, -1.0f, 1.0f);
+	const float cos_gamma = __builtin_amdgcn_fmed3f(numer2 / denom2, -1.0f, 1.0f);
+	const float alpha = ssx_acos_sin_lds(cos_alpha, under_pi, &sin_alpha, &ok_al);
+	if (!ok_al) sin_alpha = ssx_sinf_lds(alpha);
+	const float beta  = __builtin_fminf(ssx_acosf_lds(cos_beta ), under_pi);
+	const float gamma = __builtin_fminf(ssx_acosf_lds(cos_gamma), under_pi);
+	float area = alpha + beta + gamma - SSX_PI_F;
+	if (area >= 0); else area = 0;
+	t.b = b; t.cos_c = cos_c;
+	t.alpha = alpha; t.cos_alpha = cos_alpha; t.sin_alpha = sin_alpha; t.area = area;
+	if (!fast) sphtri_make_general(A, B, C, t);
 }
 
 __device__ __forceinline__ V3 func_bar(V3 x, V3 y) { // util/random.cpp:139-144
@@ -603,7 +647,7 @@ __device__ __forceinline__ V3 func_bar(V3 x, V3 y) { // util/random.cpp:139-144
 __device__ __forceinline__ V3 rand_toward_sphericaltri(Rng& rng, const SphTri& tri) {
 	float r0 = rand_1f(rng);
 	float r1 = rand_1f(rng);
-	float sin_alpha = ssx_sinf_lds(tri.alpha);
+	float sin_alpha = tri.sin_alpha; // = sin(tri.alpha), random.cpp:108
 	float q;
 	if (sin_alpha > 0) {
 		float random_area = r0 * tri.area;
