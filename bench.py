@@ -30,14 +30,14 @@ sys.path.insert(0, ROOT)
 # Algorithmic FP32 work per sample, SURVEY.md section 8(d): 33*T + 28*P + 550*S + 150 with the
 # measured per-sample counts (T tri tests, P edge-test passes, S surface interactions).
 FLOP_PER_SAMPLE = {"cornell-srgb": 1.28e4, "cornell": 1.28e4, "plane-srgb": 2.8e3}
-# Algorithmic HBM bytes per sample of the whole pipeline (SoA layout), with
-# L = continued levels per sample (3.35 Cornell, 1 plane: oracle statistics at 128x128 spp 16) and R = parked
-# shadow rays per sample (3.14 Cornell, 1.36 plane), V of them visible (2.69 / 1.33):
+# Algorithmic HBM bytes per sample of the whole pipeline, with L = continued levels
+# per sample (3.35 Cornell, 1 plane: oracle statistics at 128x128 spp 16), R = parked shadow rays per sample
+# (3.14 Cornell, 1.36 plane) and E = levels with an emission term (~0.01: camera rays that hit the light):
 #   generate  : write ray 16 + stream 16
-#   path      : read ray 16 + stream 16; per level write direct 16 (L+1 levels) + fs 16 + np 8 (L levels);
-#               at the end write {lambda, hit|levels, final stream state} 16
-#   shadow    : R x read direct 16 + V x write 16
-#   fold      : read stream 16 + direct 16 (L+1) + (fs 16 + np 8) L; write XYZA 16
+#   path      : read ray 16 + stream 16; per continued level write fs 16 + np 8; emission term 16 E;
+#               at the end write {lambda, hit | levels | masks, final stream state} 16
+#   shadow    : R x write nee 16 (write-only: contribution or zeros)
+#   fold      : read stream 16 + (fs 16 + np 8) L + nee 16 R + emission 16 E; write XYZA 16
 #   accumulate: read XYZA 16
 LEVELS = {"cornell-srgb": 3.35, "cornell": 3.35, "plane-srgb": 1.0}
 SHADOW = {"cornell-srgb": (3.14, 2.69), "cornell": (3.14, 2.69), "plane-srgb": (1.36, 1.33)}
@@ -49,8 +49,9 @@ PEAK_HBM_GBS = 8000.0
 
 def algorithmic_bytes_per_sample(scene):
     L = LEVELS.get(scene, 3.35)
-    R, V = SHADOW.get(scene, (3.14, 2.69))
-    return 32 + (32 + 16 * (L + 1) + 24 * L + 16) + (16 * R + 16 * V) + (16 + 16 * (L + 1) + 24 * L + 16) + 16
+    R, _visible = SHADOW.get(scene, (3.14, 2.69))
+    E = 0.01
+    return 32 + (32 + 24 * L + 16 * E + 16) + 16 * R + (16 + 24 * L + 16 * R + 16 * E + 16) + 16
 
 
 def host_cpu_info():

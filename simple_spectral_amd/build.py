@@ -13,7 +13,7 @@ HIP_LIB = os.path.join(PKG, "libssx_hip.so")
 HOST_LIB = os.path.join(PKG, "libssx_host.so")
 
 HIP_SRC = [os.path.join(PKG, "csrc", f) for f in ("ssx_api.hip",)]
-HIP_DEPS = [os.path.join(PKG, "csrc", f) for f in ("ssx_api.hip", "ssx_kernels.hip", "ssx_blob.h")] + [
+HIP_DEPS = [os.path.join(PKG, "csrc", f) for f in ("ssx_api.hip", "ssx_kernels.hip", "ssx_debug.hip", "ssx_blob.h", "ssx_exact.h", "ssx_lanestat.h")] + [
     os.path.join(ROOT, "include", f) for f in ("ssx.h", "ssx_fmath.h")]
 HOST_SRC = [os.path.join(PKG, "host", f) for f in
             ("spectrum.cpp", "color.cpp", "jh2019.cpp", "meng2015.cpp", "scene.cpp", "image_io.cpp", "renderer.cpp", "host_api.cpp")]
@@ -39,8 +39,31 @@ def hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
+# The path kernel reads data that other lanes of the SAME wave stored, relying on gfx9 behaviour that is below
+# what the HIP memory model promises (see "Memory-ordering contract" in csrc/ssx_kernels.hip): in-order
+# vector-memory issue per wave, write-through L1, agent-scope loads served by the L2.  That was validated
+# (bit-exact GPU parity tests, incl. the many-units-per-wave stress case) on gfx950 with the ROCm major
+# versions listed here; another compiler generation has to pass `pytest -m gpu` before it is added.
+TESTED_ROCM_MAJOR = ("7",)
+
+
+def check_toolchain():
+    root = os.path.dirname(os.path.dirname(os.path.realpath(hipcc())))
+    version = ""
+    for cand in (os.path.join(root, ".info", "version"), "/opt/rocm/.info/version"):
+        if os.path.exists(cand):
+            version = open(cand).read().strip()
+            break
+    if version and version.split(".")[0] not in TESTED_ROCM_MAJOR and os.environ.get("SSX_ALLOW_UNTESTED_ROCM") != "1":
+        raise RuntimeError("ROCm %s is not a tested toolchain for libssx_hip.so (tested majors: %s): the kernel's same-wave memory "
+                           "ordering relies on validated compiler/hardware behaviour.  Run the GPU parity tests and add the version to "
+                           "simple_spectral_amd/build.py, or set SSX_ALLOW_UNTESTED_ROCM=1." % (version, ", ".join(TESTED_ROCM_MAJOR)))
+    return version
+
+
 def build_hip(force=False, verbose=False):
     if force or _stale(HIP_LIB, HIP_DEPS):
+        check_toolchain()
         cmd = [hipcc()] + HIP_FLAGS + HIP_SRC + ["-o", HIP_LIB, "-lpthread"]
         if verbose:
             print(" ".join(cmd))

@@ -134,6 +134,7 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	h.spec_basis_r = s->spec_basis_r; h.spec_basis_g = s->spec_basis_g; h.spec_basis_b = s->spec_basis_b;
 	h.n_textures = s->n_textures;
 	h.n_lights_recip = 1.0 / (double)(float)s->n_lights;
+	for (int i = 0; i < 4; ++i) { volatile float fi = (float)i; h.lambda_steps[i] = fi * s->lambda_step; } // one IEEE float multiply each, as spectrum.cpp:63
 	{
 		const ssx_spectrum &r = s->spectra[s->spec_basis_r], &g = s->spectra[s->spec_basis_g], &b = s->spectra[s->spec_basis_b];
 		const ssx_spectrum &ox = s->spectra[s->spec_xbar], &oy = s->spectra[s->spec_ybar], &oz = s->spectra[s->spec_zbar];
@@ -146,7 +147,7 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	h.off_quads = off;     off = align4(off + s->n_quads * (uint32_t)(sizeof(SsxBlobQuad) / 4));
 	h.off_lights = off;    off = align4(off + s->n_lights);
 	h.off_spectra = off;   off = align4(off + s->n_spectra * (uint32_t)(sizeof(SsxBlobSpectrum) / 4));
-	// every table gets one zero sample in front and one behind (hero_index in ssx_kernels.hip)
+	// every table gets two zero samples in front and two behind (hero_index in ssx_kernels.hip)
 	// A table gets LDS space only if the kernels read it as a table of its own: a material's emission /
 	// constant albedo, or a basis / observer table that is not covered by its interleaved copy below.
 	std::vector<uint8_t> table_needed(s->n_spectra, 0);
@@ -160,13 +161,13 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	const uint32_t off_samples = off;
 	for (uint32_t i = 0; i < s->n_spectra; ++i) {
 		if (!table_needed[i]) { sample_pos[i] = 0u; continue; } // descriptor keeps (low, delta_recip, n) for the shared index; no samples
-		sample_pos[i] = off + 1u; off += s->spectra[i].n + 2u;
+		sample_pos[i] = off + 2u; off += s->spectra[i].n + 4u;
 	}
 	off = align4(off);
 	auto one_grid4 = [&](uint32_t ia, uint32_t flag) -> uint32_t { // interleaved float4 copy of three tables on one grid
 		if (!flag) return 0u;
-		const uint32_t at = off + 4u; // element -1 sits at `off`
-		off = align4(off + 4u * (s->spectra[ia].n + 2u));
+		const uint32_t at = off + 8u; // elements -2, -1 sit at `off`
+		off = align4(off + 4u * (s->spectra[ia].n + 4u));
 		return at;
 	};
 	h.off_basis4 = one_grid4(s->spec_basis_r, h.basis_one_grid);
@@ -280,7 +281,7 @@ int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
 // Every launch writes its samples to [tile slot][k][64] float4 (16 B per sample) and the ordered
 // accumulate pass consumes them; the buffer bounds how many samples per pixel one launch may cover.
 constexpr size_t kSampleBufferBudget = (size_t)32 << 30; // bytes of per-sample arrays one launch may use (288 GB HBM)
-constexpr size_t kBytesPerSampleInFlight = SSX_BYTES_PER_SAMPLE; // 408: ray 16 + stream 16 + 10 levels x 16 + 9 x (16 + 8)
+constexpr size_t kBytesPerSampleInFlight = SSX_BYTES_PER_SAMPLE; // 568: ray 16 + stream 16 + 10 levels x (16 + 16) + 9 x (16 + 8)
 constexpr uint32_t kMinUnits = 3072;                   // one wave work unit per wave slot of the GPU (256 CUs x 4 SIMDs x 3 waves)
 
 struct LaunchPlan { SsxKernelArgs args; size_t lds_bytes; uint32_t max_spp_per_launch; };
@@ -333,6 +334,7 @@ void bind_arrays(SsxKernelArgs& a, uint8_t* base, uint64_t cap) {
 	a.ray = reinterpret_cast<float4*>(base);                      base += cap * 16u;
 	a.st = reinterpret_cast<uint4*>(base);                        base += cap * 16u;
 	a.direct = reinterpret_cast<float4*>(base);                   base += cap * 16u * SSX_MAX_LEVELS;
+	a.nee = reinterpret_cast<float4*>(base);                      base += cap * 16u * SSX_MAX_LEVELS;
 	a.fs = reinterpret_cast<float4*>(base);                       base += cap * 16u * SSX_MAX_FRAMES;
 	a.np = reinterpret_cast<float2*>(base);
 }
@@ -492,7 +494,7 @@ int calibrate(ssx_ctx* ctx) {
 	std::vector<uint4> recs((size_t)b.n_rec);
 	SSX_HIP(ctx, hipMemcpy(recs.data(), b.a.st, recs.size() * sizeof(uint4), hipMemcpyDeviceToHost));
 	uint64_t frames = 0;
-	for (const uint4& r : recs) frames += r.y >> 8;
+	for (const uint4& r : recs) frames += (r.y >> 4) & 0xFu;
 	ctx->calib_frames = (float)((double)frames / (double)recs.size());
 	ctx->fuse_resolve = ctx->calib_frames >= 2.0f;
 	return SSX_OK;
@@ -903,7 +905,7 @@ int ssx_debug_samples(ssx_ctx* ctx, const ssx_render_params* p, float* xyza, uin
 			const size_t r = ((size_t)tile * spp + k) * 64u + lane, o = ((size_t)j * p->width + i) * spp + k;
 			if (xyza) { xyza[4 * o + 0] = ray[r].x; xyza[4 * o + 1] = ray[r].y; xyza[4 * o + 2] = ray[r].z; xyza[4 * o + 3] = ray[r].w; }
 			if (rng_state) rng_state[o] = ((uint64_t)st[r].w << 32) | st[r].z;
-			if (levels) levels[o] = st[r].y >> 8;
+			if (levels) levels[o] = (st[r].y >> 4) & 0xFu;
 		}
 	}
 	return SSX_OK;

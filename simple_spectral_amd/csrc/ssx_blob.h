@@ -26,7 +26,7 @@
 #define SSX_PERM_WORDS_PER_QUAD (6u * 12u)
 
 struct SsxBlobSpectrum { // 4 words
-	uint32_t offset; // word offset of the first sample from the blob start; the words at offset-1 and offset+n are 0
+	uint32_t offset; // word offset of the first sample from the blob start; the words at offset-2, offset-1, offset+n, offset+n+1 are 0
 	uint32_t n;
 	float low, delta_recip;
 };
@@ -60,9 +60,10 @@ struct SsxBlobHeader {
 	// Jakob-Hanika uplift (uplift == 3): scale[jh_res] in the blob, coefficient table in HBM
 	uint32_t uplift, jh_res, off_jh_scale, jh_data_lo, jh_data_hi;
 	uint32_t observer_one_grid; // the three observer tables share (low, delta_recip, n)
-	// tables on one grid, interleaved as float4 {a, b, c, 0} with one zero element in front and one behind
+	// tables on one grid, interleaved as float4 {a, b, c, 0} with two zero elements in front and two behind
 	// (word offset of element 0, 16-byte aligned; valid when the *_one_grid flag is set)
 	uint32_t off_basis4, off_observer4;
+	float lambda_steps[4];      // float(i) * lambda_step, i = 0..3 (spectrum.cpp:63: lambda_0 + i*LAMBDA_STEP)
 	double n_lights_recip;      // RN64(1 / (double)(float)n_lights): `pdf /= float(lights.size())` (scene.cpp:430) as one multiply (ssx_exact.h)
 	double pad2_;
 };
@@ -77,16 +78,19 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 //   ray[r]   float4  generate: {camera ray dir.xyz, lambda_0}; the fold overwrites it with {X, Y, Z, alpha}
 //                    ({R, G, B, alpha} in RGB mode), which the accumulate pass reads
 //   st[r]    uint4   generate: PCG32 {state, inc}; at the end of the path: {lambda_0 bits, hit_anything |
-//                    #levels << 8, final PCG32 state} (the final state = draws consumed, for the per-sample tests)
-//   direct[l*n + r] float4  level l of the recursion L(): emission + next-event estimate (a parked shadow ray
-//                    adds its contribution here later); for the path's last level the level's whole radiance
+//                    #levels << 4 | mask of levels with a next-event term << 8 | mask of levels with an emission
+//                    term << 18, final PCG32 state} (the final state = draws consumed, for the per-sample tests)
+//   direct[l*n + r] float4  level l's emission term (camera ray hitting a light; every hit in the non-ELS build):
+//                    only levels of the emission mask are written
+//   nee[l*n + r]    float4  the level's next-event term, written when its parked shadow ray is traced: the
+//                    contribution if the light is visible, zeros if not (only levels of the mask are defined)
 //   fs[l*n + r]     float4  f_s of the continuation       } rad_l = direct_l + ((rad_{l+1} * n_dot_l) * f_s) / pdf
 //   np[l*n + r]     float2  {n_dot_l, pdf}                }
 // Levels 0..MAX_DEPTH-2 can continue (0..MAX_DEPTH-3 with explicit light sampling), the last level of a path is
 // at most MAX_DEPTH-1: 10 levels of `direct`, 9 of `fs` / `np`.
 #define SSX_MAX_FRAMES 9u
 #define SSX_MAX_LEVELS 10u
-#define SSX_BYTES_PER_SAMPLE (16u + 16u + 16u * SSX_MAX_LEVELS + (16u + 8u) * SSX_MAX_FRAMES)
+#define SSX_BYTES_PER_SAMPLE (16u + 16u + 2u * 16u * SSX_MAX_LEVELS + (16u + 8u) * SSX_MAX_FRAMES)
 
 struct SsxKernelArgs {
 	const uint32_t* blob;   // device copy of the scene blob
@@ -104,6 +108,7 @@ struct SsxKernelArgs {
 	float4* ray;              // per-sample arrays, see above
 	uint4* st;
 	float4* direct;
+	float4* nee;
 	float4* fs;
 	float2* np;
 	uint64_t n_records;       // my_tiles * (k1-k0) * 64

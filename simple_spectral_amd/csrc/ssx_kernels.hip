@@ -129,25 +129,26 @@ struct Lds {
 struct Hero { float v[4]; };
 
 // spectrum.cpp:39-67: linear reconstruction, zero outside the table; lambda_i = l0 + float(i)*STEP.
-// Every table in the blob carries one zero sample in front of its first and one behind its last sample, so
-// the reference's guarded reads (`i0>=0&&i0<size ? data[i0] : 0`) are plain reads at the index clamped to
-// [-1, n] (one v_med3_i32) -- the same values, no compare/select.  The index/fraction part depends only on
-// the table's grid (low, delta_recip, n), so tables on one grid (the three basis spectra, the three observer
-// curves) share it; for those the blob also holds the three tables interleaved as float4 {a, b, c, 0}, so
-// that one 16-byte LDS read fetches a sample of all three.
-struct HeroIndex { int c0[4], c1[4]; float frac[4]; };
-__device__ __forceinline__ HeroIndex hero_index(const SsxBlobSpectrum sp, float lambda_0, float step) {
+// Every table in the blob carries TWO zero samples in front of its first and two behind its last sample, so
+// the reference's guarded reads (`i0>=0&&i0<size ? data[i0] : 0`, likewise for i0+1) are plain reads of the
+// neighbours data[c], data[c+1] at c = i0 clamped to [-2, n] (one v_med3_i32) -- the same values, no
+// compare/select, one two-address LDS read.  The index/fraction part depends only on the table's grid (low,
+// delta_recip, n), so tables on one grid (the three basis spectra, the three observer curves) share it; for
+// those the blob also holds the three tables interleaved as float4 {a, b, c, 0}, so that one 16-byte LDS
+// read fetches a sample of all three.  lambda_i = lambda_0 + float(i)*LAMBDA_STEP with the four products
+// float(i)*LAMBDA_STEP taken from the header (same float multiply, done once by the host).
+struct HeroIndex { int c[4]; float frac[4]; };
+__device__ __forceinline__ HeroIndex hero_index(const SsxBlobHeader& hd, const SsxBlobSpectrum sp, float lambda_0) {
 	HeroIndex h;
 	const int n = (int)sp.n;
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
-		float lambda = lambda_0 + (float)i * step;
+		float lambda = lambda_0 + hd.lambda_steps[i];
 		float x = (lambda - sp.low) * sp.delta_recip;
 		float i0f = __builtin_floorf(x);
 		h.frac[i] = x - i0f;
 		int i0 = (int)i0f; // v_cvt_i32_f32 saturates; lambda stays within a few steps of the tables anyway
-		h.c0[i] = min(max(i0, -1), n);
-		h.c1[i] = min(max(i0 + 1, -1), n);
+		h.c[i] = min(max(i0, -2), n);
 	}
 	return h;
 }
@@ -155,7 +156,7 @@ __device__ __forceinline__ Hero hero_gather(const Lds& L, uint32_t offset, const
 	const float* data = reinterpret_cast<const float*>(L.w + offset);
 	float v0[4], v1[4];
 #pragma unroll
-	for (int i = 0; i < 4; ++i) { v0[i] = data[h.c0[i]]; v1[i] = data[h.c1[i]]; }
+	for (int i = 0; i < 4; ++i) { v0[i] = data[h.c[i]]; v1[i] = data[h.c[i] + 1]; }
 	Hero out;
 #pragma unroll
 	for (int i = 0; i < 4; ++i) out.v[i] = v0[i] * (1.0f - h.frac[i]) + v1[i] * h.frac[i]; // math-helpers.hpp:10-12
@@ -166,7 +167,7 @@ __device__ __forceinline__ void hero_gather3(const Lds& L, uint32_t offset4, con
 	const float4* data = reinterpret_cast<const float4*>(L.w + offset4);
 	float4 v0[4], v1[4];
 #pragma unroll
-	for (int i = 0; i < 4; ++i) { v0[i] = data[h.c0[i]]; v1[i] = data[h.c1[i]]; }
+	for (int i = 0; i < 4; ++i) { v0[i] = data[h.c[i]]; v1[i] = data[h.c[i] + 1]; }
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		const float w0 = 1.0f - h.frac[i], w1 = h.frac[i];
@@ -176,7 +177,8 @@ __device__ __forceinline__ void hero_gather3(const Lds& L, uint32_t offset4, con
 	}
 }
 __device__ __forceinline__ Hero spectrum_hero(const Lds& L, const SsxBlobSpectrum sp, float lambda_0, float step) {
-	return hero_gather(L, sp.offset, hero_index(sp, lambda_0, step));
+	(void)step; // LAMBDA_STEP enters through the header's products float(i)*LAMBDA_STEP
+	return hero_gather(L, sp.offset, hero_index(L.hdr(), sp, lambda_0));
 }
 __device__ __forceinline__ Hero spectrum_hero(const Lds& L, uint32_t spec_id, float lambda_0, float step) {
 	return spectrum_hero(L, L.spectrum(spec_id), lambda_0, step);
@@ -326,8 +328,8 @@ __device__ __forceinline__ Hero meng_uplift(const Lds& L, float r, float g, floa
 	return out;
 }
 
-// material.cpp:45-97 + util/color.cpp:167-173 ("ours" basis uplift)
-__device__ __forceinline__ Hero texture_sample(const Lds& L, uint32_t tex_index, float st_x, float st_y, float lambda_0) {
+// material.cpp:65-97 (st -> clamped nearest texel) + :52-56 (sRGB8 -> linear RGB through the host-built table)
+__device__ __forceinline__ void texel_lrgb(const Lds& L, uint32_t tex_index, float st_x, float st_y, float& r, float& g, float& b) {
 	const SsxBlobTexture t = L.texture(tex_index);
 	const uint8_t* rgb = reinterpret_cast<const uint8_t*>(((uint64_t)t.ptr_hi << 32) | (uint64_t)t.ptr_lo);
 	float uvx = st_x * (float)t.w, uvy = st_y * (float)t.h;
@@ -337,7 +339,13 @@ __device__ __forceinline__ Hero texture_sample(const Lds& L, uint32_t tex_index,
 	i = (i < 0) ? 0 : i; i = (hi_i < i) ? hi_i : i;
 	j = (j < 0) ? 0 : j; j = (hi_j < j) ? hi_j : j;
 	const uint8_t* px = rgb + 3u * ((size_t)j * (size_t)t.w + (size_t)i);
-	float r = L.lut(px[0]), g = L.lut(px[1]), b = L.lut(px[2]);
+	r = L.lut(px[0]); g = L.lut(px[1]); b = L.lut(px[2]);
+}
+
+// material.cpp:45-64 + util/color.cpp:167-232: texel -> hero reflectance through the build's uplift
+__device__ __forceinline__ Hero texture_sample(const Lds& L, uint32_t tex_index, float st_x, float st_y, float lambda_0) {
+	float r, g, b;
+	texel_lrgb(L, tex_index, st_x, st_y, r, g, b);
 	const SsxBlobHeader& h = L.hdr();
 	if (h.uplift == 0u) { Hero o; o.v[0] = r; o.v[1] = g; o.v[2] = b; o.v[3] = 0.0f; return o; } // RENDER_MODE_RGB: material.cpp:61-63
 	if (h.uplift == 3u) return jh_uplift(L, r, g, b, lambda_0); // RENDER_MODE_SPECTRAL_JH (wave-uniform)
@@ -345,7 +353,7 @@ __device__ __forceinline__ Hero texture_sample(const Lds& L, uint32_t tex_index,
 	Hero br, bg, bb;
 	const SsxBlobSpectrum sr = L.spectrum(h.spec_basis_r), sg = L.spectrum(h.spec_basis_g), sb = L.spectrum(h.spec_basis_b);
 	if (h.basis_one_grid) { // wave-uniform: r, g, b tables have the same (low, delta_recip, n)
-		hero_gather3(L, h.off_basis4, hero_index(sr, lambda_0, h.lambda_step), br, bg, bb);
+		hero_gather3(L, h.off_basis4, hero_index(h, sr, lambda_0), br, bg, bb);
 	} else {
 		br = spectrum_hero(L, sr, lambda_0, h.lambda_step);
 		bg = spectrum_hero(L, sg, lambda_0, h.lambda_step);
@@ -358,7 +366,26 @@ __device__ __forceinline__ Hero texture_sample(const Lds& L, uint32_t tex_index,
 }
 
 __device__ __forceinline__ Hero material_albedo(const Lds& L, const SsxBlobQuad& Q, float st_x, float st_y, float lambda_0) {
-	if (Q.albedo_mode == 0u) return spectrum_hero(L, Q.albedo, lambda_0, L.hdr().lambda_step);
+	const SsxBlobHeader& h = L.hdr();
+	if (h.uplift == 1u && h.basis_one_grid) {
+		// The default build ("ours" uplift, basis tables on one grid; wave-uniform test).  A wave nearly always holds
+		// lanes of both kinds, so the grid lookup (hero_index) is done once for all of them -- each lane on the
+		// descriptor of ITS table, fetched by address -- and only the gathers differ: one table for a constant
+		// albedo, the three interleaved basis tables weighted by the texel for a textured one.
+		const bool tex = Q.albedo_mode != 0u;
+		const SsxBlobSpectrum* desc = tex ? reinterpret_cast<const SsxBlobSpectrum*>(L.w + h.off_spectra) + h.spec_basis_r : &Q.albedo;
+		const SsxBlobSpectrum sp = *desc;
+		const HeroIndex hi = hero_index(h, sp, lambda_0);
+		if (!tex) return hero_gather(L, sp.offset, hi);
+		float r, g, b;
+		texel_lrgb(L, Q.albedo_tex, st_x, st_y, r, g, b);
+		Hero br, bg, bb, out;
+		hero_gather3(L, h.off_basis4, hi, br, bg, bb);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) out.v[k] = (r * br.v[k] + g * bg.v[k]) + b * bb.v[k]; // util/color.cpp:167-173
+		return out;
+	}
+	if (Q.albedo_mode == 0u) return spectrum_hero(L, Q.albedo, lambda_0, h.lambda_step);
 	return texture_sample(L, Q.albedo_tex, st_x, st_y, lambda_0);
 }
 
@@ -367,7 +394,7 @@ __device__ __forceinline__ void flux_to_xyz(const Lds& L, const Hero& flux, floa
 	const SsxBlobHeader& h = L.hdr();
 	Hero bar[3];
 	if (h.observer_one_grid) { // wave-uniform: the CIE tables share one grid
-		hero_gather3(L, h.off_observer4, hero_index(L.spectrum(h.spec_xbar), lambda_0, h.lambda_step), bar[0], bar[1], bar[2]);
+		hero_gather3(L, h.off_observer4, hero_index(h, L.spectrum(h.spec_xbar), lambda_0), bar[0], bar[1], bar[2]);
 	} else {
 		bar[0] = spectrum_hero(L, h.spec_xbar, lambda_0, h.lambda_step);
 		bar[1] = spectrum_hero(L, h.spec_ybar, lambda_0, h.lambda_step);
@@ -728,6 +755,8 @@ struct Path {
 	int ignore;        // quad the ray starts on (-1: camera)
 	uint32_t depth;
 	uint32_t rec_index; // record of this sample in the per-sample arrays
+	uint32_t nee_mask;  // bit l: level l parked a shadow ray (its next-event term lives in nee[l*n + r]);
+	                    // bit 10+l: level l added an emission term (direct[l*n + r])
 	bool hit_anything;
 };
 
@@ -792,12 +821,13 @@ __device__ __forceinline__ void hit_st(const SsxBlobQuad& Q, uint32_t which, con
 
 // One level of the recursion L() (renderer.cpp:147-255) for the lane's current ray: closest hit,
 // emission (camera ray only), next-event estimation with its shadow ray, BSDF sample.  Writes the
-// level's `direct` (its whole radiance when the path ends here) and, when the path continues, the
-// factors of the continuation; returns true when it continues (p then holds the next ray).
+// level's emission term if it has one (`direct`), parks its shadow ray (whose flush writes `nee`) and,
+// when the path continues, stores the factors of the continuation; returns true when it continues (p
+// then holds the next ray).
 __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const SsxKernelArgs& a, Path& p, const HitInfo& hit, bool& pushed) {
 	const SsxBlobHeader& h = L.hdr();
 	const uint32_t level_index = p.depth * (uint32_t)a.n_records + p.rec_index; // < 2^32 per launch (host budget)
-	if (hit.tri < 0) { a.direct[level_index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); return false; }
+	if (hit.tri < 0) return false; // this level's radiance is 0: neither mask bit is set
 	SSX_STAT(4); // lanes with a hit
 	p.hit_anything = true;
 	const uint32_t hq = (uint32_t)hit.tri >> 1, which = (uint32_t)hit.tri & 1u;
@@ -816,13 +846,13 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 		Hero em = spectrum_hero(L, M.emission, p.lambda_0, h.lambda_step);
 #pragma unroll
 		for (int k = 0; k < 4; ++k) direct[k] += em.v[k];
+		// the level's emission term, read back by the fold (levels without it have none: 0 + x == x)
+		a.direct[level_index] = make_float4(direct[0], direct[1], direct[2], direct[3]);
+		p.nee_mask |= 0x400u << p.depth;
 	}
 	// :178 `if (depth+1u<MAX_DEPTH)`: with ELS a ray at depth MAX_DEPTH-1 is never started (below);
 	// without it that ray exists (its hit may emit) and ends here
-	if (p.depth + 1u >= SSX_MAX_DEPTH_) {
-		a.direct[level_index] = make_float4(direct[0], direct[1], direct[2], direct[3]);
-		return false;
-	}
+	if (p.depth + 1u >= SSX_MAX_DEPTH_) return false;
 	V3 hit_pos = add(p.orig, scl(hit.dist, p.dir)); // Ray::at
 	// hitrec.st (geometry.cpp:91-95) is read only by textured albedo
 	float st_x = 0.0f, st_y = 0.0f;
@@ -860,6 +890,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 				E[0] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, sdir.x);
 				E[1] = make_float4(sdir.y, sdir.z, c[0], c[1]);
 				E[2] = make_float4(c[2], c[3], __uint_as_float((light << 8) | hq), __uint_as_float(level_index));
+				p.nee_mask |= 1u << p.depth;
 				pushed = true;
 			}
 		}
@@ -887,8 +918,6 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 		else { n_dot_l = 1.0f; pdf_w_i = 1.0f; }
 		cont = n_dot_l > 0.0f;
 	}
-	// this level's direct light: the level's radiance if the path ends here, else the first term of the fold
-	a.direct[level_index] = make_float4(direct[0], direct[1], direct[2], direct[3]);
 	// A ray at depth MAX_DEPTH-1 can add nothing (no emission: last_was_delta is false; no further
 	// bounce: depth+1 == MAX_DEPTH) and hit_anything is already set, so it is not traced: its L()
 	// is exactly 0 and the parent adds ((0*n)*f)/p.
@@ -904,46 +933,40 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	return true;
 }
 
-// Memory-ordering contract of the two readers below (shadow_flush, unit_fold).  They read `direct`,
-// `fs`, `np` and `st` entries that OTHER LANES OF THE SAME WAVE stored earlier in the wave's single
-// instruction stream (lanes trade items at the refill, so the storing lane is in general not the
-// reading lane), and nothing that another wave wrote.  On gfx950 a wave's vector-memory operations
-// are issued in program order and its stores go through the (write-through) L1 to the L2; what a
-// reader has to exclude is (1) the compiler moving the access across the stores -- the
-// workgroup-scope fences -- and (2) a stale L1 line left by an earlier read of the same address:
-// shadow_flush therefore loads with agent scope (served by the L2), unit_fold invalidates the L1
-// with an agent-scope acquire fence.  This is below what the HIP memory model promises for
-// cross-lane communication (no release/acquire pair on an atomic), i.e. it relies on documented
-// gfx9 behaviour; an agent-scope release (L2 write-back) before every flush measured 4x slower.
-// simple_spectral_amd/build.py therefore pins the target to gfx950 and refuses an untested ROCm
-// major version, and the bit-exact GPU parity tests (tests/test_gpu_parity.py, incl. the
-// many-units-per-wave stress case) are the guard.
-//
-// Traces the parked shadow rays [first, first+n), n <= 64, one per lane, and adds the contribution
-// of every visible one to its target.  Called in uniform control flow.
+// Traces the parked shadow rays [first, first+n), n <= 64, one per lane, and stores every ray's next-event
+// term -- its contribution if the light is visible, zeros if not -- to nee[target]; the fold adds it to the
+// level's `direct` (the same float addition `radiance += ...` of renderer.cpp:216, or + 0).  Write-only:
+// a read-modify-write of `direct` here cost a 128-byte line fill per ray.  Called in uniform control flow.
 __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& a, const ShadowQ& q, uint32_t first, uint32_t n) {
 	const uint32_t lane = threadIdx.x & 63u;
-	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 	const bool have = lane < n;
-	float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = make_float4(1.0f, 0.0f, 0.0f, 0.0f), e2 = e0, old = e0;
-	float4* dst = nullptr;
+	float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = make_float4(1.0f, 0.0f, 0.0f, 0.0f), e2 = e0;
 	if (have) {
 		const float4* E = q.e + 3u * (first + lane);
 		e0 = E[0]; e1 = E[1]; e2 = E[2];
-		dst = a.direct + __float_as_uint(e2.w);
-		float* d = reinterpret_cast<float*>(dst); // in flight during the trace
-		old.x = __hip_atomic_load(d + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		old.y = __hip_atomic_load(d + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		old.z = __hip_atomic_load(d + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		old.w = __hip_atomic_load(d + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	}
 	const uint32_t tag = __float_as_uint(e2.z);
 	HitInfo sh;
 	trace(L, mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y), (int)(tag & 0xFFu), have, sh, 2);
-	if (have && sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == (tag >> 8))
-		*dst = make_float4(old.x + e1.z, old.y + e1.w, old.z + e2.x, old.w + e2.y);
+	if (have) {
+		const bool visible = sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == (tag >> 8);
+		a.nee[__float_as_uint(e2.w)] = visible ? make_float4(e1.z, e1.w, e2.x, e2.y) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	}
 }
 
+// Memory-ordering contract of the fold (unit_fold -> resolve_records).  It reads `direct`, `nee`, `fs`, `np`
+// and `st` entries that OTHER LANES OF THE SAME WAVE stored earlier in the wave's single instruction stream
+// (lanes trade items at the refill, so the storing lane is in general not the reading lane), and nothing
+// that another wave wrote.  On gfx950 a wave's vector-memory operations are issued in program order and
+// its stores go through the (write-through) L1 to the L2; what the reader has to exclude is (1) the
+// compiler moving the loads across the stores -- a workgroup-scope release fence -- and (2) a stale L1
+// line left by an earlier read of the same address -- an agent-scope acquire fence, which invalidates the
+// L1.  This is below what the HIP memory model promises for cross-lane communication (no release/acquire
+// pair on an atomic), i.e. it relies on documented gfx9 behaviour; an agent-scope release (L2 write-back)
+// measured 4x slower.  simple_spectral_amd/build.py therefore pins the target to gfx950 and refuses an
+// untested ROCm major version, and the bit-exact GPU parity tests (tests/test_gpu_parity.py, incl. the
+// many-units-per-wave stress case) are the guard.
+//
 // Backward fold of the recursion for finished samples (renderer.cpp:247: radiance += L(next) *
 // n_dot_l * f_s / pdf, evaluated innermost first = the reference's post-order) over the levels the
 // path recorded, then flux -> CIE XYZ (util/color.hpp:115-139; FLAT_FIELD_CORRECTION: flux =
@@ -957,17 +980,21 @@ template <uint32_t WAYS>
 __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count) {
 	const uint32_t n = (uint32_t)a.n_records;
 	float rad[WAYS][4];
-	uint32_t depth[WAYS], lam[WAYS], hitf[WAYS];
+	uint32_t depth[WAYS], lam[WAYS], hitf[WAYS], nee_mask[WAYS];
 	uint32_t top = 0;
+	const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
 	for (uint32_t s = 0; s < WAYS; ++s) {
-		depth[s] = 0; lam[s] = 0; hitf[s] = 0;
+		depth[s] = 0; lam[s] = 0; hitf[s] = 0; nee_mask[s] = 0;
 		rad[s][0] = rad[s][1] = rad[s][2] = rad[s][3] = 0.0f;
 		if (s < count) {
 			const uint4 st = a.st[r0 + s * stride];
-			lam[s] = st.x; hitf[s] = st.y & 1u; depth[s] = st.y >> 8;
-			const float4 last = a.direct[depth[s] * n + r0 + s * stride]; // the last level's radiance
-			rad[s][0] = last.x; rad[s][1] = last.y; rad[s][2] = last.z; rad[s][3] = last.w;
+			lam[s] = st.x; hitf[s] = st.y & 1u; depth[s] = (st.y >> 4) & 0xFu; nee_mask[s] = st.y >> 8;
+			// the last level's radiance: 0 + its emission term (if any) + its next-event term (if it parked a shadow ray)
+			const uint32_t i = depth[s] * n + r0 + s * stride;
+			const float4 last = ((nee_mask[s] >> (10u + depth[s])) & 1u) ? a.direct[i] : zero4;
+			const float4 ne = ((nee_mask[s] >> depth[s]) & 1u) ? a.nee[i] : zero4;
+			rad[s][0] = last.x + ne.x; rad[s][1] = last.y + ne.y; rad[s][2] = last.z + ne.z; rad[s][3] = last.w + ne.w;
 		}
 		top = max(top, depth[s]);
 	}
@@ -975,12 +1002,23 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 		float4 D[WAYS], F[WAYS]; float2 NP[WAYS];
 #pragma unroll
 		for (uint32_t s = 0; s < WAYS; ++s)
-			if (d < depth[s]) { const uint32_t i = d * n + r0 + s * stride; D[s] = a.direct[i]; F[s] = a.fs[i]; NP[s] = a.np[i]; }
+			if (d < depth[s]) {
+				const uint32_t i = d * n + r0 + s * stride;
+				F[s] = a.fs[i]; NP[s] = a.np[i];
+				// emission + next-event term, the order of renderer.cpp:171,216 (0 + x == x where a term is absent)
+				const bool has_ne = (nee_mask[s] >> d) & 1u;
+				D[s] = has_ne ? a.nee[i] : zero4;
+				if ((nee_mask[s] >> (10u + d)) & 1u) { // rare: an emission term below the last level (non-ELS build)
+					const float4 em = a.direct[i];
+					D[s] = has_ne ? make_float4(em.x + D[s].x, em.y + D[s].y, em.z + D[s].z, em.w + D[s].w) : em;
+				}
+			}
 #pragma unroll
 		for (uint32_t s = 0; s < WAYS; ++s)
 			if (d < depth[s]) {
 				SSX_STAT(14); // fold: level x way x lanes
 				const double pdf_recip = ssx_exact::div64_rcp_any(NP[s].y);
+				// ... + indirect term (renderer.cpp:247)
 				rad[s][0] = D[s].x + ssx_exact::div64_by((rad[s][0] * NP[s].x) * F[s].x, pdf_recip);
 				rad[s][1] = D[s].y + ssx_exact::div64_by((rad[s][1] * NP[s].x) * F[s].y, pdf_recip);
 				rad[s][2] = D[s].z + ssx_exact::div64_by((rad[s][2] * NP[s].x) * F[s].z, pdf_recip);
@@ -1069,7 +1107,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	const V3 cam = mk(h.cam_pos[0], h.cam_pos[1], h.cam_pos[2]);
 
 	Path p;
-	p.orig = cam; p.dir = mk(0.0f, 0.0f, 1.0f); p.ignore = -1; p.depth = 0; p.rec_index = 0; p.lambda_0 = 0.0f; p.hit_anything = false;
+	p.orig = cam; p.dir = mk(0.0f, 0.0f, 1.0f); p.ignore = -1; p.depth = 0; p.rec_index = 0; p.lambda_0 = 0.0f; p.hit_anything = false; p.nee_mask = 0;
 	p.rng.state = 0; p.rng.inc = 1;
 	bool active = false;
 	uint32_t p_tag = 0; // which of the (at most two) units in flight the lane's sample belongs to
@@ -1116,6 +1154,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 					p.orig = cam;
 					p.ignore = -1;
 					p.depth = 0;
+					p.nee_mask = 0;
 					p.hit_anything = false;
 					p_tag = cur_tag;
 					active = true;
@@ -1139,7 +1178,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 				// last level reached (its radiance is in direct[depth]): lambda_0, the hit flag, the number of
 				// continued levels and the final PCG32 state replace the sample's stream; the fold happens
 				// when its unit is complete
-				a.st[p.rec_index] = make_uint4(__float_as_uint(p.lambda_0), (p.hit_anything ? 1u : 0u) | (p.depth << 8),
+				a.st[p.rec_index] = make_uint4(__float_as_uint(p.lambda_0), (p.hit_anything ? 1u : 0u) | (p.depth << 4) | (p.nee_mask << 8),
 				                               (uint32_t)p.rng.state, (uint32_t)(p.rng.state >> 32));
 				active = false;
 			}

@@ -1,0 +1,11 @@
+#!/bin/bash
+# A/B on ONE GPU box (box-to-box spread is +-3 %): alternate bench.py runs of the product library and of the
+# variant libraries given as arguments (paths, loaded through SSX_HIP_LIB_OVERRIDE), three rounds each.
+# usage: tools/ab_bench.sh [variant.so ...]   -> prints value / ms_per_step / kernel_ms per run
+R=$(pwd)
+for round in 1 2 3; do
+	python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('product', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['scratch_bytes'])"
+	for V in "$@"; do
+		SSX_HIP_LIB_OVERRIDE=$R/$V python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$V', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['scratch_bytes'])"
+	done
+done

@@ -82,14 +82,14 @@ extern "C" __global__ void k_xyz_one_grid(SsxKernelArgs a, float* in, float* out
 	Lds L; L.w = stage_lds(a);
 	const SsxBlobHeader& h = L.hdr();
 	Hero bar[3];
-	hero_gather3(L, h.off_observer4, hero_index(L.spectrum(h.spec_xbar), in[256 + threadIdx.x], h.lambda_step), bar[0], bar[1], bar[2]);
+	hero_gather3(L, h.off_observer4, hero_index(h, L.spectrum(h.spec_xbar), in[256 + threadIdx.x]), bar[0], bar[1], bar[2]);
 	float acc3 = 0;
 	for (int ch = 0; ch < 3; ++ch) { float acc = 0.0f; for (int i = 0; i < 4; ++i) acc += (bar[ch].v[i] * in[64 * i + threadIdx.x]) * h.lambda_step; acc3 += acc; }
 	SINK(out, acc3);
 }
 extern "C" __global__ void k_hero_index(SsxKernelArgs a, float* in, float* out) {
 	Lds L; L.w = stage_lds(a);
-	HeroIndex hi = hero_index(L.spectrum(3), in[threadIdx.x], L.hdr().lambda_step);
-	float s = 0; for (int i = 0; i < 4; ++i) s += hi.frac[i] + (float)hi.c0[i] + (float)hi.c1[i];
+	HeroIndex hi = hero_index(L.hdr(), L.spectrum(3), in[threadIdx.x]);
+	float s = 0; for (int i = 0; i < 4; ++i) s += hi.frac[i] + (float)hi.c[i];
 	SINK(out, s);
 }
