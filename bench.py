@@ -47,11 +47,12 @@ PEAK_VALU_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
 
 
-def algorithmic_bytes_per_sample(scene):
+def algorithmic_bytes_per_sample(scene, path_kernel_only=False):
     L = LEVELS.get(scene, 3.35)
     R, _visible = SHADOW.get(scene, (3.14, 2.69))
     E = 0.01
-    return 32 + (32 + 24 * L + 16 * E + 16) + 16 * R + (16 + 24 * L + 16 * R + 16 * E + 16) + 16
+    path = (32 + 24 * L + 16 * E + 16) + 16 * R + (16 + 24 * L + 16 * R + 16 * E + 16)   # path loop + shadow flush + fold
+    return path if path_kernel_only else 32 + path + 16
 
 
 def host_cpu_info():
@@ -276,6 +277,8 @@ def main():
                          "flop_per_sample": flop,
                          "note": "FP32 VALU-issue bound (no MFMA: traversal/sampling); peak = 157.3/2 TFLOP/s because the parity contract forbids FMA contraction. HBM is busy but not the limiter: see hbm.",
                          "hbm": {"algorithmic_bytes_per_sample": round(algorithmic_bytes_per_sample(args.scene), 1),
+                                 "path_kernel_algorithmic_bytes_per_sample": round(algorithmic_bytes_per_sample(args.scene, True), 1),
+                                 "traffic_over_path_kernel_algorithmic": round(traffic / (per_gpu_samples * algorithmic_bytes_per_sample(args.scene, True)), 3) if traffic else None,
                                  "algorithmic_GBps": round(hbm_bytes / (pipeline_ms * 1e-3) / 1e9, 1),
                                  "measured_GBps": round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",

@@ -280,7 +280,7 @@ int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
 
 // Every launch writes its samples to [tile slot][k][64] float4 (16 B per sample) and the ordered
 // accumulate pass consumes them; the buffer bounds how many samples per pixel one launch may cover.
-constexpr size_t kSampleBufferBudget = (size_t)32 << 30; // bytes of per-sample arrays one launch may use (288 GB HBM)
+constexpr size_t kSampleBufferBudget = (size_t)64 << 30; // bytes of per-sample arrays one launch may use (288 GB HBM; 512^2 x 256 spp = 38 GB)
 constexpr size_t kBytesPerSampleInFlight = SSX_BYTES_PER_SAMPLE; // 568: ray 16 + stream 16 + 10 levels x (16 + 16) + 9 x (16 + 8)
 constexpr uint32_t kMinUnits = 3072;                   // one wave work unit per wave slot of the GPU (256 CUs x 4 SIMDs x 3 waves)
 
