@@ -209,6 +209,11 @@ int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* s
  * the end of each wave's unit inside the path kernel (1) or as a streaming kernel of its own (0).
  * A performance choice only: both give the same bits. */
 int ssx_plan_info(ssx_ctx* ctx, float* frames_per_sample, int* fold_in_path_kernel);
+/* Which path kernel the uploaded scene runs: 0 = the generic one (pass 1 of the intersection loops over the
+ * quads), 1 / 2 = the kernel whose pass 1 is specialised to the mesh topology of the reference's Cornell box /
+ * plane scene (the scene's quad corners coincide in exactly that pattern; positions are free).  A performance
+ * choice only: same bits.  The environment variable SSX_GENERIC_KERNEL forces 0 at upload.  -1: no scene. */
+int ssx_kernel_variant(ssx_ctx* ctx);
 
 /* ---- Diagnostics for the parity tests (not part of the reference's interface) ---------------------
  * ssx_debug_eval runs one building block of the path kernel -- the same device function the kernel

@@ -13,7 +13,7 @@ HIP_LIB = os.path.join(PKG, "libssx_hip.so")
 HOST_LIB = os.path.join(PKG, "libssx_host.so")
 
 HIP_SRC = [os.path.join(PKG, "csrc", f) for f in ("ssx_api.hip",)]
-HIP_DEPS = [os.path.join(PKG, "csrc", f) for f in ("ssx_api.hip", "ssx_kernels.hip", "ssx_debug.hip", "ssx_blob.h", "ssx_exact.h", "ssx_lanestat.h")] + [
+HIP_DEPS = [os.path.join(PKG, "csrc", f) for f in ("ssx_api.hip", "ssx_kernels.hip", "ssx_debug.hip", "ssx_blob.h", "ssx_exact.h", "ssx_lanestat.h", "ssx_pass1_gen.h")] + [
     os.path.join(ROOT, "include", f) for f in ("ssx.h", "ssx_fmath.h")]
 HOST_SRC = [os.path.join(PKG, "host", f) for f in
             ("spectrum.cpp", "color.cpp", "jh2019.cpp", "meng2015.cpp", "scene.cpp", "image_io.cpp", "renderer.cpp", "host_api.cpp")]

@@ -6,9 +6,11 @@
 
 #include "../../include/ssx.h"
 
+#include <array>
 #include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <algorithm>
 #include <cstring>
@@ -35,7 +37,9 @@ struct ssx_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;       // used by the asynchronous start/stop/wait path
 	uint32_t* d_blob = nullptr;
-	uint32_t blob_words = 0;
+	uint32_t blob_words = 0;      // whole blob (generic / calibration / debug kernels stage all of it)
+	uint32_t path_blob_words = 0; // what the path kernel stages: without the per-quad vertex table when a specialised kernel runs
+	uint32_t topology = 0;        // 0, or the built-in mesh topology the scene matched (csrc/ssx_pass1_gen.h)
 	std::vector<uint8_t*> d_textures;
 	float* d_jh_data = nullptr;
 	bool rgb_mode = false;     // scene uploaded with uplift == SSX_MODE_RGB
@@ -142,8 +146,29 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 		h.basis_one_grid = (r.n == g.n && r.n == b.n && r.low == g.low && r.low == b.low && r.delta_recip == g.delta_recip && r.delta_recip == b.delta_recip) ? 1u : 0u;
 	}
 
+	// Which corners coincide?  Distinct vertices numbered by first occurrence of their position (bitwise); if the pattern is
+	// that of one of the reference's built-in meshes (csrc/ssx_pass1_gen.h) the kernel with that topology's pass 1 runs.
+	std::vector<std::array<uint8_t, 4>> vid(s->n_quads);
+	std::vector<const float*> distinct;
+	for (uint32_t q = 0; q < s->n_quads; ++q) {
+		const ssx_vertex* vs[4] = { &s->quads[q].v00, &s->quads[q].v10, &s->quads[q].v11, &s->quads[q].v01 };
+		for (int v = 0; v < 4; ++v) {
+			size_t k = 0;
+			while (k < distinct.size() && memcmp(distinct[k], vs[v]->pos, 12) != 0) ++k;
+			if (k == distinct.size()) distinct.push_back(vs[v]->pos);
+			vid[q][v] = (uint8_t)k; // n_quads <= 32: at most 128 distinct vertices
+		}
+	}
+	h.topology = 0; h.n_verts = (uint32_t)distinct.size();
+	for (const SsxTopology& t : ssx_topologies) {
+		if (t.n_quads != s->n_quads || t.n_verts != distinct.size()) continue;
+		bool same = true;
+		for (uint32_t q = 0; q < s->n_quads && same; ++q) for (int v = 0; v < 4; ++v) same = same && t.vid[q][v] == vid[q][v];
+		if (same) h.topology = t.id;
+	}
+	if (getenv("SSX_GENERIC_KERNEL")) h.topology = 0; // A/B measurements and tests of the generic loop on the built-in scenes
+
 	uint32_t off = (uint32_t)(sizeof(SsxBlobHeader) / 4);
-	h.off_perm = off;      off = align4(off + s->n_quads * SSX_PERM_WORDS_PER_QUAD);
 	h.off_quads = off;     off = align4(off + s->n_quads * (uint32_t)(sizeof(SsxBlobQuad) / 4));
 	h.off_lights = off;    off = align4(off + s->n_lights);
 	h.off_spectra = off;   off = align4(off + s->n_spectra * (uint32_t)(sizeof(SsxBlobSpectrum) / 4));
@@ -182,9 +207,16 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	if (s->uplift == SSX_UPLIFT_JH || s->uplift == SSX_UPLIFT_MENG) { // the uplift's table in HBM (JH coefficients / Meng grid)
 		h.jh_data_lo = (uint32_t)(uintptr_t)d_jh; h.jh_data_hi = (uint32_t)((uint64_t)(uintptr_t)d_jh >> 32);
 	}
+	if (h.topology) { // distinct-vertex table per axis permutation + vertex ids per quad
+		h.vtab_stride = (3u * h.n_verts + 1u) & ~1u; // even: the {x,y} pairs stay 8-byte aligned
+		h.off_vtab = off;  off = align4(off + 6u * h.vtab_stride);
+		h.off_vid = off;   off = align4(off + s->n_quads);
+	}
+	h.words_without_perm = off;
+	h.off_perm = off;      off = align4(off + s->n_quads * SSX_PERM_WORDS_PER_QUAD); // last: not staged by the specialised kernels
 	h.total_words = off;
 	// prefix + blob + the four waves' shadow-ray queues is what a path-kernel workgroup allocates (<= 64 KiB)
-	if ((size_t)off * 4 > SSX_BLOB_MAX_BYTES) return fail(ctx, SSX_ERR_SCENE, fmt("scene tables need %u bytes of LDS (max %u)", off * 4, SSX_BLOB_MAX_BYTES));
+	if ((size_t)(h.topology ? h.words_without_perm : off) * 4 > SSX_BLOB_MAX_BYTES) return fail(ctx, SSX_ERR_SCENE, fmt("scene tables need %u bytes of LDS (max %u)", off * 4, SSX_BLOB_MAX_BYTES));
 
 	blob.assign(off, 0u);
 	memcpy(blob.data(), &h, sizeof h);
@@ -220,6 +252,17 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 		const ssx_spectrum& es = s->spectra[m.emission_spectrum];
 		bq[q].is_emissive = 0;
 		for (uint32_t k = 0; k < es.n; ++k) if (s->samples[es.offset + k] != 0.0f) bq[q].is_emissive = 1;
+	}
+	if (h.topology) {
+		float* vt = reinterpret_cast<float*>(blob.data() + h.off_vtab);
+		for (uint32_t p = 0; p < 6; ++p) {
+			uint32_t kz = p >> 1, kx = (kz + 1) % 3, ky = (kz + 2) % 3;
+			if (p & 1u) { uint32_t t = kx; kx = ky; ky = t; }
+			float* dst = vt + p * h.vtab_stride;
+			for (uint32_t k = 0; k < h.n_verts; ++k) { dst[2 * k] = distinct[k][kx]; dst[2 * k + 1] = distinct[k][ky]; dst[2 * h.n_verts + k] = distinct[k][kz]; }
+		}
+		for (uint32_t q = 0; q < s->n_quads; ++q)
+			blob[h.off_vid + q] = (uint32_t)vid[q][0] | ((uint32_t)vid[q][1] << 8) | ((uint32_t)vid[q][2] << 16) | ((uint32_t)vid[q][3] << 24);
 	}
 	memcpy(blob.data() + h.off_lights, s->lights, 4 * s->n_lights);
 	SsxBlobSpectrum* bs = reinterpret_cast<SsxBlobSpectrum*>(blob.data() + h.off_spectra);
@@ -289,7 +332,7 @@ struct LaunchPlan { SsxKernelArgs args; size_t lds_bytes; uint32_t max_spp_per_l
 LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	LaunchPlan pl{};
 	SsxKernelArgs& a = pl.args;
-	a.blob = ctx->d_blob; a.blob_words = ctx->blob_words;
+	a.blob = ctx->d_blob; a.blob_words = ctx->path_blob_words;
 	a.width = p->width; a.height = p->height;
 	a.tiles_x = (p->width + 7u) / 8u;
 	a.n_tiles = a.tiles_x * ((p->height + 7u) / 8u);
@@ -300,7 +343,7 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	a.rgb_mode = ctx->rgb_mode ? 1u : 0u;
 	a.fuse_resolve = ctx->fuse_resolve ? 1u : 0u;
 	a.my_tiles = a.n_tiles > p->tile_first ? (a.n_tiles - p->tile_first + p->tile_stride - 1u) / p->tile_stride : 0u;
-	pl.lds_bytes = ((size_t)ctx->blob_words + SSX_LDS_PREFIX_WORDS) * 4;
+	pl.lds_bytes = ((size_t)ctx->path_blob_words + SSX_LDS_PREFIX_WORDS) * 4;
 	size_t per_spp = (size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u * kBytesPerSampleInFlight;
 	// the budget, or 80 % of what is free on the device right now (plus what this context already holds)
 	size_t budget = kSampleBufferBudget, free_b = 0, total_b = 0;
@@ -403,12 +446,15 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[1], stream));
 	// persistent waves: as many workgroups as the GPU holds at once (or fewer, for a small launch); they
 	// fetch work units from a counter
-	const size_t path_lds = pl.lds_bytes + 4u * SSX_WAVE_SCRATCH_WORDS * 4u;
+	// the calibration render runs the generic kernel, which reads the per-quad vertex table: it stages the whole blob
+	if (calibration) b.a.blob_words = ctx->blob_words;
+	const size_t path_lds = ((size_t)b.a.blob_words + SSX_LDS_PREFIX_WORDS) * 4 + 4u * SSX_WAVE_SCRATCH_WORDS * 4u;
+	auto path_kernel = ctx->topology == 1u ? ssx_render_kernel_cornell : (ctx->topology == 2u ? ssx_render_kernel_plane : ssx_render_kernel);
 	if (!ctx->d_unit_counter) SSX_HIP(ctx, hipMalloc((void**)&ctx->d_unit_counter, sizeof(uint32_t)));
-	if (ctx->resident_blocks == 0) {
+	if (ctx->resident_blocks == 0 || calibration) {
 		int per_cu = 0;
 		hipDeviceProp_t prop;
-		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ssx_render_kernel, 256, path_lds));
+		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, calibration ? (const void*)ssx_calibrate_kernel : (const void*)path_kernel, 256, path_lds));
 		SSX_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
 		ctx->resident_blocks = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
 	}
@@ -416,8 +462,9 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	b.a.unit_counter = ctx->d_unit_counter;
 	const uint32_t want_blocks = (b.units + 3u) / 4u;
 	const uint32_t blocks = want_blocks < (uint32_t)ctx->resident_blocks ? want_blocks : (uint32_t)ctx->resident_blocks;
-	hipLaunchKernelGGL(calibration ? ssx_calibrate_kernel : ssx_render_kernel, dim3(blocks), dim3(256), path_lds, stream, b.a);
+	hipLaunchKernelGGL(calibration ? ssx_calibrate_kernel : path_kernel, dim3(blocks), dim3(256), path_lds, stream, b.a);
 	SSX_HIP(ctx, hipGetLastError());
+	if (calibration) ctx->resident_blocks = 0; // computed for the calibration kernel: recompute for the path kernel
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[2], stream));
 	return SSX_OK;
 }
@@ -680,6 +727,11 @@ int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 	SSX_HIP(ctx, hipMalloc((void**)&ctx->d_blob, blob.size() * 4));
 	SSX_HIP(ctx, hipMemcpy(ctx->d_blob, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
 	ctx->blob_words = (uint32_t)blob.size();
+	{
+		const SsxBlobHeader* bh = reinterpret_cast<const SsxBlobHeader*>(blob.data());
+		ctx->topology = bh->topology;
+		ctx->path_blob_words = bh->topology ? bh->words_without_perm : ctx->blob_words;
+	}
 	ctx->resident_blocks = 0; // depends on the blob's LDS footprint
 	ctx->have_scene = true;
 	return calibrate(ctx);
@@ -919,6 +971,8 @@ int ssx_lanestat(unsigned long long* out, int reset) {
 }
 #endif
 
+int ssx_kernel_variant(ssx_ctx* ctx) { return (ctx && ctx->have_scene) ? (int)ctx->topology : -1; }
+
 int ssx_plan_info(ssx_ctx* ctx, float* frames_per_sample, int* fold_in_path_kernel) {
 	if (!ctx) return SSX_ERR_ARG;
 	if (!ctx->have_scene) return fail(ctx, SSX_ERR_STATE, "no scene uploaded");
@@ -931,14 +985,15 @@ int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* s
 	if (!ctx) return SSX_ERR_ARG;
 	SSX_HIP(ctx, hipSetDevice(ctx->device));
 	hipFuncAttributes at;
-	SSX_HIP(ctx, hipFuncGetAttributes(&at, (const void*)ssx_render_kernel));
+	const void* path_kernel = ctx->topology == 1u ? (const void*)ssx_render_kernel_cornell : (ctx->topology == 2u ? (const void*)ssx_render_kernel_plane : (const void*)ssx_render_kernel);
+	SSX_HIP(ctx, hipFuncGetAttributes(&at, path_kernel));
 	if (vgprs) *vgprs = at.numRegs;
 	if (sgprs) *sgprs = 0;
-	if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes + (int)(ctx->blob_words + SSX_LDS_PREFIX_WORDS) * 4 + (int)(4u * SSX_WAVE_SCRATCH_WORDS * 4u); // path kernel: coefficients + blob + 4 waves' shadow-ray queues
+	if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes + (int)(ctx->path_blob_words + SSX_LDS_PREFIX_WORDS) * 4 + (int)(4u * SSX_WAVE_SCRATCH_WORDS * 4u); // path kernel: coefficients + blob + 4 waves' shadow-ray queues
 	if (scratch_bytes) *scratch_bytes = (int)at.localSizeBytes;
 	if (max_blocks_per_cu) {
 		int nb = 0;
-		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)ssx_render_kernel, 256, ((size_t)ctx->blob_words + SSX_LDS_PREFIX_WORDS) * 4 + 4u * SSX_WAVE_SCRATCH_WORDS * 4u));
+		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, path_kernel, 256, ((size_t)ctx->path_blob_words + SSX_LDS_PREFIX_WORDS) * 4 + 4u * SSX_WAVE_SCRATCH_WORDS * 4u));
 		*max_blocks_per_cu = nb;
 	}
 	return SSX_OK;

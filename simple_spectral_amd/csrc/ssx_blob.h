@@ -63,6 +63,11 @@ struct SsxBlobHeader {
 	// tables on one grid, interleaved as float4 {a, b, c, 0} with two zero elements in front and two behind
 	// (word offset of element 0, 16-byte aligned; valid when the *_one_grid flag is set)
 	uint32_t off_basis4, off_observer4;
+	// Topology-specialised kernels (csrc/ssx_pass1_gen.h): topology = 0 (none) or the id of the built-in mesh topology the
+	// scene's corners coincide like; off_vtab: for each of the 6 axis permutations vtab_stride words: {v[kx], v[ky]} of the
+	// n_verts distinct vertices, then their v[kz]; off_vid: per quad 4 x u8 distinct-vertex ids of v00, v10, v11, v01.
+	// The per-quad permuted table (off_perm) is the LAST section of the blob: the specialised kernels do not stage it.
+	uint32_t topology, n_verts, off_vtab, vtab_stride, off_vid, words_without_perm, pad3_[2];
 	float lambda_steps[4];      // float(i) * lambda_step, i = 0..3 (spectrum.cpp:63: lambda_0 + i*LAMBDA_STEP)
 	double n_lights_recip;      // RN64(1 / (double)(float)n_lights): `pdf /= float(lights.size())` (scene.cpp:430) as one multiply (ssx_exact.h)
 	double pad2_;

@@ -133,7 +133,7 @@ extern "C" __global__ void __launch_bounds__(256) ssx_debug_eval_kernel(SsxKerne
 	}
 	case SSX_DBG_TRACE: { // in: orig, dir, ignore quad (int) -> hit quad (-1: none), tri of the quad, dist, st
 		HitInfo h;
-		trace(L, mk(f(x[0]), f(x[1]), f(x[2])), mk(f(x[3]), f(x[4]), f(x[5])), (int)x[6], true, h);
+		trace<0>(L, mk(f(x[0]), f(x[1]), f(x[2])), mk(f(x[3]), f(x[4]), f(x[5])), (int)x[6], true, h);
 		o[0] = h.tri < 0 ? 0xFFFFFFFFu : (uint32_t)h.tri >> 1;
 		o[1] = h.tri < 0 ? 0u : (uint32_t)h.tri & 1u;
 		o[2] = u(h.dist);

@@ -113,6 +113,11 @@ struct Lds {
 	__device__ __forceinline__ const float* perm(uint32_t q, uint32_t p) const {
 		return reinterpret_cast<const float*>(w + hdr().off_perm) + q * SSX_PERM_WORDS_PER_QUAD + p * 12u;
 	}
+	// distinct-vertex table of axis permutation p (topology-specialised kernels): {x,y} pairs, then z
+	__device__ __forceinline__ const float* vtab(uint32_t p) const {
+		return reinterpret_cast<const float*>(w + hdr().off_vtab) + p * hdr().vtab_stride;
+	}
+	__device__ __forceinline__ uint32_t vid(uint32_t q) const { return w[hdr().off_vid + q]; } // 4 x u8: distinct-vertex ids of v00, v10, v11, v01
 	__device__ __forceinline__ const SsxBlobQuad& quad(uint32_t q) const {
 		return reinterpret_cast<const SsxBlobQuad*>(w + hdr().off_quads)[q];
 	}
@@ -475,6 +480,10 @@ __device__ __forceinline__ SV shear_xyz(float x, float y, float z, const RaySetu
 	return s;
 }
 
+} // namespace
+#include "ssx_pass1_gen.h" // pass1_cornell / pass1_plane: pass 1 straight-line for the built-in scenes' mesh topologies
+namespace {
+
 // scene.cpp:433-445 + geometry.cpp:128-139 + geometry.cpp:12-101.
 // Pass 1 (all quads, uniform loop): edge functions U,V,W of both triangles from the four shared
 // sheared vertices; a triangle whose nonzero edge values have mixed signs can never be accepted
@@ -484,6 +493,11 @@ __device__ __forceinline__ SV shear_xyz(float x, float y, float z, const RaySetu
 // dist, closest-so-far with strict '<' -- and skip tri1 when tri0 of the same quad was accepted
 // (the `goto HIT` of PrimQuad::intersect).
 // has_ray = false: the lane takes part in the wave-uniform pass 1 but traces nothing.
+// TOPO: 0 = any scene (loop over quads, per-quad vertex table); 1, 2 = the scene's corners coincide in the pattern of
+// the reference's Cornell box / plane scene (ssx_upload_scene checks): pass 1 is the generated straight-line code that
+// shears every distinct vertex once and evaluates every distinct edge once (tools/gen_pass1.py), pass 2 looks its three
+// vertices up in the distinct-vertex table.  Same floats, same candidates, same hits either way.
+template <int TOPO>
 __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_quad, bool has_ray, HitInfo& hit, int stat_base = 0) {
 	const RaySetup rs = ray_setup(orig, dir);
 	const uint32_t nq = L.hdr().n_quads;
@@ -510,8 +524,12 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(__builtin_fmaf(mn1, mx1, 0.0f)), 31u);
 	};
 	const uint32_t n0 = min(nq, 16u), n1 = nq - n0;
-	for (uint32_t q = 0; q < n0; ++q) quad_flags(q, acc0);
-	for (uint32_t q = 16u; q < nq; ++q) quad_flags(q, acc1);
+	if constexpr (TOPO == 1) pass1_cornell(L.vtab(rs.perm), rs, acc0, acc1);
+	else if constexpr (TOPO == 2) pass1_plane(L.vtab(rs.perm), rs, acc0, acc1);
+	else {
+		for (uint32_t q = 0; q < n0; ++q) quad_flags(q, acc0);
+		for (uint32_t q = 16u; q < nq; ++q) quad_flags(q, acc1);
+	}
 	// triangle k of an accumulator (k-th shifted in) sits at bit (count - 1 - k): reverse and align
 	const uint32_t mixed0 = __builtin_bitreverse32(acc0) >> (32u - 2u * n0);
 	const uint32_t mixed1 = n1 ? __builtin_bitreverse32(acc1) >> (32u - 2u * n1) : 0u;
@@ -531,11 +549,21 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		uint32_t q = bit >> 1, which = bit & 1u;
 		// the candidate's three vertices only: A = vertex 0, B = vertex 1 + which, C = vertex 2 + which of
 		// { x0 y0 x1 y1 x2 y2 x3 y3 | z0 z1 z2 z3 }
-		const float* pq = L.perm(q, rs.perm);
-		const float2 Axy = *reinterpret_cast<const float2*>(pq);
-		const float2 Bxy = *reinterpret_cast<const float2*>(pq + 2u + 2u * which);
-		const float2 Cxy = *reinterpret_cast<const float2*>(pq + 4u + 2u * which);
-		const float pv3[9] = { Axy.x, Axy.y, pq[8], Bxy.x, Bxy.y, pq[9u + which], Cxy.x, Cxy.y, pq[10u + which] };
+		float pv3[9];
+		if constexpr (TOPO != 0) {
+			const uint32_t ids = L.vid(q);
+			const uint32_t ia = ids & 0xFFu, ib = (ids >> (8u + 8u * which)) & 0xFFu, ic = (ids >> (16u + 8u * which)) & 0xFFu;
+			const float* vt = L.vtab(rs.perm);
+			const float* vz = vt + 2u * L.hdr().n_verts;
+			const float2 Axy = *reinterpret_cast<const float2*>(vt + 2u * ia), Bxy = *reinterpret_cast<const float2*>(vt + 2u * ib), Cxy = *reinterpret_cast<const float2*>(vt + 2u * ic);
+			pv3[0] = Axy.x; pv3[1] = Axy.y; pv3[2] = vz[ia]; pv3[3] = Bxy.x; pv3[4] = Bxy.y; pv3[5] = vz[ib]; pv3[6] = Cxy.x; pv3[7] = Cxy.y; pv3[8] = vz[ic];
+		} else {
+			const float* pq = L.perm(q, rs.perm);
+			const float2 Axy = *reinterpret_cast<const float2*>(pq);
+			const float2 Bxy = *reinterpret_cast<const float2*>(pq + 2u + 2u * which);
+			const float2 Cxy = *reinterpret_cast<const float2*>(pq + 4u + 2u * which);
+			pv3[0] = Axy.x; pv3[1] = Axy.y; pv3[2] = pq[8]; pv3[3] = Bxy.x; pv3[4] = Bxy.y; pv3[5] = pq[9u + which]; pv3[6] = Cxy.x; pv3[7] = Cxy.y; pv3[8] = pq[10u + which];
+		}
 		SV A = shear_xyz(pv3[0], pv3[1], pv3[2], rs), B = shear_xyz(pv3[3], pv3[4], pv3[5], rs), C = shear_xyz(pv3[6], pv3[7], pv3[8], rs);
 		float U = B.y * C.x - B.x * C.y;
 		float V = C.y * A.x - C.x * A.y;
@@ -937,6 +965,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 // term -- its contribution if the light is visible, zeros if not -- to nee[target]; the fold adds it to the
 // level's `direct` (the same float addition `radiance += ...` of renderer.cpp:216, or + 0).  Write-only:
 // a read-modify-write of `direct` here cost a 128-byte line fill per ray.  Called in uniform control flow.
+template <int TOPO>
 __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& a, const ShadowQ& q, uint32_t first, uint32_t n) {
 	const uint32_t lane = threadIdx.x & 63u;
 	const bool have = lane < n;
@@ -947,7 +976,7 @@ __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& 
 	}
 	const uint32_t tag = __float_as_uint(e2.z);
 	HitInfo sh;
-	trace(L, mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y), (int)(tag & 0xFFu), have, sh, 2);
+	trace<TOPO>(L, mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y), (int)(tag & 0xFFu), have, sh, 2);
 	if (have) {
 		const bool visible = sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == (tag >> 8);
 		a.nee[__float_as_uint(e2.w)] = visible ? make_float4(e1.z, e1.w, e2.x, e2.y) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1097,6 +1126,7 @@ __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, 
 			resolve_records<SSX_RESOLVE_WAYS>(L, a, u.rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, u.n_kq - kq));
 }
 
+template <int TOPO>
 __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	uint32_t* const lds_words = stage_lds(a);
 	Lds L; L.w = lds_words;
@@ -1164,7 +1194,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		}
 		if (!__any(active)) {
 			// nothing is running: fold what is pending; stop when nothing is left to hand out either
-			if (sq.count) { shadow_flush(L, a, sq, 0u, sq.count); sq.count = 0; }
+			if (sq.count) { shadow_flush<TOPO>(L, a, sq, 0u, sq.count); sq.count = 0; }
 			if (old_pending) { unit_fold(L, a, old); old_pending = false; }
 			if (!cur_valid && !more) break;
 			continue;
@@ -1172,7 +1202,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		bool pushed = false;
 		HitInfo hit; // the primary rays of all lanes: traced in uniform control flow
 		if (active) SSX_STAT(13); // lanes with a path, per iteration
-		trace(L, p.orig, p.dir, p.ignore, active, hit, 0);
+		trace<TOPO>(L, p.orig, p.dir, p.ignore, active, hit, 0);
 		if (active) {
 			if (!path_step(L, sq, a, p, hit, pushed)) {
 				// last level reached (its radiance is in direct[depth]): lambda_0, the hit flag, the number of
@@ -1187,11 +1217,11 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		if (sq.count >= SSX_SQ_FLUSH_AT) { // a full wave of shadow rays
 			const uint32_t take = min(sq.count, 64u);
 			sq.count -= take;
-			shadow_flush(L, a, sq, sq.count, take);
+			shadow_flush<TOPO>(L, a, sq, sq.count, take);
 		}
 		// the previous unit's last paths are done: apply the parked shadow rays (some may be its), fold it
 		if (old_pending && !__any(active && p_tag == old_tag)) {
-			if (sq.count) { shadow_flush(L, a, sq, 0u, sq.count); sq.count = 0; }
+			if (sq.count) { shadow_flush<TOPO>(L, a, sq, 0u, sq.count); sq.count = 0; }
 			unit_fold(L, a, old);
 			old_pending = false;
 		}
@@ -1202,10 +1232,13 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 #define SSX_WAVES_PER_EU 4
 #endif
 // 4 waves per SIMD (128 VGPRs): four 256-lane workgroups per CU with the CIE 1931 tables
-extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SSX_WAVES_PER_EU))) ssx_render_kernel(SsxKernelArgs a) { render_body(a); }
-// The same kernel under another name for the calibration render of ssx_upload_scene, so that
-// kernel traces and statistics of ssx_render_kernel contain real launches only.
-extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) ssx_calibrate_kernel(SsxKernelArgs a) { render_body(a); }
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SSX_WAVES_PER_EU))) ssx_render_kernel(SsxKernelArgs a) { render_body<0>(a); }
+// the same megakernel with pass 1 specialised to the mesh topology of the reference's Cornell box / plane scene
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SSX_WAVES_PER_EU))) ssx_render_kernel_cornell(SsxKernelArgs a) { render_body<1>(a); }
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SSX_WAVES_PER_EU))) ssx_render_kernel_plane(SsxKernelArgs a) { render_body<2>(a); }
+// The generic kernel under another name for the calibration render of ssx_upload_scene (64x64x4 samples), so that
+// kernel traces and statistics of ssx_render_kernel* contain real launches only.
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) ssx_calibrate_kernel(SsxKernelArgs a) { render_body<0>(a); }
 
 // The fold as a pass of its own (one lane per sample, persistent blocks, streaming reads), used
 // instead of the path kernel's tail when SsxKernelArgs::fuse_resolve is 0.

@@ -246,7 +246,8 @@ class Renderer:
         """What the calibration render at scene upload found: frames per sample, and where the fold runs."""
         f, k = C.c_float(), C.c_int()
         self._check(self._lib.ssx_plan_info(self._ctx, C.byref(f), C.byref(k)))
-        return {"frames_per_sample": round(f.value, 3), "fold": "path kernel" if k.value else "resolve kernel"}
+        variant = {0: "generic", 1: "cornell topology", 2: "plane topology"}.get(self._lib.ssx_kernel_variant(self._ctx), "?")
+        return {"frames_per_sample": round(f.value, 3), "fold": "path kernel" if k.value else "resolve kernel", "pass1": variant}
 
     def save(self, path):
         fb = np.ascontiguousarray(self.framebuffer, dtype=np.float32)

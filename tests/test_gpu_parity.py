@@ -409,3 +409,30 @@ def test_many_units_per_wave_parity_and_determinism():
         outs.append(out.cpu().numpy())
     assert np.array_equal(bits(outs[0]), bits(outs[1])) and np.array_equal(bits(outs[0]), bits(outs[2]))
     assert np.isfinite(outs[0]).all()
+
+
+def test_pass1_variants_specialised_for_builtin_topologies_generic_otherwise():
+    """The built-in scenes run the kernels whose pass 1 is specialised to their mesh topology (every test above
+    therefore covers those); a scene with another sharing pattern -- here: one corner of the Cornell box moved
+    apart from its twin -- runs the generic loop.  With SSX_GENERIC_KERNEL set the built-in scenes run the generic
+    loop too: a subprocess repeats the oracle comparisons that way."""
+    import subprocess, sys
+    import custom_scene as cs
+    r = Renderer(Options(scene_name="cornell-srgb", res=(8, 8), spp=1, texture="test-img.png"))
+    assert r.plan_info()["pass1"] == "cornell topology"
+    assert Renderer(Options(scene_name="plane-srgb", res=(8, 8), spp=1, texture="test-img.png")).plan_info()["pass1"] == "plane topology"
+    c = cs.CustomScene("cornell-srgb")
+    pos, st, m = c.quads[0]
+    pos = pos.copy(); pos[0, 0] += 1.0                     # the floor's first corner no longer coincides with the left wall's
+    c.quads[0] = (pos, st, m)
+    orc = c.oracle()
+    r.upload_scene_desc(c.desc(orc))
+    assert r.plan_info()["pass1"] == "generic"
+    r.options.res = (40, 32); r.options.spp = 4; r.options.seed = 3
+    r.xyza = np.zeros((32, 40, 4), dtype=np.float32)
+    r.render_start(); r.render_wait()
+    assert np.array_equal(bits(r.xyza), bits(orc.render(40, 32, 4, seed=3)))
+    env = dict(os.environ, SSX_GENERIC_KERNEL="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                          "bit_exact_against_oracle or config1 or many_units or jakob_hanika_uplift"], env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
+    assert out.returncode == 0, out.stdout[-3000:]

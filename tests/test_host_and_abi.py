@@ -196,3 +196,11 @@ def test_rgb_mode_host_scene_equals_the_oracle(scene):
     assert np.array_equal(s.xyza_to_srgba(x).view(np.uint32), o.to_srgba(x).view(np.uint32))
     with pytest.raises(SsxError):
         Scene(scene, texture="test-img.png", render_mode="nope")
+
+
+def test_generated_pass1_header_is_up_to_date():
+    """csrc/ssx_pass1_gen.h (pass 1 specialised to the built-in scenes' mesh topologies) is generated from the host's
+    scene builder by tools/gen_pass1.py and committed: regenerating must give the same text."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_pass1.py"), "--check"]).returncode == 0

@@ -42,7 +42,7 @@ extern "C" __global__ void k_trace(SsxKernelArgs a, float* in, float* out) {
 	Lds L; L.w = stage_lds(a);
 	const float* p = in + 6 * threadIdx.x;
 	HitInfo h;
-	trace(L, mk(p[0], p[1], p[2]), mk(p[3], p[4], p[5]), (int)p[6], true, h);
+	trace<0>(L, mk(p[0], p[1], p[2]), mk(p[3], p[4], p[5]), (int)p[6], true, h);
 	SINK(out, h.dist + h.U + h.V + h.W + h.det_recip + (float)h.tri);
 }
 extern "C" __global__ void k_bsdf(SsxKernelArgs a, float* in, float* out) {
@@ -92,4 +92,11 @@ extern "C" __global__ void k_hero_index(SsxKernelArgs a, float* in, float* out) 
 	HeroIndex hi = hero_index(L.hdr(), L.spectrum(3), in[threadIdx.x]);
 	float s = 0; for (int i = 0; i < 4; ++i) s += hi.frac[i] + (float)hi.c[i];
 	SINK(out, s);
+}
+extern "C" __global__ void k_trace_cornell(SsxKernelArgs a, float* in, float* out) { // trace() with the Cornell topology's straight-line pass 1
+	Lds L; L.w = stage_lds(a);
+	const float* p = in + 6 * threadIdx.x;
+	HitInfo h;
+	trace<1>(L, mk(p[0], p[1], p[2]), mk(p[3], p[4], p[5]), (int)p[6], true, h);
+	SINK(out, h.dist + h.U + h.V + h.W + h.det_recip + (float)h.tri);
 }
