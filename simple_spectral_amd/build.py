@@ -24,7 +24,10 @@ CLI_SRC = os.path.join(PKG, "host", "main.cpp")
 CLI_BIN = os.path.join(ROOT, "simple-spectral")
 
 # -ffp-contract=off is part of the numerics contract (bit parity with the oracle).
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# -fno-slp-vectorize: the SLP vectoriser pairs adjacent scalar f32 adds / multiplies into v_pk_add_f32 / v_pk_mul_f32.  On
+# gfx950 a packed op issues in 4.4 cycles against 2 x 2.5 for the VOP2 forms and stalls the issue of what follows (measured:
+# SQ_WAIT_INST_ANY -28 % without them); A/B on one box: +4.7 % (2763 against 2640 Msamples/s).  Same operations, same bits.
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra"]
 
 

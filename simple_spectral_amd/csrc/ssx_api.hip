@@ -411,7 +411,7 @@ int timing_events(ssx_ctx* ctx, hipEvent_t** out) {
 	return SSX_OK;
 }
 
-// One batch = samples [k0,k1) of every owned pixel, with its records and frames at record offset
+// One batch = samples [k0,k1) of every owned pixel, with its per-sample arrays at record offset
 // rec_off of the buffers.  front = generate -> path megakernel; back = resolve (fold + XYZ) ->
 // ordered f64 accumulation.
 struct Batch { SsxKernelArgs a; uint32_t units; uint64_t n_rec; hipEvent_t* tev; };
@@ -523,12 +523,12 @@ int launch_pipelined(ssx_ctx* ctx, LaunchPlan& pl, uint32_t spp, uint32_t batch,
 // Where the fold runs is a pure performance choice (same arithmetic, same bits): inside the path
 // kernel its loads hide under other waves' arithmetic (Cornell: 49.4 against 52.6 ms), but its own
 // arithmetic adds to a VALU-bound kernel, which loses when paths are so short that the fold is a
-// large share of the work (plane-srgb: one frame per sample, 5.0 against 5.5 Gsamples/s).  A
-// 64x64x4-sample render of the scene at upload time counts the frames per sample and decides.
+// large share of the work (plane-srgb: one continued level per sample, 5.0 against 5.5 Gsamples/s).  A
+// 64x64x4-sample render of the scene at upload time counts the continued levels per sample and decides.
 int calibrate(ssx_ctx* ctx) {
 	ssx_render_params cp{};
 	cp.struct_size = sizeof cp; cp.width = 64; cp.height = 64; cp.spp = 4; cp.tile_stride = 1;
-	ctx->fuse_resolve = false; // records keep {radiance, lambda_0, hit, #frames}
+	ctx->fuse_resolve = false; // st[] keeps {lambda_0, hit | levels | masks, ...}: the level counts are read back below
 	LaunchPlan pl = make_plan(ctx, &cp);
 	int rc = ensure_samples(ctx, pl, cp.spp);
 	if (rc) return rc;

@@ -727,7 +727,11 @@ __device__ __forceinline__ V3 rand_toward_sphericaltri(Rng& rng, const SphTri& t
 // scene.cpp:417-431 -> geometry.cpp:141-145 -> geometry.cpp:103-116
 __device__ __forceinline__ void sample_light(const Lds& L, Rng& rng, V3 from, V3& dir, uint32_t& light_quad, float& pdf) {
 	const uint32_t nl = L.hdr().n_lights;
-	light_quad = L.light(rand_choice(rng, nl));
+	// one light (wave-uniform test): uniform_int_distribution(0, 0) still draws once (range 1: product = draw, its low
+	// word is below the range only for draw == 0, and then the threshold (2^32 - 1) % 1 = 0 ends the loop) and returns 0
+	uint32_t pick = 0u;
+	if (nl == 1u) (void)rng_next(rng); else pick = rand_choice(rng, nl);
+	light_quad = L.light(pick);
 	const SsxBlobQuad& Q = L.quad(light_quad);
 	bool first = rand_1f(rng) <= 0.5f;
 	const float* p0 = Q.pos[0];

@@ -82,7 +82,7 @@ def main():
     hipcc = "/opt/rocm/bin/hipcc"
     with tempfile.TemporaryDirectory() as td:
         asm = args.keep or os.path.join(td, "k.s")
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-g", "-S", "--cuda-device-only",
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-g", "-S", "--cuda-device-only",
                "-o", asm, SRC] + ["-D" + d for d in args.D]
         subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
         text = open(asm, errors="replace").read().split("\n")

@@ -5,7 +5,7 @@ import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 with tempfile.TemporaryDirectory() as td:
     asm = os.path.join(td, "k.s")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-o", asm,
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-S", "--cuda-device-only", "-o", asm,
                            os.path.join(ROOT, "simple_spectral_amd", "csrc", "ssx_api.hip")] + sys.argv[1:], stderr=subprocess.DEVNULL)
     t = open(asm).read()
 print("%-28s %6s %6s %6s %6s %8s" % ("kernel", "vgpr", "vspill", "sgpr", "sspill", "scratch"))

@@ -20,7 +20,7 @@ def main():
     args = ap.parse_args()
     with tempfile.TemporaryDirectory() as td:
         asm = args.asm or os.path.join(td, "r.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S",
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-S",
                                "--cuda-device-only", "-o", asm, SRC] + ["-D" + d for d in args.D], stderr=subprocess.DEVNULL)
         text = open(asm, errors="replace").read().split("\n")
     cur = None
