@@ -31,27 +31,29 @@ sys.path.insert(0, ROOT)
 # measured per-sample counts (T tri tests, P edge-test passes, S surface interactions).
 FLOP_PER_SAMPLE = {"cornell-srgb": 1.28e4, "cornell": 1.28e4, "plane-srgb": 2.8e3}
 # Algorithmic HBM bytes per sample of the whole pipeline, with L = continued levels
-# per sample (3.35 Cornell, 1 plane: oracle statistics at 128x128 spp 16), R = parked shadow rays per sample
-# (3.14 Cornell, 1.36 plane) and E = levels with an emission term (~0.01: camera rays that hit the light):
+# per sample (the calibration render of the scene at upload measures it: plan_info()["frames_per_sample"], 4.07
+# for the Cornell box, 1.0 for the plane), R = parked shadow rays per sample (3.08 Cornell, 1.36 plane: lane
+# statistics of the profiling build, profiles/*/lanestat.log) and E = levels with an emission term (~0.01:
+# camera rays that hit the light):
 #   generate  : write ray 16 + stream 16
-#   path      : read ray 16 + stream 16; per continued level write fs 16 + np 8; emission term 16 E;
-#               at the end write {lambda, hit | levels | masks, final stream state} 16
+#   path      : read ray 16 + stream 16; per continued level append fs 16 + np 8 + chain word 4; emission term 16 E;
+#               at the end write {lambda, tail word, final stream state} 16
 #   shadow    : R x write nee 16 (write-only: contribution or zeros)
-#   fold      : read stream 16 + (fs 16 + np 8) L + nee 16 R + emission 16 E; write XYZA 16
+#   fold      : read stream 16 + (fs 16 + np 8 + chain word 4) L + nee 16 R + emission 16 E; write XYZA 16
 #   accumulate: read XYZA 16
-LEVELS = {"cornell-srgb": 3.35, "cornell": 3.35, "plane-srgb": 1.0}
-SHADOW = {"cornell-srgb": (3.14, 2.69), "cornell": (3.14, 2.69), "plane-srgb": (1.36, 1.33)}
+LEVELS = {"cornell-srgb": 4.07, "cornell": 4.07, "plane-srgb": 1.0}
+SHADOW = {"cornell-srgb": 3.08, "cornell": 3.08, "plane-srgb": 1.36}
 # gfx950 FP32 vector peak is 157.3 TFLOP/s counting FMA as 2; the parity contract forbids
 # contraction, so the ceiling that applies is the non-fused issue rate, half of it.
 PEAK_VALU_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
 
 
-def algorithmic_bytes_per_sample(scene, path_kernel_only=False):
-    L = LEVELS.get(scene, 3.35)
-    R, _visible = SHADOW.get(scene, (3.14, 2.69))
+def algorithmic_bytes_per_sample(scene, path_kernel_only=False, levels=None):
+    L = levels if levels else LEVELS.get(scene, 4.07)
+    R = SHADOW.get(scene, 3.08)
     E = 0.01
-    path = (32 + 24 * L + 16 * E + 16) + 16 * R + (16 + 24 * L + 16 * R + 16 * E + 16)   # path loop + shadow flush + fold
+    path = (32 + 28 * L + 16 * E + 16) + 16 * R + (16 + 28 * L + 16 * R + 16 * E + 16)   # path loop + shadow flush + fold
     return path if path_kernel_only else 32 + path + 16
 
 
@@ -256,7 +258,9 @@ def main():
         per_gpu_samples = W * H * args.spp
         flop = FLOP_PER_SAMPLE.get(args.scene, 1.28e4)
         achieved_tflops = per_gpu_samples * flop / (kernel_ms * 1e-3) / 1e12
-        hbm_bytes = per_gpu_samples * algorithmic_bytes_per_sample(args.scene)
+        plan = r.plan_info()
+        L = plan["frames_per_sample"]  # continued levels per sample, measured on this scene at upload
+        hbm_bytes = per_gpu_samples * algorithmic_bytes_per_sample(args.scene, levels=L)
         traffic, traffic_detail = measured_traffic(args, world)
         info = r.kernel_info()
         line = {
@@ -276,16 +280,16 @@ def main():
                          "pipeline_ms": round(pipeline_ms, 3), "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
                          "flop_per_sample": flop,
                          "note": "FP32 VALU-issue bound (no MFMA: traversal/sampling); peak = 157.3/2 TFLOP/s because the parity contract forbids FMA contraction. HBM is busy but not the limiter: see hbm.",
-                         "hbm": {"algorithmic_bytes_per_sample": round(algorithmic_bytes_per_sample(args.scene), 1),
-                                 "path_kernel_algorithmic_bytes_per_sample": round(algorithmic_bytes_per_sample(args.scene, True), 1),
-                                 "traffic_over_path_kernel_algorithmic": round(traffic / (per_gpu_samples * algorithmic_bytes_per_sample(args.scene, True)), 3) if traffic else None,
+                         "hbm": {"algorithmic_bytes_per_sample": round(algorithmic_bytes_per_sample(args.scene, levels=L), 1),
+                                 "path_kernel_algorithmic_bytes_per_sample": round(algorithmic_bytes_per_sample(args.scene, True, L), 1),
+                                 "traffic_over_path_kernel_algorithmic": round(traffic / (per_gpu_samples * algorithmic_bytes_per_sample(args.scene, True, L)), 3) if traffic else None,
                                  "algorithmic_GBps": round(hbm_bytes / (pipeline_ms * 1e-3) / 1e9, 1),
                                  "measured_GBps": round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac_algorithmic": round(hbm_bytes / (pipeline_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                                  "frac_measured": round(traffic / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else None},
                          "vgprs": info["vgprs"], "scratch_bytes": info["scratch_bytes"], "lds_bytes": info["lds_bytes"],
-                         "plan": r.plan_info()},
+                         "plan": plan},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.scene, W, H, texture if not texture.startswith("procedural:") else "crystal-lizard-512.png")

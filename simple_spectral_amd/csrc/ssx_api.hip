@@ -324,7 +324,7 @@ int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
 // Every launch writes its samples to [tile slot][k][64] float4 (16 B per sample) and the ordered
 // accumulate pass consumes them; the buffer bounds how many samples per pixel one launch may cover.
 constexpr size_t kSampleBufferBudget = (size_t)64 << 30; // bytes of per-sample arrays one launch may use (288 GB HBM; 512^2 x 256 spp = 38 GB)
-constexpr size_t kBytesPerSampleInFlight = SSX_BYTES_PER_SAMPLE; // 568: ray 16 + stream 16 + 10 levels x (16 + 16) + 9 x (16 + 8)
+constexpr size_t kBytesPerSampleInFlight = SSX_BYTES_PER_SAMPLE; // 604: ray 16 + stream 16 + 10 levels x (16 + 16) + 9 x (16 + 8 + 4)
 constexpr uint32_t kMinUnits = 3072;                   // one wave work unit per wave slot of the GPU (256 CUs x 4 SIMDs x 3 waves)
 
 struct LaunchPlan { SsxKernelArgs args; size_t lds_bytes; uint32_t max_spp_per_launch; };
@@ -379,7 +379,8 @@ void bind_arrays(SsxKernelArgs& a, uint8_t* base, uint64_t cap) {
 	a.direct = reinterpret_cast<float4*>(base);                   base += cap * 16u * SSX_MAX_LEVELS;
 	a.nee = reinterpret_cast<float4*>(base);                      base += cap * 16u * SSX_MAX_LEVELS;
 	a.fs = reinterpret_cast<float4*>(base);                       base += cap * 16u * SSX_MAX_FRAMES;
-	a.np = reinterpret_cast<float2*>(base);
+	a.np = reinterpret_cast<float2*>(base);                       base += cap * 8u * SSX_MAX_FRAMES;
+	a.link = reinterpret_cast<uint32_t*>(base);
 }
 
 // adds the stage durations of the recorded batches to ctx->stage_ms
@@ -429,7 +430,7 @@ Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1, u
 	// 8 samples per pixel and unit (512 items: enough for the refill, and short units balance the end of
 	// the launch; measured best of 1..64 with persistent waves) unless the launch is so small that this
 	// would leave SIMDs without a wave (3 waves x 1024 SIMDs)
-	uint32_t g = 8;
+	uint32_t g = SSX_MAX_UNIT_KS;
 	while (g > 1u && (uint64_t)((n_k + g - 1u) / g) * a.my_tiles < kMinUnits) g >>= 1;
 	a.group_spp = g;
 	if (a.group_spp > n_k) a.group_spp = n_k;
@@ -448,7 +449,7 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	// fetch work units from a counter
 	// the calibration render runs the generic kernel, which reads the per-quad vertex table: it stages the whole blob
 	if (calibration) b.a.blob_words = ctx->blob_words;
-	const size_t path_lds = ((size_t)b.a.blob_words + SSX_LDS_PREFIX_WORDS) * 4 + 4u * SSX_WAVE_SCRATCH_WORDS * 4u;
+	const size_t path_lds = ((size_t)b.a.blob_words + SSX_LDS_PREFIX_WORDS) * 4 + 4u * (SSX_WAVE_SCRATCH_WORDS + SSX_WAVE_COUNTER_WORDS) * 4u;
 	auto path_kernel = ctx->topology == 1u ? ssx_render_kernel_cornell : (ctx->topology == 2u ? ssx_render_kernel_plane : ssx_render_kernel);
 	if (!ctx->d_unit_counter) SSX_HIP(ctx, hipMalloc((void**)&ctx->d_unit_counter, sizeof(uint32_t)));
 	if (ctx->resident_blocks == 0 || calibration) {
@@ -541,7 +542,7 @@ int calibrate(ssx_ctx* ctx) {
 	std::vector<uint4> recs((size_t)b.n_rec);
 	SSX_HIP(ctx, hipMemcpy(recs.data(), b.a.st, recs.size() * sizeof(uint4), hipMemcpyDeviceToHost));
 	uint64_t frames = 0;
-	for (const uint4& r : recs) frames += (r.y >> 4) & 0xFu;
+	for (const uint4& r : recs) frames += (r.y >> 2) & 0xFu;
 	ctx->calib_frames = (float)((double)frames / (double)recs.size());
 	ctx->fuse_resolve = ctx->calib_frames >= 2.0f;
 	return SSX_OK;
@@ -957,7 +958,7 @@ int ssx_debug_samples(ssx_ctx* ctx, const ssx_render_params* p, float* xyza, uin
 			const size_t r = ((size_t)tile * spp + k) * 64u + lane, o = ((size_t)j * p->width + i) * spp + k;
 			if (xyza) { xyza[4 * o + 0] = ray[r].x; xyza[4 * o + 1] = ray[r].y; xyza[4 * o + 2] = ray[r].z; xyza[4 * o + 3] = ray[r].w; }
 			if (rng_state) rng_state[o] = ((uint64_t)st[r].w << 32) | st[r].z;
-			if (levels) levels[o] = (st[r].y >> 4) & 0xFu;
+			if (levels) levels[o] = (st[r].y >> 2) & 0xFu;
 		}
 	}
 	return SSX_OK;
@@ -989,11 +990,11 @@ int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* s
 	SSX_HIP(ctx, hipFuncGetAttributes(&at, path_kernel));
 	if (vgprs) *vgprs = at.numRegs;
 	if (sgprs) *sgprs = 0;
-	if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes + (int)(ctx->path_blob_words + SSX_LDS_PREFIX_WORDS) * 4 + (int)(4u * SSX_WAVE_SCRATCH_WORDS * 4u); // path kernel: coefficients + blob + 4 waves' shadow-ray queues
+	if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes + (int)(ctx->path_blob_words + SSX_LDS_PREFIX_WORDS) * 4 + (int)(4u * (SSX_WAVE_SCRATCH_WORDS + SSX_WAVE_COUNTER_WORDS) * 4u); // path kernel: coefficients + blob + 4 waves' shadow-ray queues
 	if (scratch_bytes) *scratch_bytes = (int)at.localSizeBytes;
 	if (max_blocks_per_cu) {
 		int nb = 0;
-		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, path_kernel, 256, ((size_t)ctx->path_blob_words + SSX_LDS_PREFIX_WORDS) * 4 + 4u * SSX_WAVE_SCRATCH_WORDS * 4u));
+		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, path_kernel, 256, ((size_t)ctx->path_blob_words + SSX_LDS_PREFIX_WORDS) * 4 + 4u * (SSX_WAVE_SCRATCH_WORDS + SSX_WAVE_COUNTER_WORDS) * 4u));
 		*max_blocks_per_cu = nb;
 	}
 	return SSX_OK;

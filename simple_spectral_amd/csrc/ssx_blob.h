@@ -11,10 +11,10 @@
 // 128 entries x 12 words = 6 KB; a 256-lane workgroup takes prefix + blob + 24 KB: four fit a CU's 160 KB
 // for blobs up to 15.6 KB (CIE 1931 tables), three up to 29 KB (CIE 2006)
 #define SSX_WAVE_SCRATCH_WORDS (128u * 12u)
-// dynamic LDS of the kernels that stage the blob: [coefficient table of ssx_fmath.h][blob][wave scratch]
+// dynamic LDS of the kernels that stage the blob: [coefficient table of ssx_fmath.h][blob][4 shadow-ray queues][4 x log counters]
 #define SSX_LDS_PREFIX_WORDS 80u
-// prefix + blob + 4 queues must fit the 64 KiB a workgroup may allocate: 65536 - 320 - 24576 = 40640
-#define SSX_BLOB_MAX_BYTES 40640u
+// prefix + blob + 4 queues + 4 x 16 counters must fit the 64 KiB a workgroup may allocate: 65536 - 320 - 24576 - 256 = 40384
+#define SSX_BLOB_MAX_BYTES 40384u
 
 // Permuted vertex table: for quad q and axis permutation p (0..5) the 12 floats
 //   v00[kx] v00[ky]  v10[kx] v10[ky]  v11[kx] v11[ky]  v01[kx] v01[ky] | v00[kz] v10[kz] v11[kz] v01[kz]
@@ -78,24 +78,38 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 	uint32_t ptr_lo, ptr_hi, w, h;
 };
 
-// Per-sample state in HBM, structure of arrays over the launch's records r = [tile slot][k-k0][pixel in
-// tile] (a wave touches 64 consecutive records, so every array is read and written in full lines):
+// Per-sample state in HBM.  Records r = [tile slot][k-k0][pixel in tile]; a wave's work unit (8x8 tile x
+// group_spp samples, <= 512 records) owns the contiguous records [rec_base, rec_base + 64*n_kq).
 //   ray[r]   float4  generate: {camera ray dir.xyz, lambda_0}; the fold overwrites it with {X, Y, Z, alpha}
 //                    ({R, G, B, alpha} in RGB mode), which the accumulate pass reads
-//   st[r]    uint4   generate: PCG32 {state, inc}; at the end of the path: {lambda_0 bits, hit_anything |
-//                    #levels << 4 | mask of levels with a next-event term << 8 | mask of levels with an emission
-//                    term << 18, final PCG32 state} (the final state = draws consumed, for the per-sample tests)
+//   st[r]    uint4   generate: PCG32 {state, inc}; at the end of the path: {lambda_0 bits, tail word, final PCG32
+//                    state} (the final state = draws consumed, for the per-sample tests).  Tail word (D = number
+//                    of continued levels = the path's last level): hit_anything | level D has an emission term << 1
+//                    | D << 2 | slot of level D-1's entry << 6 | slot of level D's next-event term << 19
 //   direct[l*n + r] float4  level l's emission term (camera ray hitting a light; every hit in the non-ELS build):
-//                    only levels of the emission mask are written
-//   nee[l*n + r]    float4  the level's next-event term, written when its parked shadow ray is traced: the
-//                    contribution if the light is visible, zeros if not (only levels of the mask are defined)
-//   fs[l*n + r]     float4  f_s of the continuation       } rad_l = direct_l + ((rad_{l+1} * n_dot_l) * f_s) / pdf
-//   np[l*n + r]     float2  {n_dot_l, pdf}                }
+//                    written only where it exists (rare)
+// The levels of the recursion are NOT stored per record (paths have 0..9 levels, a [level][record] array is
+// read and written in 128-byte lines of which the deep levels use one record in three): they go to LOGS,
+// entries appended in the order the wave produces them, so that the stores of one wave iteration and the fold's
+// reads fill whole lines.  One log per array and COHORT = the SSX_COHORT_KS consecutive samples per pixel of a
+// unit that one pass of the fold takes (128 records starting at base_rec): a pass reads its cohort's logs
+// front to back, once.
+//   entry of a continued level l of some path, at index base_rec*9 + slot (slot < 9 * 128):
+//     fs[.]    float4  f_s of the continuation       } rad_l = (emission_l + nee_l) + ((rad_{l+1} * n_dot_l) * f_s) / pdf
+//     np[.]    float2  {n_dot_l, pdf}                }
+//     link[.]  uint32  slot of level l-1's entry | slot of level l's next-event term << 13 | level l has an emission
+//                      term << 26   (slots are 13-bit, SSX_NO_SLOT = none): the fold walks a path's chain from its tail
+//   nee[base_rec*10 + slot]  float4  a level's next-event term, appended when its shadow ray is parked, written when
+//                    the ray is traced: the contribution if the light is visible, zeros if not (write-only until the fold)
 // Levels 0..MAX_DEPTH-2 can continue (0..MAX_DEPTH-3 with explicit light sampling), the last level of a path is
-// at most MAX_DEPTH-1: 10 levels of `direct`, 9 of `fs` / `np`.
+// at most MAX_DEPTH-1: 10 levels of `direct` / `nee`, 9 of `fs` / `np` / `link`.
 #define SSX_MAX_FRAMES 9u
 #define SSX_MAX_LEVELS 10u
-#define SSX_BYTES_PER_SAMPLE (16u + 16u + 2u * 16u * SSX_MAX_LEVELS + (16u + 8u) * SSX_MAX_FRAMES)
+#define SSX_NO_SLOT 0x1FFFu
+#define SSX_COHORT_KS 2u          // samples per pixel in a cohort: 128 records, 13-bit slots (10 * 128 < SSX_NO_SLOT)
+#define SSX_MAX_UNIT_KS 8u        // samples per pixel in a work unit: four cohorts (the counters below)
+#define SSX_WAVE_COUNTER_WORDS 16u // per wave, behind the shadow-ray queues: fill counts [unit tag 2][cohort 4][fs, nee]
+#define SSX_BYTES_PER_SAMPLE (16u + 16u + 2u * 16u * SSX_MAX_LEVELS + (16u + 8u + 4u) * SSX_MAX_FRAMES)
 
 struct SsxKernelArgs {
 	const uint32_t* blob;   // device copy of the scene blob
@@ -116,6 +130,7 @@ struct SsxKernelArgs {
 	float4* nee;
 	float4* fs;
 	float2* np;
+	uint32_t* link;
 	uint64_t n_records;       // my_tiles * (k1-k0) * 64
 	uint32_t* unit_counter;   // next work unit of the path kernel's persistent waves (zeroed before the launch)
 	uint32_t rgb_mode;        // 1: RENDER_MODE_RGB (scene uplift == SSX_MODE_RGB): no wavelength draw, no XYZ, plain mean

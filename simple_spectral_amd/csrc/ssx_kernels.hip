@@ -787,10 +787,23 @@ struct Path {
 	int ignore;        // quad the ray starts on (-1: camera)
 	uint32_t depth;
 	uint32_t rec_index; // record of this sample in the per-sample arrays
-	uint32_t nee_mask;  // bit l: level l parked a shadow ray (its next-event term lives in nee[l*n + r]);
-	                    // bit 10+l: level l added an emission term (direct[l*n + r])
+	uint32_t prev_slot; // slot of the previous level's entry in the unit's log (SSX_NO_SLOT at level 0), ssx_blob.h
 	bool hit_anything;
 };
+
+// Where the lane's path appends its level entries: the logs of its COHORT -- the SSX_COHORT_KS consecutive samples
+// per pixel of its work unit that one pass of the fold takes (ssx_blob.h).  A wave has at most two units in flight
+// (the one it hands out items of, and the previous one, whose last paths are still running), each with up to four
+// cohorts; their fill counts live in the wave's LDS words `cnt` ([unit tag][cohort][fs, nee]) and a lane takes a
+// slot with one LDS atomic (the order of the slots within one wave iteration is immaterial).
+struct LogRef {
+	uint32_t* cnt;      // this wave's 16 counters
+	uint32_t group;     // the lane's counter pair: 4 * unit tag + cohort
+	uint32_t base_rec;  // first record of the lane's cohort: its logs start at base_rec * 9 (fs, np, link) / base_rec * 10 (nee)
+};
+__device__ __forceinline__ uint32_t log_append(const LogRef& lg, uint32_t which) {
+	return __hip_atomic_fetch_add(lg.cnt + 2u * lg.group + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
 
 // renderer.cpp:113-138: camera ray (f64, as the reference) and hero wavelength of sample k of
 // pixel (i,j), from its own PCG32 stream (the seeding contract of include/ssx.h).  Runs in
@@ -854,12 +867,14 @@ __device__ __forceinline__ void hit_st(const SsxBlobQuad& Q, uint32_t which, con
 // One level of the recursion L() (renderer.cpp:147-255) for the lane's current ray: closest hit,
 // emission (camera ray only), next-event estimation with its shadow ray, BSDF sample.  Writes the
 // level's emission term if it has one (`direct`), parks its shadow ray (whose flush writes `nee`) and,
-// when the path continues, stores the factors of the continuation; returns true when it continues (p
-// then holds the next ray).
-__device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const SsxKernelArgs& a, Path& p, const HitInfo& hit, bool& pushed) {
+// when the path continues, appends the level's entry (the factors of the continuation and the chain word) to
+// the unit's log; returns true when it continues (p then holds the next ray), else level_word describes the
+// path's last level for the tail word.
+__device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const SsxKernelArgs& a, const LogRef& lg, Path& p, const HitInfo& hit, bool& pushed, uint32_t& level_word) {
 	const SsxBlobHeader& h = L.hdr();
-	const uint32_t level_index = p.depth * (uint32_t)a.n_records + p.rec_index; // < 2^32 per launch (host budget)
-	if (hit.tri < 0) return false; // this level's radiance is 0: neither mask bit is set
+	// what the level's entry (or the path's tail word) says about this level: slot of its next-event term << 13 | has an emission term << 26
+	level_word = SSX_NO_SLOT << 13;
+	if (hit.tri < 0) return false; // this level's radiance is 0: no term of either kind
 	SSX_STAT(4); // lanes with a hit
 	p.hit_anything = true;
 	const uint32_t hq = (uint32_t)hit.tri >> 1, which = (uint32_t)hit.tri & 1u;
@@ -879,8 +894,8 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 #pragma unroll
 		for (int k = 0; k < 4; ++k) direct[k] += em.v[k];
 		// the level's emission term, read back by the fold (levels without it have none: 0 + x == x)
-		a.direct[level_index] = make_float4(direct[0], direct[1], direct[2], direct[3]);
-		p.nee_mask |= 0x400u << p.depth;
+		a.direct[p.depth * (uint32_t)a.n_records + p.rec_index] = make_float4(direct[0], direct[1], direct[2], direct[3]); // < 2^32 per launch (host budget)
+		level_word |= 1u << 26;
 	}
 	// :178 `if (depth+1u<MAX_DEPTH)`: with ELS a ray at depth MAX_DEPTH-1 is never started (below);
 	// without it that ray exists (its hit may emit) and ends here
@@ -921,8 +936,10 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 				float4* E = q.e + 3u * slot;
 				E[0] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, sdir.x);
 				E[1] = make_float4(sdir.y, sdir.z, c[0], c[1]);
-				E[2] = make_float4(c[2], c[3], __uint_as_float((light << 8) | hq), __uint_as_float(level_index));
-				p.nee_mask |= 1u << p.depth;
+				// the term's place in its cohort's log: appended now (parking order = flush order: a flush writes runs of consecutive slots)
+				const uint32_t nslot = log_append(lg, 1u);
+				E[2] = make_float4(c[2], c[3], __uint_as_float((light << 8) | hq), __uint_as_float(lg.base_rec * SSX_MAX_LEVELS + nslot));
+				level_word = (level_word & ~(SSX_NO_SLOT << 13)) | (nslot << 13);
 				pushed = true;
 			}
 		}
@@ -958,8 +975,12 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	if (!cont || (els && p.depth + 2u >= SSX_MAX_DEPTH_)) return false;
 	// the factors of the continuation for the backward fold (resolve_record, when the wave's unit is complete)
 	SSX_STAT(12); // continuing lanes
-	a.fs[level_index] = make_float4(f_s[0], f_s[1], f_s[2], f_s[3]);
-	a.np[level_index] = make_float2(n_dot_l, pdf_w_i);
+	const uint32_t slot = log_append(lg, 0u);
+	const uint32_t entry = lg.base_rec * SSX_MAX_FRAMES + slot;
+	a.fs[entry] = make_float4(f_s[0], f_s[1], f_s[2], f_s[3]);
+	a.np[entry] = make_float2(n_dot_l, pdf_w_i);
+	a.link[entry] = p.prev_slot | level_word;
+	p.prev_slot = slot;
 	p.orig = hit_pos; p.dir = w_i; p.ignore = (int)hq;
 	++p.depth;
 	return true;
@@ -1004,51 +1025,64 @@ __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& 
 // n_dot_l * f_s / pdf, evaluated innermost first = the reference's post-order) over the levels the
 // path recorded, then flux -> CIE XYZ (util/color.hpp:115-139; FLAT_FIELD_CORRECTION: flux =
 // radiance, renderer.cpp:262-263).  ray[r] becomes {X, Y, Z, alpha} ({R, G, B, alpha} in RGB mode).
-// Four records of the lane (consecutive k of its pixel) are folded side by side so that the loads
-// of a level are four independent requests instead of a chain of dependent round trips.
+// A record's levels are a chain through its unit's log: the tail word names the entry of the last continued
+// level, every entry's `link` names the entry below and the level's own next-event term, and the chain word of
+// the next level is fetched one round trip ahead, so a level costs one round trip.  SSX_RESOLVE_WAYS records of the
+// lane (consecutive k of its pixel) are folded side by side: independent chains.
 #ifndef SSX_RESOLVE_WAYS
-#define SSX_RESOLVE_WAYS 4u
+#define SSX_RESOLVE_WAYS 2u // measured: 4 ways spill 13 VGPRs in the path loop (-1.3 %), 3: +2.4 %, 2: +2.7 % (one box, r02t)
 #endif
+static_assert(SSX_RESOLVE_WAYS == SSX_COHORT_KS, "a pass of the fold takes one cohort");
+// fs_base / nee_base: index of slot 0 of the unit's logs (rec_base * 9, rec_base * 10)
 template <uint32_t WAYS>
-__device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count) {
+__device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count, uint32_t fs_base, uint32_t nee_base) {
 	const uint32_t n = (uint32_t)a.n_records;
 	float rad[WAYS][4];
-	uint32_t depth[WAYS], lam[WAYS], hitf[WAYS], nee_mask[WAYS];
+	uint32_t depth[WAYS]; // hit_anything << 4 | number of continued levels
+	uint32_t K[WAYS]; // chain word of the level about to be folded: its entry's `link` (parent slot | nee slot << 13 | emission << 26)
+	uint32_t at[WAYS]; // slot of that level's entry
 	uint32_t top = 0;
 	const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
 	for (uint32_t s = 0; s < WAYS; ++s) {
-		depth[s] = 0; lam[s] = 0; hitf[s] = 0; nee_mask[s] = 0;
+		depth[s] = 0; K[s] = 0; at[s] = 0;
 		rad[s][0] = rad[s][1] = rad[s][2] = rad[s][3] = 0.0f;
 		if (s < count) {
-			const uint4 st = a.st[r0 + s * stride];
-			lam[s] = st.x; hitf[s] = st.y & 1u; depth[s] = (st.y >> 4) & 0xFu; nee_mask[s] = st.y >> 8;
+			const uint32_t y = a.st[r0 + s * stride].y;
+			const uint32_t dep = (y >> 2) & 0xFu;
+			depth[s] = dep | ((y & 1u) << 4);
+			at[s] = (y >> 6) & SSX_NO_SLOT;
 			// the last level's radiance: 0 + its emission term (if any) + its next-event term (if it parked a shadow ray)
-			const uint32_t i = depth[s] * n + r0 + s * stride;
-			const float4 last = ((nee_mask[s] >> (10u + depth[s])) & 1u) ? a.direct[i] : zero4;
-			const float4 ne = ((nee_mask[s] >> depth[s]) & 1u) ? a.nee[i] : zero4;
+			const uint32_t ns = y >> 19;
+			const float4 last = ((y >> 1) & 1u) ? a.direct[dep * n + r0 + s * stride] : zero4;
+			const float4 ne = ns != SSX_NO_SLOT ? a.nee[nee_base + ns] : zero4;
+			if (dep) K[s] = a.link[fs_base + at[s]];
 			rad[s][0] = last.x + ne.x; rad[s][1] = last.y + ne.y; rad[s][2] = last.z + ne.z; rad[s][3] = last.w + ne.w;
+			top = max(top, dep);
 		}
-		top = max(top, depth[s]);
 	}
 	for (uint32_t d = top; d-- > 0u;) {
 		float4 D[WAYS], F[WAYS]; float2 NP[WAYS];
 #pragma unroll
 		for (uint32_t s = 0; s < WAYS; ++s)
-			if (d < depth[s]) {
-				const uint32_t i = d * n + r0 + s * stride;
+			if (d < (depth[s] & 0xFu)) {
+				const uint32_t i = fs_base + at[s];
 				F[s] = a.fs[i]; NP[s] = a.np[i];
 				// emission + next-event term, the order of renderer.cpp:171,216 (0 + x == x where a term is absent)
-				const bool has_ne = (nee_mask[s] >> d) & 1u;
-				D[s] = has_ne ? a.nee[i] : zero4;
-				if ((nee_mask[s] >> (10u + d)) & 1u) { // rare: an emission term below the last level (non-ELS build)
-					const float4 em = a.direct[i];
+				const uint32_t ns = (K[s] >> 13) & SSX_NO_SLOT;
+				const bool has_ne = ns != SSX_NO_SLOT;
+				D[s] = has_ne ? a.nee[nee_base + ns] : zero4;
+				if ((K[s] >> 26) & 1u) { // rare: an emission term below the last level (non-ELS build)
+					const float4 em = a.direct[d * n + r0 + s * stride];
 					D[s] = has_ne ? make_float4(em.x + D[s].x, em.y + D[s].y, em.z + D[s].z, em.w + D[s].w) : em;
 				}
+				// the chain word of the level below, one round trip ahead of its use
+				at[s] = K[s] & SSX_NO_SLOT;
+				if (d) K[s] = a.link[fs_base + at[s]];
 			}
 #pragma unroll
 		for (uint32_t s = 0; s < WAYS; ++s)
-			if (d < depth[s]) {
+			if (d < (depth[s] & 0xFu)) {
 				SSX_STAT(14); // fold: level x way x lanes
 				const double pdf_recip = ssx_exact::div64_rcp_any(NP[s].y);
 				// ... + indirect term (renderer.cpp:247)
@@ -1065,8 +1099,8 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 			Hero flux; flux.v[0] = rad[s][0]; flux.v[1] = rad[s][1]; flux.v[2] = rad[s][2]; flux.v[3] = rad[s][3];
 			float xyz[3];
 			if (a.rgb_mode) { xyz[0] = rad[s][0]; xyz[1] = rad[s][1]; xyz[2] = rad[s][2]; } // renderer.cpp:274-276: lRGB_A_F32(pixel_flux_est, hit)
-			else flux_to_xyz(L, flux, __uint_as_float(lam[s]), xyz);
-			a.ray[r0 + s * stride] = make_float4(xyz[0], xyz[1], xyz[2], hitf[s] ? 1.0f : 0.0f);
+			else flux_to_xyz(L, flux, __uint_as_float(a.st[r0 + s * stride].x), xyz); // lambda_0 (re-read: a register per way less across the chain walk)
+			a.ray[r0 + s * stride] = make_float4(xyz[0], xyz[1], xyz[2], (depth[s] >> 4) ? 1.0f : 0.0f);
 		}
 }
 
@@ -1127,7 +1161,7 @@ __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, 
 	const uint32_t lane = threadIdx.x & 63u;
 	if ((lane & 7u) < u.tw && (lane >> 3) < u.th)
 		for (uint32_t kq = 0; kq < u.n_kq; kq += SSX_RESOLVE_WAYS)
-			resolve_records<SSX_RESOLVE_WAYS>(L, a, u.rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, u.n_kq - kq));
+			resolve_records<SSX_RESOLVE_WAYS>(L, a, u.rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, u.n_kq - kq), (u.rec_base + kq * 64u) * SSX_MAX_FRAMES, (u.rec_base + kq * 64u) * SSX_MAX_LEVELS); // one cohort per pass
 }
 
 template <int TOPO>
@@ -1141,17 +1175,20 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	const V3 cam = mk(h.cam_pos[0], h.cam_pos[1], h.cam_pos[2]);
 
 	Path p;
-	p.orig = cam; p.dir = mk(0.0f, 0.0f, 1.0f); p.ignore = -1; p.depth = 0; p.rec_index = 0; p.lambda_0 = 0.0f; p.hit_anything = false; p.nee_mask = 0;
+	p.orig = cam; p.dir = mk(0.0f, 0.0f, 1.0f); p.ignore = -1; p.depth = 0; p.rec_index = 0; p.lambda_0 = 0.0f; p.hit_anything = false; p.prev_slot = SSX_NO_SLOT;
 	p.rng.state = 0; p.rng.inc = 1;
 	bool active = false;
-	uint32_t p_tag = 0; // which of the (at most two) units in flight the lane's sample belongs to
+	uint32_t p_tag = 0; // which of the (at most two) units in flight the lane's sample belongs to, and its cohort there:
+	                    // unit tag | cohort << 1 | (sample's position in the cohort) << 3
+	uint32_t* const log_cnt = lds_words + a.blob_words + 4u * SSX_WAVE_SCRATCH_WORDS + wave * SSX_WAVE_COUNTER_WORDS; // see LogRef
 	ShadowQ sq; // this wave's queue behind the blob (16-byte aligned: blob_words is a multiple of 4)
 	sq.e = reinterpret_cast<float4*>(lds_words + a.blob_words + wave * SSX_WAVE_SCRATCH_WORDS);
 	sq.count = 0;
 	// Persistent waves: units are fetched from a global counter, and the next unit's items are handed
 	// out as soon as the current one has none left -- its last paths finish alongside the new ones
 	// instead of on a draining wave (10 % of all wave iterations with one unit per wave).  `cur` feeds
-	// idle lanes; `old` is the previous unit, still waiting for its last lanes and then for its fold.
+	// idle lanes; `old` is the previous unit, still waiting for its last lanes and then for its fold (when the
+	// fold is a kernel of its own, a.fuse_resolve == 0, `old` is tracked all the same: its lanes append to its logs).
 	WorkUnit cur, old;
 	bool cur_valid = false, old_pending = false, more = true;
 	uint32_t cur_tag = 0, old_tag = 0;
@@ -1159,14 +1196,17 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	for (;;) {
 		// rotate: the current unit has no items left and the previous one is folded
 		if (cur_valid && next_item >= cur.n_items && !old_pending) {
-			if (a.fuse_resolve) { old = cur; old_tag = cur_tag; old_pending = true; }
+			old = cur; old_tag = cur_tag; old_pending = true;
 			cur_valid = false;
 		}
 		if (!cur_valid && more) {
 			uint32_t u = 0;
 			if (lane == 0u) u = atomicAdd(a.unit_counter, 1u);
 			u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
-			if (u < total_units) { unit_setup(a, u, cur); cur_tag ^= 1u; next_item = 0; cur_valid = true; }
+			if (u < total_units) {
+				unit_setup(a, u, cur); cur_tag ^= 1u; next_item = 0; cur_valid = true;
+				if (lane < 8u) log_cnt[8u * cur_tag + lane] = 0u; // the logs of its cohorts are empty (the last unit with this tag has been folded)
+			}
 			else more = false;
 		}
 		// hand out items to idle lanes
@@ -1188,9 +1228,9 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 					p.orig = cam;
 					p.ignore = -1;
 					p.depth = 0;
-					p.nee_mask = 0;
+					p.prev_slot = SSX_NO_SLOT;
 					p.hit_anything = false;
-					p_tag = cur_tag;
+					p_tag = cur_tag | ((kq / SSX_COHORT_KS) << 1) | ((kq % SSX_COHORT_KS) << 3);
 					active = true;
 				}
 			}
@@ -1199,7 +1239,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		if (!__any(active)) {
 			// nothing is running: fold what is pending; stop when nothing is left to hand out either
 			if (sq.count) { shadow_flush<TOPO>(L, a, sq, 0u, sq.count); sq.count = 0; }
-			if (old_pending) { unit_fold(L, a, old); old_pending = false; }
+			if (old_pending) { if (a.fuse_resolve) unit_fold(L, a, old); old_pending = false; }
 			if (!cur_valid && !more) break;
 			continue;
 		}
@@ -1208,12 +1248,16 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		if (active) SSX_STAT(13); // lanes with a path, per iteration
 		trace<TOPO>(L, p.orig, p.dir, p.ignore, active, hit, 0);
 		if (active) {
-			if (!path_step(L, sq, a, p, hit, pushed)) {
-				// last level reached (its radiance is in direct[depth]): lambda_0, the hit flag, the number of
-				// continued levels and the final PCG32 state replace the sample's stream; the fold happens
-				// when its unit is complete
-				a.st[p.rec_index] = make_uint4(__float_as_uint(p.lambda_0), (p.hit_anything ? 1u : 0u) | (p.depth << 4) | (p.nee_mask << 8),
-				                               (uint32_t)p.rng.state, (uint32_t)(p.rng.state >> 32));
+			LogRef lg;
+			lg.cnt = log_cnt; lg.group = ((p_tag & 1u) << 2) | ((p_tag >> 1) & 3u);
+			lg.base_rec = (p.rec_index & ~63u) - ((p_tag >> 3) << 6);
+			uint32_t level_word;
+			if (!path_step(L, sq, a, lg, p, hit, pushed, level_word)) {
+				// last level reached: lambda_0, the tail word (hit flag, number of continued levels, where the chain of
+				// its levels starts, the last level's own terms: ssx_blob.h) and the final PCG32 state replace the
+				// sample's stream; the fold happens when its unit is complete
+				const uint32_t tail = (p.hit_anything ? 1u : 0u) | ((level_word >> 26) << 1) | (p.depth << 2) | (p.prev_slot << 6) | ((level_word >> 13) << 19);
+				a.st[p.rec_index] = make_uint4(__float_as_uint(p.lambda_0), tail, (uint32_t)p.rng.state, (uint32_t)(p.rng.state >> 32));
 				active = false;
 			}
 		}
@@ -1224,9 +1268,11 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			shadow_flush<TOPO>(L, a, sq, sq.count, take);
 		}
 		// the previous unit's last paths are done: apply the parked shadow rays (some may be its), fold it
-		if (old_pending && !__any(active && p_tag == old_tag)) {
-			if (sq.count) { shadow_flush<TOPO>(L, a, sq, 0u, sq.count); sq.count = 0; }
-			unit_fold(L, a, old);
+		if (old_pending && !__any(active && (p_tag & 1u) == old_tag)) {
+			if (a.fuse_resolve) {
+				if (sq.count) { shadow_flush<TOPO>(L, a, sq, 0u, sq.count); sq.count = 0; }
+				unit_fold(L, a, old);
+			}
 			old_pending = false;
 		}
 	}
@@ -1257,7 +1303,12 @@ extern "C" __global__ void __launch_bounds__(256) ssx_resolve_kernel(SsxKernelAr
 			const uint32_t i = (tile % a.tiles_x) * 8u + (lane & 7u), j = (tile / a.tiles_x) * 8u + (lane >> 3);
 			if (i >= a.width || j >= a.height) continue;
 		}
-		resolve_records<1u>(L, a, (uint32_t)r, 0u, 1u);
+		// the cohort of record r (unit_setup, LogRef): records of one tile slot are k-major, units are groups of group_spp
+		// consecutive k, cohorts groups of SSX_COHORT_KS consecutive k of a unit
+		const uint32_t n_k = a.k1 - a.k0;
+		const uint32_t rk = (uint32_t)(r >> 6), kk = rk % n_k;
+		const uint32_t base_rec = (rk - (kk % a.group_spp) % SSX_COHORT_KS) * 64u; // first record of r's cohort
+		resolve_records<1u>(L, a, (uint32_t)r, 0u, 1u, base_rec * SSX_MAX_FRAMES, base_rec * SSX_MAX_LEVELS);
 	}
 }
 
