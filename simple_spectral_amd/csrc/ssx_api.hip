@@ -48,6 +48,7 @@ struct ssx_ctx {
 	double* d_accum = nullptr;  size_t accum_pixels = 0;
 	uint32_t* d_unit_counter = nullptr; // work-unit counter of the path kernel's persistent waves
 	int resident_blocks = 0;            // 256-lane path-kernel workgroups the GPU holds at once
+	uint32_t queue_words = SSX_QUEUE_WORDS_WIDE; // entry size of the shadow-ray queues the launches use (pick_queue)
 	uint8_t* d_samples = nullptr; size_t sample_slots = 0; // per-sample arrays (ssx_blob.h), one allocation; record capacity
 	float* d_out = nullptr;     size_t out_pixels = 0;
 	float* d_peer = nullptr;    size_t peer_pixels = 0; // staging buffer of ssx_accumulate_peer
@@ -215,8 +216,9 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	h.words_without_perm = off;
 	h.off_perm = off;      off = align4(off + s->n_quads * SSX_PERM_WORDS_PER_QUAD); // last: not staged by the specialised kernels
 	h.total_words = off;
-	// prefix + blob + the four waves' shadow-ray queues is what a path-kernel workgroup allocates (<= 64 KiB)
-	if ((size_t)(h.topology ? h.words_without_perm : off) * 4 > SSX_BLOB_MAX_BYTES) return fail(ctx, SSX_ERR_SCENE, fmt("scene tables need %u bytes of LDS (max %u)", off * 4, SSX_BLOB_MAX_BYTES));
+	// prefix + blob + the four waves' shadow-ray queues is what a path-kernel workgroup allocates (<= 64 KiB); the
+	// calibration render stages the whole blob also where the scene's own kernel stops before the per-quad table
+	if ((size_t)off * 4 > SSX_BLOB_MAX_BYTES) return fail(ctx, SSX_ERR_SCENE, fmt("scene tables need %u bytes of LDS (max %u)", off * 4, SSX_BLOB_MAX_BYTES));
 
 	blob.assign(off, 0u);
 	memcpy(blob.data(), &h, sizeof h);
@@ -324,7 +326,7 @@ int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
 // Every launch writes its samples to [tile slot][k][64] float4 (16 B per sample) and the ordered
 // accumulate pass consumes them; the buffer bounds how many samples per pixel one launch may cover.
 constexpr size_t kSampleBufferBudget = (size_t)64 << 30; // bytes of per-sample arrays one launch may use (288 GB HBM; 512^2 x 256 spp = 38 GB)
-constexpr size_t kBytesPerSampleInFlight = SSX_BYTES_PER_SAMPLE; // 604: ray 16 + stream 16 + 10 levels x (16 + 16) + 9 x (16 + 8 + 4)
+constexpr size_t kBytesPerSampleInFlight = SSX_BYTES_PER_SAMPLE; // 620: ray 16 + stream 16 + 10 levels x (16 + 16 + 1) + 9 x (16 + 8 + 4) + 6
 constexpr uint32_t kMinUnits = 3072;                   // one wave work unit per wave slot of the GPU (256 CUs x 4 SIMDs x 3 waves)
 
 struct LaunchPlan { SsxKernelArgs args; size_t lds_bytes; uint32_t max_spp_per_launch; };
@@ -380,7 +382,8 @@ void bind_arrays(SsxKernelArgs& a, uint8_t* base, uint64_t cap) {
 	a.nee = reinterpret_cast<float4*>(base);                      base += cap * 16u * SSX_MAX_LEVELS;
 	a.fs = reinterpret_cast<float4*>(base);                       base += cap * 16u * SSX_MAX_FRAMES;
 	a.np = reinterpret_cast<float2*>(base);                       base += cap * 8u * SSX_MAX_FRAMES;
-	a.link = reinterpret_cast<uint32_t*>(base);
+	a.link = reinterpret_cast<uint32_t*>(base);                   base += cap * 4u * SSX_MAX_FRAMES;
+	a.vis = base;
 }
 
 // adds the stage durations of the recorded batches to ctx->stage_ms
@@ -440,6 +443,29 @@ Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1, u
 	return b;
 }
 
+// dynamic LDS of a path-kernel workgroup: coefficient table + staged blob + 4 waves' shadow-ray queues and log counters
+size_t path_lds_bytes(uint32_t blob_words, uint32_t queue_words) {
+	return ((size_t)blob_words + SSX_LDS_PREFIX_WORDS) * 4 + 4u * ((size_t)SSX_QUEUE_ENTRIES * queue_words + SSX_WAVE_COUNTER_WORDS) * 4u;
+}
+// the path megakernel for a pass-1 variant (0 generic, 1 Cornell topology, 2 plane topology) and queue entry size
+typedef void (*path_kernel_t)(SsxKernelArgs);
+path_kernel_t path_kernel_of(uint32_t topology, bool narrow) {
+	if (topology == 1u) return narrow ? ssx_render_kernel_cornell_nq : ssx_render_kernel_cornell;
+	if (topology == 2u) return narrow ? ssx_render_kernel_plane_nq : ssx_render_kernel_plane;
+	return narrow ? ssx_render_kernel_nq : ssx_render_kernel;
+}
+// Wide queue entries (ssx_blob.h) unless the narrow ones let one more workgroup live on a CU (or only they fit at all).
+int pick_queue(ssx_ctx* ctx, uint32_t topology, uint32_t blob_words, uint32_t* queue_words, int* blocks_per_cu) {
+	int wide = 0, narrow = 0;
+	if (path_lds_bytes(blob_words, SSX_QUEUE_WORDS_WIDE) <= 65536u)
+		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&wide, (const void*)path_kernel_of(topology, false), 256, path_lds_bytes(blob_words, SSX_QUEUE_WORDS_WIDE)));
+	SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&narrow, (const void*)path_kernel_of(topology, true), 256, path_lds_bytes(blob_words, SSX_QUEUE_WORDS_NARROW)));
+	const bool use_narrow = narrow > wide || getenv("SSX_NARROW_QUEUE") != nullptr; // the variable: tests and A/B runs
+	*queue_words = use_narrow ? SSX_QUEUE_WORDS_NARROW : SSX_QUEUE_WORDS_WIDE;
+	if (blocks_per_cu) *blocks_per_cu = use_narrow ? narrow : wide;
+	return SSX_OK;
+}
+
 int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stream, bool calibration = false) {
 	if (ctx->timing) { int r = timing_events(ctx, &b.tev); if (r) return r; SSX_HIP(ctx, hipEventRecord(b.tev[0], stream)); }
 	hipLaunchKernelGGL(ssx_generate_kernel, dim3((uint32_t)((b.n_rec + 255u) / 256u)), dim3(256), 0, stream, b.a);
@@ -449,16 +475,23 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	// fetch work units from a counter
 	// the calibration render runs the generic kernel, which reads the per-quad vertex table: it stages the whole blob
 	if (calibration) b.a.blob_words = ctx->blob_words;
-	const size_t path_lds = ((size_t)b.a.blob_words + SSX_LDS_PREFIX_WORDS) * 4 + 4u * (SSX_WAVE_SCRATCH_WORDS + SSX_WAVE_COUNTER_WORDS) * 4u;
-	auto path_kernel = ctx->topology == 1u ? ssx_render_kernel_cornell : (ctx->topology == 2u ? ssx_render_kernel_plane : ssx_render_kernel);
 	if (!ctx->d_unit_counter) SSX_HIP(ctx, hipMalloc((void**)&ctx->d_unit_counter, sizeof(uint32_t)));
 	if (ctx->resident_blocks == 0 || calibration) {
 		int per_cu = 0;
 		hipDeviceProp_t prop;
-		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, calibration ? (const void*)ssx_calibrate_kernel : (const void*)path_kernel, 256, path_lds));
+		if (calibration) {
+			ctx->queue_words = SSX_QUEUE_WORDS_NARROW;
+			SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ssx_calibrate_kernel, 256, path_lds_bytes(b.a.blob_words, SSX_QUEUE_WORDS_NARROW)));
+		} else {
+			int r = pick_queue(ctx, ctx->topology, b.a.blob_words, &ctx->queue_words, &per_cu);
+			if (r) return r;
+		}
 		SSX_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
 		ctx->resident_blocks = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
 	}
+	b.a.queue_words = ctx->queue_words;
+	const size_t path_lds = path_lds_bytes(b.a.blob_words, b.a.queue_words);
+	auto path_kernel = path_kernel_of(ctx->topology, b.a.queue_words == SSX_QUEUE_WORDS_NARROW);
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_unit_counter, 0, sizeof(uint32_t), stream));
 	b.a.unit_counter = ctx->d_unit_counter;
 	const uint32_t want_blocks = (b.units + 3u) / 4u;
@@ -986,17 +1019,15 @@ int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* s
 	if (!ctx) return SSX_ERR_ARG;
 	SSX_HIP(ctx, hipSetDevice(ctx->device));
 	hipFuncAttributes at;
-	const void* path_kernel = ctx->topology == 1u ? (const void*)ssx_render_kernel_cornell : (ctx->topology == 2u ? (const void*)ssx_render_kernel_plane : (const void*)ssx_render_kernel);
-	SSX_HIP(ctx, hipFuncGetAttributes(&at, path_kernel));
+	uint32_t qw = 0; int nb = 0;
+	int r = pick_queue(ctx, ctx->topology, ctx->path_blob_words, &qw, &nb);
+	if (r) return r;
+	SSX_HIP(ctx, hipFuncGetAttributes(&at, (const void*)path_kernel_of(ctx->topology, qw == SSX_QUEUE_WORDS_NARROW)));
 	if (vgprs) *vgprs = at.numRegs;
 	if (sgprs) *sgprs = 0;
-	if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes + (int)(ctx->path_blob_words + SSX_LDS_PREFIX_WORDS) * 4 + (int)(4u * (SSX_WAVE_SCRATCH_WORDS + SSX_WAVE_COUNTER_WORDS) * 4u); // path kernel: coefficients + blob + 4 waves' shadow-ray queues
+	if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes + (int)path_lds_bytes(ctx->path_blob_words, qw);
 	if (scratch_bytes) *scratch_bytes = (int)at.localSizeBytes;
-	if (max_blocks_per_cu) {
-		int nb = 0;
-		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, path_kernel, 256, ((size_t)ctx->path_blob_words + SSX_LDS_PREFIX_WORDS) * 4 + 4u * (SSX_WAVE_SCRATCH_WORDS + SSX_WAVE_COUNTER_WORDS) * 4u));
-		*max_blocks_per_cu = nb;
-	}
+	if (max_blocks_per_cu) *max_blocks_per_cu = nb;
 	return SSX_OK;
 }
 

@@ -7,14 +7,19 @@
 #include <stdint.h>
 #include <hip/hip_runtime.h>
 
-// per-wave LDS scratch of the path kernel: the queue of parked shadow rays (ShadowQ in ssx_kernels.hip),
-// 128 entries x 12 words = 6 KB; a 256-lane workgroup takes prefix + blob + 24 KB: four fit a CU's 160 KB
-// for blobs up to 15.6 KB (CIE 1931 tables), three up to 29 KB (CIE 2006)
-#define SSX_WAVE_SCRATCH_WORDS (128u * 12u)
+// per-wave LDS scratch of the path kernel: the queue of parked shadow rays (ShadowQ in ssx_kernels.hip), 128
+// entries of 12 words (6 KB: the entry carries the ray's contribution) or of 8 words (4 KB: the contribution goes
+// to HBM when the ray is parked, SsxKernelArgs::queue_words).  A 256-lane workgroup takes prefix + blob + 4 queues
+// + counters, and a CU's 160 KB hold four of them up to 40.96 KB each: the host takes the 12-word entries when
+// four fit with them (CIE 1931 tables) and the 8-word entries when that buys the fourth workgroup (CIE 2006
+// tables with the distinct-vertex table of the specialised kernels).
+#define SSX_QUEUE_ENTRIES 128u
+#define SSX_QUEUE_WORDS_WIDE 12u
+#define SSX_QUEUE_WORDS_NARROW 8u
 // dynamic LDS of the kernels that stage the blob: [coefficient table of ssx_fmath.h][blob][4 shadow-ray queues][4 x log counters]
 #define SSX_LDS_PREFIX_WORDS 80u
-// prefix + blob + 4 queues + 4 x 16 counters must fit the 64 KiB a workgroup may allocate: 65536 - 320 - 24576 - 256 = 40384
-#define SSX_BLOB_MAX_BYTES 40384u
+// prefix + blob + 4 (narrow) queues + 4 x 16 counters must fit the 64 KiB a workgroup may allocate: 65536 - 320 - 16384 - 256 = 48576
+#define SSX_BLOB_MAX_BYTES 48576u
 
 // Permuted vertex table: for quad q and axis permutation p (0..5) the 12 floats
 //   v00[kx] v00[ky]  v10[kx] v10[ky]  v11[kx] v11[ky]  v01[kx] v01[ky] | v00[kz] v10[kz] v11[kz] v01[kz]
@@ -99,17 +104,22 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 //     np[.]    float2  {n_dot_l, pdf}                }
 //     link[.]  uint32  slot of level l-1's entry | slot of level l's next-event term << 13 | level l has an emission
 //                      term << 26   (slots are 13-bit, SSX_NO_SLOT = none): the fold walks a path's chain from its tail
-//   nee[base_rec*10 + slot]  float4  a level's next-event term, appended when its shadow ray is parked, written when
-//                    the ray is traced: the contribution if the light is visible, zeros if not (write-only until the fold)
+//   nee[base_rec*10 + slot]  float4  a level's next-event term, slot appended when its shadow ray is parked.  Wide queue
+//                    entries: written when the ray is traced, the contribution ((emitted*n_dot_l)*f_s)/pdf if the light is
+//                    visible, zeros if not.  Narrow entries: the contribution, written when the ray is parked, and
+//   vis[base_rec*10 + slot]  uint8   written when the ray is traced: 1 if the light is visible, 0 if not; the term is
+//                    vis ? nee : 0.  (All write-only until the fold.)
 // Levels 0..MAX_DEPTH-2 can continue (0..MAX_DEPTH-3 with explicit light sampling), the last level of a path is
 // at most MAX_DEPTH-1: 10 levels of `direct` / `nee`, 9 of `fs` / `np` / `link`.
 #define SSX_MAX_FRAMES 9u
 #define SSX_MAX_LEVELS 10u
 #define SSX_NO_SLOT 0x1FFFu
+#ifndef SSX_COHORT_KS
 #define SSX_COHORT_KS 2u          // samples per pixel in a cohort: 128 records, 13-bit slots (10 * 128 < SSX_NO_SLOT)
+#endif
 #define SSX_MAX_UNIT_KS 8u        // samples per pixel in a work unit: four cohorts (the counters below)
 #define SSX_WAVE_COUNTER_WORDS 16u // per wave, behind the shadow-ray queues: fill counts [unit tag 2][cohort 4][fs, nee]
-#define SSX_BYTES_PER_SAMPLE (16u + 16u + 2u * 16u * SSX_MAX_LEVELS + (16u + 8u + 4u) * SSX_MAX_FRAMES)
+#define SSX_BYTES_PER_SAMPLE (16u + 16u + (2u * 16u + 1u) * SSX_MAX_LEVELS + (16u + 8u + 4u) * SSX_MAX_FRAMES + 6u) // 6: keeps the arrays 16-byte aligned
 
 struct SsxKernelArgs {
 	const uint32_t* blob;   // device copy of the scene blob
@@ -131,8 +141,10 @@ struct SsxKernelArgs {
 	float4* fs;
 	float2* np;
 	uint32_t* link;
+	uint8_t* vis;
 	uint64_t n_records;       // my_tiles * (k1-k0) * 64
 	uint32_t* unit_counter;   // next work unit of the path kernel's persistent waves (zeroed before the launch)
 	uint32_t rgb_mode;        // 1: RENDER_MODE_RGB (scene uplift == SSX_MODE_RGB): no wavelength draw, no XYZ, plain mean
 	uint32_t fuse_resolve;    // 1: the path kernel folds each unit's samples itself; 0: ssx_resolve_kernel does
+	uint32_t queue_words;     // words per entry of the shadow-ray queues: SSX_QUEUE_WORDS_WIDE or _NARROW (see above)
 };

@@ -838,15 +838,18 @@ __device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const Ss
 
 // Deferred shadow rays.  Only about half of the lanes that shade a hit have a shadow ray
 // (n.l > 0), and a trace costs a wave the same whether 32 or 64 of its lanes hold a ray.  So the
-// shadow ray of an interaction is not traced on the spot: the lane parks it -- origin, direction,
-// quad to ignore, light, and the contribution ((emitted*n_dot_l)*f_s)/pdf it adds if the light
-// is visible (renderer.cpp:216) -- in a per-wave LDS queue, and whenever 64 have gathered the
-// wave traces them with every lane busy (any lane takes any entry) and adds the contributions of
-// the visible ones to that level's `direct` (direct[level*n + record], written by path_step before
-// the ray can be flushed).  `direct` + contribution is one float addition with the same operands
-// as `radiance += ...` in place, so the bits do not change; the RNG stream is untouched (the
-// shadow test draws nothing).
-//   entry = 3 x float4: {orig.xyz, dir.x} {dir.y, dir.z, c0, c1} {c2, c3, light<<8|ignore, target}
+// shadow ray of an interaction is not traced on the spot: the lane appends the contribution
+// ((emitted*n_dot_l)*f_s)/pdf the ray adds if the light is visible (renderer.cpp:216) to its cohort's `nee`
+// log and parks the ray -- origin, direction, quad to ignore, light, the contribution's index -- in a
+// per-wave LDS queue; whenever 64 have gathered the wave traces them with every lane busy (any lane
+// takes any entry) and records each ray's visibility (vis[index]).  The fold adds `vis ? nee : 0` to the
+// level's radiance: the same float addition as `radiance += ...` in place (or + 0), so the bits do not
+// change; the RNG stream is untouched (the shadow test draws nothing).
+//   narrow entry = 2 x float4: {orig.xyz, dir.x} {dir.y, dir.z, light<<8|ignore, index}
+// With wide entries (SsxKernelArgs::queue_words, ssx_blob.h: used when their 2 KB per wave do not cost a workgroup
+// per CU) the contribution rides in the entry instead -- {orig.xyz, dir.x} {dir.y, dir.z, c0, c1} {c2, c3,
+// light<<8|ignore, index} -- and the flush writes the finished term, contribution or zeros, to nee[index]: one
+// 16-byte store per ray instead of a 16-byte and a 1-byte one, no `vis` load in the fold (1 % faster).
 #define SSX_SQ_FLUSH_AT 64u
 #define SSX_SQ_CAPACITY 128u // < 64 left over + 64 new per iteration
 struct ShadowQ {
@@ -870,6 +873,7 @@ __device__ __forceinline__ void hit_st(const SsxBlobQuad& Q, uint32_t which, con
 // when the path continues, appends the level's entry (the factors of the continuation and the chain word) to
 // the unit's log; returns true when it continues (p then holds the next ray), else level_word describes the
 // path's last level for the tail word.
+template <bool NARROW>
 __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const SsxKernelArgs& a, const LogRef& lg, Path& p, const HitInfo& hit, bool& pushed, uint32_t& level_word) {
 	const SsxBlobHeader& h = L.hdr();
 	// what the level's entry (or the path's tail word) says about this level: slot of its next-event term << 13 | has an emission term << 26
@@ -933,12 +937,20 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 				SSX_STAT(10); // shadow rays parked
 				const uint64_t pushing = __ballot(1);
 				const uint32_t slot = q.count + __builtin_amdgcn_mbcnt_hi((uint32_t)(pushing >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushing, 0u));
-				float4* E = q.e + 3u * slot;
-				E[0] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, sdir.x);
-				E[1] = make_float4(sdir.y, sdir.z, c[0], c[1]);
-				// the term's place in its cohort's log: appended now (parking order = flush order: a flush writes runs of consecutive slots)
+				// the contribution's place in its cohort's log (parking order = flush order: a flush writes runs of consecutive bytes)
 				const uint32_t nslot = log_append(lg, 1u);
-				E[2] = make_float4(c[2], c[3], __uint_as_float((light << 8) | hq), __uint_as_float(lg.base_rec * SSX_MAX_LEVELS + nslot));
+				const uint32_t ni = lg.base_rec * SSX_MAX_LEVELS + nslot;
+				if (NARROW) {
+					a.nee[ni] = make_float4(c[0], c[1], c[2], c[3]);
+					float4* E = q.e + 2u * slot;
+					E[0] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, sdir.x);
+					E[1] = make_float4(sdir.y, sdir.z, __uint_as_float((light << 8) | hq), __uint_as_float(ni));
+				} else {
+					float4* E = q.e + 3u * slot;
+					E[0] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, sdir.x);
+					E[1] = make_float4(sdir.y, sdir.z, c[0], c[1]);
+					E[2] = make_float4(c[2], c[3], __uint_as_float((light << 8) | hq), __uint_as_float(ni));
+				}
 				level_word = (level_word & ~(SSX_NO_SLOT << 13)) | (nslot << 13);
 				pushed = true;
 			}
@@ -986,29 +998,30 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	return true;
 }
 
-// Traces the parked shadow rays [first, first+n), n <= 64, one per lane, and stores every ray's next-event
-// term -- its contribution if the light is visible, zeros if not -- to nee[target]; the fold adds it to the
-// level's `direct` (the same float addition `radiance += ...` of renderer.cpp:216, or + 0).  Write-only:
-// a read-modify-write of `direct` here cost a 128-byte line fill per ray.  Called in uniform control flow.
-template <int TOPO>
+// Traces the parked shadow rays [first, first+n), n <= 64, one per lane, and records the outcome: the ray's visibility
+// (vis[index]; narrow entries, the contribution went to nee[index] when the ray was parked) or the finished next-event
+// term (nee[index] = visible ? contribution : 0; wide entries).  Called in uniform control flow.
+template <int TOPO, bool NARROW>
 __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& a, const ShadowQ& q, uint32_t first, uint32_t n) {
 	const uint32_t lane = threadIdx.x & 63u;
 	const bool have = lane < n;
-	float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = make_float4(1.0f, 0.0f, 0.0f, 0.0f), e2 = e0;
+	const bool narrow = NARROW;
+	float4 e0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), e1 = make_float4(0.0f, 1.0f, 0.0f, 0.0f), e2 = e0;
 	if (have) {
-		const float4* E = q.e + 3u * (first + lane);
-		e0 = E[0]; e1 = E[1]; e2 = E[2];
+		if (narrow) { const float4* E = q.e + 2u * (first + lane); e0 = E[0]; e1 = E[1]; e2.z = e1.z; e2.w = e1.w; }
+		else { const float4* E = q.e + 3u * (first + lane); e0 = E[0]; e1 = E[1]; e2 = E[2]; }
 	}
 	const uint32_t tag = __float_as_uint(e2.z);
 	HitInfo sh;
 	trace<TOPO>(L, mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y), (int)(tag & 0xFFu), have, sh, 2);
 	if (have) {
 		const bool visible = sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == (tag >> 8);
-		a.nee[__float_as_uint(e2.w)] = visible ? make_float4(e1.z, e1.w, e2.x, e2.y) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (narrow) a.vis[__float_as_uint(e2.w)] = visible ? (uint8_t)1 : (uint8_t)0;
+		else a.nee[__float_as_uint(e2.w)] = visible ? make_float4(e1.z, e1.w, e2.x, e2.y) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	}
 }
 
-// Memory-ordering contract of the fold (unit_fold -> resolve_records).  It reads `direct`, `nee`, `fs`, `np`
+// Memory-ordering contract of the fold (unit_fold -> resolve_records).  It reads `direct`, `nee`, `vis`, `fs`, `np`, `link`
 // and `st` entries that OTHER LANES OF THE SAME WAVE stored earlier in the wave's single instruction stream
 // (lanes trade items at the refill, so the storing lane is in general not the reading lane), and nothing
 // that another wave wrote.  On gfx950 a wave's vector-memory operations are issued in program order and
@@ -1030,11 +1043,24 @@ __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& 
 // the next level is fetched one round trip ahead, so a level costs one round trip.  SSX_RESOLVE_WAYS records of the
 // lane (consecutive k of its pixel) are folded side by side: independent chains.
 #ifndef SSX_RESOLVE_WAYS
-#define SSX_RESOLVE_WAYS 2u // measured: 4 ways spill 13 VGPRs in the path loop (-1.3 %), 3: +2.4 %, 2: +2.7 % (one box, r02t)
+#define SSX_RESOLVE_WAYS SSX_COHORT_KS // measured: 4 ways spill 13 VGPRs in the path loop (-1.3 %), 3: +2.4 %, 2: +2.7 % (one box, r02t)
 #endif
 static_assert(SSX_RESOLVE_WAYS == SSX_COHORT_KS, "a pass of the fold takes one cohort");
-// fs_base / nee_base: index of slot 0 of the unit's logs (rec_base * 9, rec_base * 10)
-template <uint32_t WAYS>
+// a level's next-event term where the level parked a shadow ray, else 0: nee[i] as the flush wrote it (wide queue
+// entries), or vis ? nee : 0 (narrow entries; both loads in flight together)
+template <bool NARROW>
+__device__ __forceinline__ float4 nee_term(const SsxKernelArgs& a, uint32_t i, bool has) {
+	uint32_t v = 1u;
+	float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	if (has) {
+		if (NARROW) v = a.vis[i];
+		c = a.nee[i];
+	}
+	if (!NARROW) return c;
+	return make_float4(v ? c.x : 0.0f, v ? c.y : 0.0f, v ? c.z : 0.0f, v ? c.w : 0.0f);
+}
+// fs_base / nee_base: index of slot 0 of the cohort's logs (base_rec * 9, base_rec * 10)
+template <uint32_t WAYS, bool NARROW>
 __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count, uint32_t fs_base, uint32_t nee_base) {
 	const uint32_t n = (uint32_t)a.n_records;
 	float rad[WAYS][4];
@@ -1055,7 +1081,7 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 			// the last level's radiance: 0 + its emission term (if any) + its next-event term (if it parked a shadow ray)
 			const uint32_t ns = y >> 19;
 			const float4 last = ((y >> 1) & 1u) ? a.direct[dep * n + r0 + s * stride] : zero4;
-			const float4 ne = ns != SSX_NO_SLOT ? a.nee[nee_base + ns] : zero4;
+			const float4 ne = nee_term<NARROW>(a, nee_base + ns, ns != SSX_NO_SLOT);
 			if (dep) K[s] = a.link[fs_base + at[s]];
 			rad[s][0] = last.x + ne.x; rad[s][1] = last.y + ne.y; rad[s][2] = last.z + ne.z; rad[s][3] = last.w + ne.w;
 			top = max(top, dep);
@@ -1071,7 +1097,7 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 				// emission + next-event term, the order of renderer.cpp:171,216 (0 + x == x where a term is absent)
 				const uint32_t ns = (K[s] >> 13) & SSX_NO_SLOT;
 				const bool has_ne = ns != SSX_NO_SLOT;
-				D[s] = has_ne ? a.nee[nee_base + ns] : zero4;
+				D[s] = nee_term<NARROW>(a, nee_base + ns, has_ne);
 				if ((K[s] >> 26) & 1u) { // rare: an emission term below the last level (non-ELS build)
 					const float4 em = a.direct[d * n + r0 + s * stride];
 					D[s] = has_ne ? make_float4(em.x + D[s].x, em.y + D[s].y, em.z + D[s].z, em.w + D[s].w) : em;
@@ -1154,6 +1180,7 @@ __device__ __forceinline__ void unit_setup(const SsxKernelArgs& a, uint32_t unit
 // a separate HBM-bound pass after the kernel could not.  (For scenes with very short paths --
 // plane-srgb: one continued level per sample -- the fold is a large share of the arithmetic and the
 // separate streaming kernel is faster; the host picks, see ssx_api.hip.)
+template <bool NARROW>
 __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, const WorkUnit& u) {
 	// see "Memory-ordering contract" above: wait for this wave's stores, drop the CU's L1 lines
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1161,10 +1188,10 @@ __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, 
 	const uint32_t lane = threadIdx.x & 63u;
 	if ((lane & 7u) < u.tw && (lane >> 3) < u.th)
 		for (uint32_t kq = 0; kq < u.n_kq; kq += SSX_RESOLVE_WAYS)
-			resolve_records<SSX_RESOLVE_WAYS>(L, a, u.rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, u.n_kq - kq), (u.rec_base + kq * 64u) * SSX_MAX_FRAMES, (u.rec_base + kq * 64u) * SSX_MAX_LEVELS); // one cohort per pass
+			resolve_records<SSX_RESOLVE_WAYS, NARROW>(L, a, u.rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, u.n_kq - kq), (u.rec_base + kq * 64u) * SSX_MAX_FRAMES, (u.rec_base + kq * 64u) * SSX_MAX_LEVELS); // one cohort per pass
 }
 
-template <int TOPO>
+template <int TOPO, bool NARROW>
 __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	uint32_t* const lds_words = stage_lds(a);
 	Lds L; L.w = lds_words;
@@ -1180,9 +1207,10 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	bool active = false;
 	uint32_t p_tag = 0; // which of the (at most two) units in flight the lane's sample belongs to, and its cohort there:
 	                    // unit tag | cohort << 1 | (sample's position in the cohort) << 3
-	uint32_t* const log_cnt = lds_words + a.blob_words + 4u * SSX_WAVE_SCRATCH_WORDS + wave * SSX_WAVE_COUNTER_WORDS; // see LogRef
+	constexpr uint32_t queue_words = SSX_QUEUE_ENTRIES * (NARROW ? SSX_QUEUE_WORDS_NARROW : SSX_QUEUE_WORDS_WIDE); // per wave (ssx_blob.h)
+	uint32_t* const log_cnt = lds_words + a.blob_words + 4u * queue_words + wave * SSX_WAVE_COUNTER_WORDS; // see LogRef
 	ShadowQ sq; // this wave's queue behind the blob (16-byte aligned: blob_words is a multiple of 4)
-	sq.e = reinterpret_cast<float4*>(lds_words + a.blob_words + wave * SSX_WAVE_SCRATCH_WORDS);
+	sq.e = reinterpret_cast<float4*>(lds_words + a.blob_words + wave * queue_words);
 	sq.count = 0;
 	// Persistent waves: units are fetched from a global counter, and the next unit's items are handed
 	// out as soon as the current one has none left -- its last paths finish alongside the new ones
@@ -1238,8 +1266,8 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		}
 		if (!__any(active)) {
 			// nothing is running: fold what is pending; stop when nothing is left to hand out either
-			if (sq.count) { shadow_flush<TOPO>(L, a, sq, 0u, sq.count); sq.count = 0; }
-			if (old_pending) { if (a.fuse_resolve) unit_fold(L, a, old); old_pending = false; }
+			if (sq.count) { shadow_flush<TOPO, NARROW>(L, a, sq, 0u, sq.count); sq.count = 0; }
+			if (old_pending) { if (a.fuse_resolve) unit_fold<NARROW>(L, a, old); old_pending = false; }
 			if (!cur_valid && !more) break;
 			continue;
 		}
@@ -1252,7 +1280,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			lg.cnt = log_cnt; lg.group = ((p_tag & 1u) << 2) | ((p_tag >> 1) & 3u);
 			lg.base_rec = (p.rec_index & ~63u) - ((p_tag >> 3) << 6);
 			uint32_t level_word;
-			if (!path_step(L, sq, a, lg, p, hit, pushed, level_word)) {
+			if (!path_step<NARROW>(L, sq, a, lg, p, hit, pushed, level_word)) {
 				// last level reached: lambda_0, the tail word (hit flag, number of continued levels, where the chain of
 				// its levels starts, the last level's own terms: ssx_blob.h) and the final PCG32 state replace the
 				// sample's stream; the fold happens when its unit is complete
@@ -1265,13 +1293,13 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		if (sq.count >= SSX_SQ_FLUSH_AT) { // a full wave of shadow rays
 			const uint32_t take = min(sq.count, 64u);
 			sq.count -= take;
-			shadow_flush<TOPO>(L, a, sq, sq.count, take);
+			shadow_flush<TOPO, NARROW>(L, a, sq, sq.count, take);
 		}
 		// the previous unit's last paths are done: apply the parked shadow rays (some may be its), fold it
 		if (old_pending && !__any(active && (p_tag & 1u) == old_tag)) {
 			if (a.fuse_resolve) {
-				if (sq.count) { shadow_flush<TOPO>(L, a, sq, 0u, sq.count); sq.count = 0; }
-				unit_fold(L, a, old);
+				if (sq.count) { shadow_flush<TOPO, NARROW>(L, a, sq, 0u, sq.count); sq.count = 0; }
+				unit_fold<NARROW>(L, a, old);
 			}
 			old_pending = false;
 		}
@@ -1281,14 +1309,21 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 #ifndef SSX_WAVES_PER_EU
 #define SSX_WAVES_PER_EU 4
 #endif
-// 4 waves per SIMD (128 VGPRs): four 256-lane workgroups per CU with the CIE 1931 tables
-extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SSX_WAVES_PER_EU))) ssx_render_kernel(SsxKernelArgs a) { render_body<0>(a); }
-// the same megakernel with pass 1 specialised to the mesh topology of the reference's Cornell box / plane scene
-extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SSX_WAVES_PER_EU))) ssx_render_kernel_cornell(SsxKernelArgs a) { render_body<1>(a); }
-extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SSX_WAVES_PER_EU))) ssx_render_kernel_plane(SsxKernelArgs a) { render_body<2>(a); }
+// 4 waves per SIMD (128 VGPRs): four 256-lane workgroups per CU where the LDS allows.  One kernel per pass-1 variant
+// (generic / specialised to the mesh topology of the reference's Cornell box / plane scene) and shadow-queue entry
+// size (wide / narrow, ssx_blob.h); the host picks.
+#define SSX_PATH_KERNEL(name, topo, narrow, waves) \
+	extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(waves))) name(SsxKernelArgs a) { render_body<topo, narrow>(a); }
+SSX_PATH_KERNEL(ssx_render_kernel, 0, false, SSX_WAVES_PER_EU)
+SSX_PATH_KERNEL(ssx_render_kernel_cornell, 1, false, SSX_WAVES_PER_EU)
+SSX_PATH_KERNEL(ssx_render_kernel_plane, 2, false, SSX_WAVES_PER_EU)
+SSX_PATH_KERNEL(ssx_render_kernel_nq, 0, true, SSX_WAVES_PER_EU)
+SSX_PATH_KERNEL(ssx_render_kernel_cornell_nq, 1, true, SSX_WAVES_PER_EU)
+SSX_PATH_KERNEL(ssx_render_kernel_plane_nq, 2, true, SSX_WAVES_PER_EU)
 // The generic kernel under another name for the calibration render of ssx_upload_scene (64x64x4 samples), so that
-// kernel traces and statistics of ssx_render_kernel* contain real launches only.
-extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) ssx_calibrate_kernel(SsxKernelArgs a) { render_body<0>(a); }
+// kernel traces and statistics of ssx_render_kernel* contain real launches only.  Narrow queue entries: it stages the
+// whole blob, which may only fit with them.
+SSX_PATH_KERNEL(ssx_calibrate_kernel, 0, true, 3)
 
 // The fold as a pass of its own (one lane per sample, persistent blocks, streaming reads), used
 // instead of the path kernel's tail when SsxKernelArgs::fuse_resolve is 0.
@@ -1308,7 +1343,8 @@ extern "C" __global__ void __launch_bounds__(256) ssx_resolve_kernel(SsxKernelAr
 		const uint32_t n_k = a.k1 - a.k0;
 		const uint32_t rk = (uint32_t)(r >> 6), kk = rk % n_k;
 		const uint32_t base_rec = (rk - (kk % a.group_spp) % SSX_COHORT_KS) * 64u; // first record of r's cohort
-		resolve_records<1u>(L, a, (uint32_t)r, 0u, 1u, base_rec * SSX_MAX_FRAMES, base_rec * SSX_MAX_LEVELS);
+		if (a.queue_words == SSX_QUEUE_WORDS_NARROW) resolve_records<1u, true>(L, a, (uint32_t)r, 0u, 1u, base_rec * SSX_MAX_FRAMES, base_rec * SSX_MAX_LEVELS);
+		else resolve_records<1u, false>(L, a, (uint32_t)r, 0u, 1u, base_rec * SSX_MAX_FRAMES, base_rec * SSX_MAX_LEVELS);
 	}
 }
 

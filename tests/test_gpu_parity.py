@@ -436,3 +436,20 @@ def test_pass1_variants_specialised_for_builtin_topologies_generic_otherwise():
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
                           "bit_exact_against_oracle or config1 or many_units or jakob_hanika_uplift"], env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
     assert out.returncode == 0, out.stdout[-3000:]
+
+
+def test_shadow_queue_layouts_wide_by_default_narrow_when_it_buys_a_workgroup():
+    """The shadow-ray queues have 48-byte entries (the contribution rides along, the flush writes the finished
+    next-event term) unless 32-byte entries (contribution to HBM at park time, visibility byte at flush time)
+    let a fourth workgroup live on a CU: the CIE 2006 tables on the Cornell topology.  Both layouts give the same
+    bits; with SSX_NARROW_QUEUE set a subprocess repeats the oracle comparisons of the default scenes that way."""
+    import subprocess, sys
+    r = Renderer(Options(scene_name="cornell-srgb", res=(8, 8), spp=1, texture="test-img.png"))
+    r.render_start(); r.render_wait()
+    assert r.kernel_info()["max_blocks_per_cu"] == 4 and r.kernel_info()["lds_bytes"] > 32768   # wide
+    r6 = Renderer(Options(scene_name="cornell-srgb", res=(8, 8), spp=1, texture="test-img.png", observer=2006))
+    assert r6.kernel_info()["max_blocks_per_cu"] == 4                                              # narrow buys the fourth
+    env = dict(os.environ, SSX_NARROW_QUEUE="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                          "bit_exact_against_oracle or config1 or many_units or without_explicit"], env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
+    assert out.returncode == 0, out.stdout[-3000:]
