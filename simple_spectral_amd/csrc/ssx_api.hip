@@ -43,7 +43,7 @@ struct ssx_ctx {
 	std::vector<uint8_t*> d_textures;
 	float* d_jh_data = nullptr;
 	bool rgb_mode = false;     // scene uploaded with uplift == SSX_MODE_RGB
-	bool fuse_resolve = true;  // fold inside the path kernel (long paths) or as its own streaming kernel (short paths)
+	bool fuse_resolve = true;  // fold inside the path kernel, or as its own streaming kernel (SSX_FUSE_RESOLVE=0)
 	float calib_frames = 0.0f; // frames per sample measured by the calibration render of ssx_upload_scene
 	double* d_accum = nullptr;  size_t accum_pixels = 0;
 	uint32_t* d_unit_counter = nullptr; // work-unit counter of the path kernel's persistent waves
@@ -554,11 +554,12 @@ int launch_pipelined(ssx_ctx* ctx, LaunchPlan& pl, uint32_t spp, uint32_t batch,
 	return SSX_OK;
 }
 
-// Where the fold runs is a pure performance choice (same arithmetic, same bits): inside the path
-// kernel its loads hide under other waves' arithmetic (Cornell: 49.4 against 52.6 ms), but its own
-// arithmetic adds to a VALU-bound kernel, which loses when paths are so short that the fold is a
-// large share of the work (plane-srgb: one continued level per sample, 5.0 against 5.5 Gsamples/s).  A
-// 64x64x4-sample render of the scene at upload time counts the continued levels per sample and decides.
+// A 64x64x4-sample render of the scene at upload time counts the continued levels per sample (plan_info: what the
+// benchmark prices the algorithmic HBM bytes with).  It used to decide where the fold runs -- inside the path kernel,
+// where its loads hide under other waves' arithmetic, or as a streaming kernel of its own, which won for very short
+// paths (plane-srgb) while the levels lived in [level][record] arrays.  With the levels in per-cohort logs the fold
+// inside the path kernel wins there too (plane-srgb 1024^2 spp 1024: 9.91 against 9.68 Gsamples/s), so it is the
+// rule; SSX_FUSE_RESOLVE=0 selects the separate kernel (same arithmetic, same bits: the tests run both).
 int calibrate(ssx_ctx* ctx) {
 	ssx_render_params cp{};
 	cp.struct_size = sizeof cp; cp.width = 64; cp.height = 64; cp.spp = 4; cp.tile_stride = 1;
@@ -577,7 +578,8 @@ int calibrate(ssx_ctx* ctx) {
 	uint64_t frames = 0;
 	for (const uint4& r : recs) frames += (r.y >> 2) & 0xFu;
 	ctx->calib_frames = (float)((double)frames / (double)recs.size());
-	ctx->fuse_resolve = ctx->calib_frames >= 2.0f;
+	ctx->fuse_resolve = true;
+	if (const char* e = getenv("SSX_FUSE_RESOLVE")) ctx->fuse_resolve = e[0] != '0';
 	return SSX_OK;
 }
 

@@ -1177,9 +1177,7 @@ __device__ __forceinline__ void unit_setup(const SsxKernelArgs& a, uint32_t unit
 }
 // Every lane folds the records of its own pixel of a finished unit.  The loads (levels and records
 // this wave wrote during the unit) overlap with the arithmetic of the other waves on the SIMD, which
-// a separate HBM-bound pass after the kernel could not.  (For scenes with very short paths --
-// plane-srgb: one continued level per sample -- the fold is a large share of the arithmetic and the
-// separate streaming kernel is faster; the host picks, see ssx_api.hip.)
+// a separate HBM-bound pass after the kernel could not (ssx_resolve_kernel: kept as an option, SSX_FUSE_RESOLVE=0).
 template <bool NARROW>
 __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, const WorkUnit& u) {
 	// see "Memory-ordering contract" above: wait for this wave's stores, drop the CU's L1 lines

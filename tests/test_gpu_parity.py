@@ -377,17 +377,22 @@ def test_rgb_render_mode_bit_exact(scene, texture, W, H, spp, io, els):
         assert not np.array_equal(bits(spectral), bits(ref))
 
 
-def test_fold_placement_is_calibrated_and_does_not_change_the_image():
-    """ssx_upload_scene renders 64x64x4 samples of the scene to count frames per sample and puts the
-    fold of the recursion inside the path kernel (long paths) or in its own kernel (short paths).
-    Both are covered bit-exactly by the parity tests above (Cornell scenes: path kernel; plane-srgb:
-    resolve kernel); here the choice itself."""
+def test_fold_placement_does_not_change_the_image():
+    """ssx_upload_scene renders 64x64x4 samples of the scene to count the continued levels per sample.  The fold
+    of the recursion runs inside the path kernel (every test above); with SSX_FUSE_RESOLVE=0 it is the streaming
+    kernel of its own: a subprocess repeats the oracle comparisons that way."""
+    import subprocess, sys
     r = Renderer(Options(scene_name="cornell-srgb", res=(16, 16), spp=1, texture="test-img.png"))
     info = r.plan_info()
     assert info["fold"] == "path kernel" and 3.0 < info["frames_per_sample"] < 4.5      # interactions per sample - 1
     r = Renderer(Options(scene_name="plane-srgb", res=(16, 16), spp=1, texture="test-img.png"))
     info = r.plan_info()
-    assert info["fold"] == "resolve kernel" and 0.8 < info["frames_per_sample"] <= 1.0   # S = 2 where the plane is hit: one continued level
+    assert info["fold"] == "path kernel" and 0.8 < info["frames_per_sample"] <= 1.0      # S = 2 where the plane is hit: one continued level
+    for extra in ({}, {"SSX_NARROW_QUEUE": "1"}):
+        env = dict(os.environ, SSX_FUSE_RESOLVE="0", **extra)
+        out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                              "bit_exact_against_oracle or config1 or launch_chunking"], env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
+        assert out.returncode == 0, out.stdout[-3000:]
 
 
 def test_many_units_per_wave_parity_and_determinism():
