@@ -13,7 +13,9 @@ for seed in range(1, 13):
     scene = ("cornell-srgb", "cornell", "plane-srgb")[seed % 3]
     W, H = int(rng.integers(40, 600)), int(rng.integers(40, 600))
     spp = int(rng.integers(3, 40))
-    cases.append((scene, W, H, spp, seed, dict(observer=2006) if seed % 4 == 0 else {}))
+    kw = dict(observer=2006) if seed % 4 == 0 else {}
+    if seed % 3 == 1: kw["spp_per_launch"] = int(rng.integers(1, spp + 1))   # odd launch sizes: partial units and cohorts
+    cases.append((scene, W, H, spp, seed, kw))
 oracles = {}
 for scene, W, H, spp, seed, kw in cases:
     tex = None if scene == "cornell" else "crystal-lizard-512.png"
@@ -22,7 +24,7 @@ for scene, W, H, spp, seed, kw in cases:
     key = (scene, kw.get("observer", 1931))
     if key not in oracles: oracles[key] = ol.Oracle(scene, texture=tex, observer=key[1])
     t = time.time()
-    ref = oracles[key].render(W, H, spp, seed=seed)
+    ref = oracles[key].render(W, H, spp, seed=seed, nthreads=min(16, os.cpu_count() or 1))
     d = int((bits(r.xyza) != bits(ref)).sum()); bad += d; total += W * H * spp
     print("%-13s %4dx%-4d spp %3d seed %2d %-18s differing floats: %d (oracle %.1f s)" % (scene, W, H, spp, seed, kw, d, time.time() - t), flush=True)
 print("samples checked: %.1f M, differing floats: %d" % (total / 1e6, bad))
