@@ -145,15 +145,15 @@ struct Hero { float v[4]; };
 struct HeroIndex { int c[4]; float frac[4]; };
 __device__ __forceinline__ HeroIndex hero_index(const SsxBlobHeader& hd, const SsxBlobSpectrum sp, float lambda_0) {
 	HeroIndex h;
-	const int n = (int)sp.n;
+	const float nf = (float)sp.n; // table sizes are far below 2^24
 #pragma unroll
 	for (int i = 0; i < 4; ++i) {
 		float lambda = lambda_0 + hd.lambda_steps[i];
 		float x = (lambda - sp.low) * sp.delta_recip;
 		float i0f = __builtin_floorf(x);
 		h.frac[i] = x - i0f;
-		int i0 = (int)i0f; // v_cvt_i32_f32 saturates; lambda stays within a few steps of the tables anyway
-		h.c[i] = min(max(i0, -2), n);
+		// clamp(i0, -2, n) on the integer-valued float (one v_med3_f32 instead of an integer max and min), then convert
+		h.c[i] = (int)__builtin_amdgcn_fmed3f(i0f, -2.0f, nf);
 	}
 	return h;
 }
@@ -420,27 +420,27 @@ struct RaySetup { // per-ray constants of the watertight test (geometry.cpp:17-3
 	float Sx, Sy, Sz;
 	uint32_t perm;       // 2*kz + swapped
 };
-__device__ __forceinline__ float comp(V3 v, uint32_t k) { return k == 0u ? v.x : (k == 1u ? v.y : v.z); }
 
 __device__ __forceinline__ RaySetup ray_setup(V3 orig, V3 dir) {
-	float ax = __builtin_fabsf(dir.x), ay = __builtin_fabsf(dir.y), az = __builtin_fabsf(dir.z);
-	uint32_t kx, ky, kz;
-	if (ax > ay) {
-		if (ax > az) { kz = 0; kx = 1; ky = 2; } else { kz = 2; kx = 0; ky = 1; }
-	} else {
-		if (ay > az) { kz = 1; kx = 2; ky = 0; } else { kz = 2; kx = 0; ky = 1; }
-	}
-	uint32_t swapped = comp(dir, kz) < 0 ? 1u : 0u;
-	if (swapped) { uint32_t t = kx; kx = ky; ky = t; }
+	// geometry.cpp:19-32 as selects on three compare masks (a select costs what an FMA costs: the nested-if form of the
+	// reference compiles to 23 of them; this to 17)
+	const float ax = __builtin_fabsf(dir.x), ay = __builtin_fabsf(dir.y), az = __builtin_fabsf(dir.z);
+	const bool xy = ax > ay;
+	const bool k0 = xy && ax > az;       // kz = 0, (kx, ky) = (1, 2)
+	const bool k1 = !xy && ay > az;      // kz = 1, (kx, ky) = (2, 0); otherwise kz = 2, (kx, ky) = (0, 1)
+	const float dkz = k0 ? dir.x : (k1 ? dir.y : dir.z);
+	const float da = k0 ? dir.y : (k1 ? dir.z : dir.x), db = k0 ? dir.z : (k1 ? dir.x : dir.y);
+	const float oa = k0 ? orig.y : (k1 ? orig.z : orig.x), ob = k0 ? orig.z : (k1 ? orig.x : orig.y);
+	const bool swapped = dkz < 0; // :32: kx and ky trade places
 	RaySetup rs;
-	float dkz = comp(dir, kz);
 	// three IEEE divisions by one divisor: one binary64 reciprocal, one multiply each (exact: ssx_exact.h)
 	const double dkz_recip = ssx_exact::div64_rcp_any(dkz);
-	rs.Sx = ssx_exact::div64_by(comp(dir, kx), dkz_recip);
-	rs.Sy = ssx_exact::div64_by(comp(dir, ky), dkz_recip);
+	rs.Sx = ssx_exact::div64_by(swapped ? db : da, dkz_recip);
+	rs.Sy = ssx_exact::div64_by(swapped ? da : db, dkz_recip);
 	rs.Sz = ssx_exact::div64_by(1.0f, dkz_recip);
-	rs.okx = comp(orig, kx); rs.oky = comp(orig, ky); rs.okz = comp(orig, kz);
-	rs.perm = 2u * kz + swapped;
+	rs.okx = swapped ? ob : oa; rs.oky = swapped ? oa : ob;
+	rs.okz = k0 ? orig.x : (k1 ? orig.y : orig.z);
+	rs.perm = (k0 ? 0u : (k1 ? 2u : 4u)) + (swapped ? 1u : 0u); // 2*kz + swapped
 	return rs;
 }
 

@@ -133,10 +133,13 @@ def main():
         if op.startswith("v_div_fixup"):
             per_func[f]["div"] += 1
             total["div"] += 1
+        if op.startswith(("v_cndmask", "v_cmp", "v_min", "v_max", "v_med3")):   # the 4.3-cycle select/compare kind
+            per_func[f]["sel"] += 1
+            total["sel"] += 1
         total[c] += 1
         total["all"] += 1
         per_line[(os.path.basename(files.get(cur[0], "?")), cur[1])] += 1
-    cols = ("all", "valu", "f64", "trans", "salu", "lds", "vmem", "div")
+    cols = ("all", "valu", "f64", "trans", "salu", "lds", "vmem", "div", "sel")
     print("%-28s" % args.kernel + "".join("%8s" % c for c in cols))
     for f, cnt in sorted(per_func.items(), key=lambda kv: -kv[1]["all"]):
         print("%-28s" % f[:28] + "".join("%8d" % cnt[c] for c in cols))
