@@ -568,10 +568,11 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		float U = B.y * C.x - B.x * C.y;
 		float V = C.y * A.x - C.x * A.y;
 		float W = A.y * B.x - A.x * B.y;
-		if (U != 0.0f && V != 0.0f && W != 0.0f) {
-			// geometry.cpp:55-56 (pass 1 is only a conservative filter, so the exact test is here)
-			if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) continue;
-		} else {
+		// geometry.cpp:55-67.  With U, V, W all nonzero the reference rejects a triangle of mixed signs (:55-56): pass 1
+		// has tested exactly that on these same floats (same operands, same operations; a shared edge evaluated the other
+		// way round is the exact negative) and a candidate is a triangle that passed, so nothing is left to test here.
+		// With a zero among them the reference decides on the binary64 values (:57-67), which pass 1 does not look at:
+		if (U == 0.0f || V == 0.0f || W == 0.0f) {
 			double Ud = (double)B.y * (double)C.x - (double)B.x * (double)C.y;
 			double Vd = (double)C.y * (double)A.x - (double)C.x * (double)A.y;
 			double Wd = (double)A.y * (double)B.x - (double)A.x * (double)B.y;
