@@ -9,7 +9,8 @@ def bits(a): return np.ascontiguousarray(a, np.float32).view(np.uint32)
 bad = 0; total = 0
 rng = np.random.default_rng(2026)
 cases = []
-for seed in range(1, 13):
+N_CASES = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+for seed in range(1, N_CASES + 1):
     scene = ("cornell-srgb", "cornell", "plane-srgb")[seed % 3]
     W, H = int(rng.integers(40, 600)), int(rng.integers(40, 600))
     spp = int(rng.integers(3, 40))
