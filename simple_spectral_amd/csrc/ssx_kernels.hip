@@ -1221,6 +1221,30 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	uint32_t cur_tag = 0, old_tag = 0;
 	uint32_t next_item = 0; // wave-uniform
 	for (;;) {
+		// One iteration: (1) one interaction of every running path; (2) hand the lanes that fell idle their next samples --
+		// before (3), so that the loads of the new camera rays are in flight during the shadow flush; (3) flush / fold.
+		const bool running = __any(active);
+		if (running) {
+			bool pushed = false;
+			HitInfo hit; // the primary rays of all lanes: traced in uniform control flow
+			if (active) SSX_STAT(13); // lanes with a path, per iteration
+			trace<TOPO>(L, p.orig, p.dir, p.ignore, active, hit, 0);
+			if (active) {
+				LogRef lg;
+				lg.cnt = log_cnt; lg.group = ((p_tag & 1u) << 2) | ((p_tag >> 1) & 3u);
+				lg.base_rec = (p.rec_index & ~63u) - ((p_tag >> 3) << 6);
+				uint32_t level_word;
+				if (!path_step<NARROW>(L, sq, a, lg, p, hit, pushed, level_word)) {
+					// last level reached: lambda_0, the tail word (hit flag, number of continued levels, where the chain of
+					// its levels starts, the last level's own terms: ssx_blob.h) and the final PCG32 state replace the
+					// sample's stream; the fold happens when its unit is complete
+					const uint32_t tail = (p.hit_anything ? 1u : 0u) | ((level_word >> 26) << 1) | (p.depth << 2) | (p.prev_slot << 6) | ((level_word >> 13) << 19);
+					a.st[p.rec_index] = make_uint4(__float_as_uint(p.lambda_0), tail, (uint32_t)p.rng.state, (uint32_t)(p.rng.state >> 32));
+					active = false;
+				}
+			}
+			sq.count += (uint32_t)__popcll(__ballot(pushed));
+		}
 		// rotate: the current unit has no items left and the previous one is folded
 		if (cur_valid && next_item >= cur.n_items && !old_pending) {
 			old = cur; old_tag = cur_tag; old_pending = true;
@@ -1263,33 +1287,12 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			}
 			next_item = min(cur.n_items, next_item + (uint32_t)__popcll(idle));
 		}
-		const bool running = __any(active);
-		if (running) {
-			bool pushed = false;
-			HitInfo hit; // the primary rays of all lanes: traced in uniform control flow
-			if (active) SSX_STAT(13); // lanes with a path, per iteration
-			trace<TOPO>(L, p.orig, p.dir, p.ignore, active, hit, 0);
-			if (active) {
-				LogRef lg;
-				lg.cnt = log_cnt; lg.group = ((p_tag & 1u) << 2) | ((p_tag >> 1) & 3u);
-				lg.base_rec = (p.rec_index & ~63u) - ((p_tag >> 3) << 6);
-				uint32_t level_word;
-				if (!path_step<NARROW>(L, sq, a, lg, p, hit, pushed, level_word)) {
-					// last level reached: lambda_0, the tail word (hit flag, number of continued levels, where the chain of
-					// its levels starts, the last level's own terms: ssx_blob.h) and the final PCG32 state replace the
-					// sample's stream; the fold happens when its unit is complete
-					const uint32_t tail = (p.hit_anything ? 1u : 0u) | ((level_word >> 26) << 1) | (p.depth << 2) | (p.prev_slot << 6) | ((level_word >> 13) << 19);
-					a.st[p.rec_index] = make_uint4(__float_as_uint(p.lambda_0), tail, (uint32_t)p.rng.state, (uint32_t)(p.rng.state >> 32));
-					active = false;
-				}
-			}
-			sq.count += (uint32_t)__popcll(__ballot(pushed));
-		}
+		const bool busy = __any(active);
 		// The parked shadow rays are traced a full wave at a time; all of them when the previous unit's last paths are
 		// done (some may be its: they must be in before its fold) or when nothing is running at all.  One call site:
 		// a flush inlines a whole trace.
 		const bool fold_old = old_pending && !__any(active && (p_tag & 1u) == old_tag);
-		const bool drain = (fold_old && a.fuse_resolve) || !running;
+		const bool drain = (fold_old && a.fuse_resolve) || !busy;
 		while (sq.count >= SSX_SQ_FLUSH_AT || (drain && sq.count)) {
 			const uint32_t take = min(sq.count, 64u);
 			sq.count -= take;
@@ -1299,7 +1302,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			if (a.fuse_resolve) unit_fold<NARROW>(L, a, old);
 			old_pending = false;
 		}
-		if (!running && !cur_valid && !more) break; // nothing runs, nothing left to hand out
+		if (!busy && !cur_valid && !more) break; // nothing runs, nothing left to hand out
 	}
 }
 
