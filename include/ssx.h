@@ -204,16 +204,20 @@ int ssx_get_timing(ssx_ctx* ctx, float stage_ms[4]);
 /* Introspection: ABI version, and per-kernel resource usage for reports. */
 int ssx_abi_version(void);
 int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* scratch_bytes, int* max_blocks_per_cu);
-/* What ssx_upload_scene's calibration render (64x64x4 samples of the scene, fixed seed) found and
- * chose: frames (continued interactions) per sample, and whether the fold of the recursion runs at
- * the end of each wave's unit inside the path kernel (1) or as a streaming kernel of its own (0).
- * A performance choice only: both give the same bits. */
+/* What ssx_upload_scene's calibration render (64x64x4 samples of the scene, fixed seed) found: frames
+ * (continued interactions) per sample; and whether the fold of the recursion runs at the end of each
+ * wave's unit inside the path kernel (1: the rule) or as a streaming kernel of its own (0: with
+ * SSX_FUSE_RESOLVE=0 in the environment at upload).  A performance choice only: both give the same bits. */
 int ssx_plan_info(ssx_ctx* ctx, float* frames_per_sample, int* fold_in_path_kernel);
 /* Which path kernel the uploaded scene runs: 0 = the generic one (pass 1 of the intersection loops over the
  * quads), 1 / 2 = the kernel whose pass 1 is specialised to the mesh topology of the reference's Cornell box /
  * plane scene (the scene's quad corners coincide in exactly that pattern; positions are free).  A performance
  * choice only: same bits.  The environment variable SSX_GENERIC_KERNEL forces 0 at upload.  -1: no scene. */
 int ssx_kernel_variant(ssx_ctx* ctx);
+/* The name of the path kernel the context launches for the uploaded scene, as a profiler lists it
+ * ("ssx_render_kernel", "..._cornell", "..._plane", each also with "_nq": the variants with narrow shadow-ray
+ * queue entries, taken where they let one more workgroup live on a CU).  NULL: no scene. */
+const char* ssx_kernel_name(ssx_ctx* ctx);
 
 /* ---- Diagnostics for the parity tests (not part of the reference's interface) ---------------------
  * ssx_debug_eval runs one building block of the path kernel -- the same device function the kernel

@@ -1009,6 +1009,16 @@ int ssx_lanestat(unsigned long long* out, int reset) {
 
 int ssx_kernel_variant(ssx_ctx* ctx) { return (ctx && ctx->have_scene) ? (int)ctx->topology : -1; }
 
+const char* ssx_kernel_name(ssx_ctx* ctx) {
+	if (!ctx || !ctx->have_scene) return nullptr;
+	if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+	uint32_t qw = 0;
+	if (pick_queue(ctx, ctx->topology, ctx->path_blob_words, &qw, nullptr) != SSX_OK) return nullptr;
+	static const char* const names[3][2] = { { "ssx_render_kernel", "ssx_render_kernel_nq" }, { "ssx_render_kernel_cornell", "ssx_render_kernel_cornell_nq" },
+	                                         { "ssx_render_kernel_plane", "ssx_render_kernel_plane_nq" } };
+	return names[ctx->topology < 3u ? ctx->topology : 0u][qw == SSX_QUEUE_WORDS_NARROW ? 1 : 0];
+}
+
 int ssx_plan_info(ssx_ctx* ctx, float* frames_per_sample, int* fold_in_path_kernel) {
 	if (!ctx) return SSX_ERR_ARG;
 	if (!ctx->have_scene) return fail(ctx, SSX_ERR_STATE, "no scene uploaded");

@@ -247,7 +247,9 @@ class Renderer:
         f, k = C.c_float(), C.c_int()
         self._check(self._lib.ssx_plan_info(self._ctx, C.byref(f), C.byref(k)))
         variant = {0: "generic", 1: "cornell topology", 2: "plane topology"}.get(self._lib.ssx_kernel_variant(self._ctx), "?")
-        return {"frames_per_sample": round(f.value, 3), "fold": "path kernel" if k.value else "resolve kernel", "pass1": variant}
+        name = self._lib.ssx_kernel_name(self._ctx)
+        return {"frames_per_sample": round(f.value, 3), "fold": "path kernel" if k.value else "resolve kernel", "pass1": variant,
+                "kernel": name.decode() if name else None}
 
     def save(self, path):
         fb = np.ascontiguousarray(self.framebuffer, dtype=np.float32)

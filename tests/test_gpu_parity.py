@@ -452,8 +452,10 @@ def test_shadow_queue_layouts_wide_by_default_narrow_when_it_buys_a_workgroup():
     r = Renderer(Options(scene_name="cornell-srgb", res=(8, 8), spp=1, texture="test-img.png"))
     r.render_start(); r.render_wait()
     assert r.kernel_info()["max_blocks_per_cu"] == 4 and r.kernel_info()["lds_bytes"] > 32768   # wide
+    assert r.plan_info()["kernel"] == "ssx_render_kernel_cornell"
     r6 = Renderer(Options(scene_name="cornell-srgb", res=(8, 8), spp=1, texture="test-img.png", observer=2006))
     assert r6.kernel_info()["max_blocks_per_cu"] == 4                                              # narrow buys the fourth
+    assert r6.plan_info()["kernel"] == "ssx_render_kernel_cornell_nq"
     env = dict(os.environ, SSX_NARROW_QUEUE="1")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
                           "bit_exact_against_oracle or config1 or many_units or without_explicit"], env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
