@@ -430,10 +430,12 @@ Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1, u
 	// rec_off = 0, or the first record of the second half of a double-buffered allocation: each half is a
 	// region of its own (capacity = records of a full batch >= this batch)
 	bind_arrays(a, ctx->d_samples + rec_off * kBytesPerSampleInFlight, rec_off ? rec_off : a.n_records);
-	// 8 samples per pixel and unit (512 items: enough for the refill, and short units balance the end of
-	// the launch; measured best of 1..64 with persistent waves) unless the launch is so small that this
-	// would leave SIMDs without a wave (3 waves x 1024 SIMDs)
-	uint32_t g = SSX_MAX_UNIT_KS;
+	// Samples per pixel and unit.  Long paths (Cornell: 4 continued levels per sample) run best with 4 -- 256 items keep the
+	// refill busy, less of a unit's logs is in flight per wave, and short units balance the end of the launch: 3052 against
+	// 3016 Msamples/s with 8, 3031 with 2, 2899 with 16 (one box) --, short ones (plane-srgb: 1 level) with 8: 10.07 against
+	// 9.89 Gsamples/s.  Halved while the launch is so small that SIMDs would be left without a wave (3 waves x 1024 SIMDs).
+	uint32_t g = ctx->calib_frames >= 2.0f ? SSX_MAX_UNIT_KS / 2u : SSX_MAX_UNIT_KS;
+	if (const char* e = getenv("SSX_UNIT_SPP")) { const int v = atoi(e); if (v >= 1 && v <= (int)SSX_MAX_UNIT_KS) g = (uint32_t)v; } // A/B runs
 	while (g > 1u && (uint64_t)((n_k + g - 1u) / g) * a.my_tiles < kMinUnits) g >>= 1;
 	a.group_spp = g;
 	if (a.group_spp > n_k) a.group_spp = n_k;

@@ -117,8 +117,11 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 #ifndef SSX_COHORT_KS
 #define SSX_COHORT_KS 2u          // samples per pixel in a cohort: 128 records, 13-bit slots (10 * 128 < SSX_NO_SLOT)
 #endif
-#define SSX_MAX_UNIT_KS 8u        // samples per pixel in a work unit: four cohorts (the counters below)
-#define SSX_WAVE_COUNTER_WORDS 16u // per wave, behind the shadow-ray queues: fill counts [unit tag 2][cohort 4][fs, nee]
+#ifndef SSX_MAX_UNIT_KS
+#define SSX_MAX_UNIT_KS 8u        // most samples per pixel in a work unit: four cohorts (the host picks 4 or 8 per scene, make_batch)
+#endif
+#define SSX_UNIT_COHORTS (SSX_MAX_UNIT_KS / SSX_COHORT_KS)  // a power of two
+#define SSX_WAVE_COUNTER_WORDS (4u * SSX_UNIT_COHORTS) // per wave, behind the shadow-ray queues: fill counts [unit tag 2][cohort][fs, nee]
 #define SSX_BYTES_PER_SAMPLE (16u + 16u + (2u * 16u + 1u) * SSX_MAX_LEVELS + (16u + 8u + 4u) * SSX_MAX_FRAMES + 6u) // 6: keeps the arrays 16-byte aligned
 
 struct SsxKernelArgs {

@@ -799,7 +799,7 @@ struct Path {
 // slot with one LDS atomic (the order of the slots within one wave iteration is immaterial).
 struct LogRef {
 	uint32_t* cnt;      // this wave's 16 counters
-	uint32_t group;     // the lane's counter pair: 4 * unit tag + cohort
+	uint32_t group;     // the lane's counter pair: SSX_UNIT_COHORTS * unit tag + cohort
 	uint32_t base_rec;  // first record of the lane's cohort: its logs start at base_rec * 9 (fs, np, link) / base_rec * 10 (nee)
 };
 __device__ __forceinline__ uint32_t log_append(const LogRef& lg, uint32_t which) {
@@ -1205,7 +1205,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	p.rng.state = 0; p.rng.inc = 1;
 	bool active = false;
 	uint32_t p_tag = 0; // which of the (at most two) units in flight the lane's sample belongs to, and its cohort there:
-	                    // unit tag | cohort << 1 | (sample's position in the cohort) << 3
+	                    // unit tag | cohort << 1 | (sample's position in the cohort) << 8
 	constexpr uint32_t queue_words = SSX_QUEUE_ENTRIES * (NARROW ? SSX_QUEUE_WORDS_NARROW : SSX_QUEUE_WORDS_WIDE); // per wave (ssx_blob.h)
 	uint32_t* const log_cnt = lds_words + a.blob_words + 4u * queue_words + wave * SSX_WAVE_COUNTER_WORDS; // see LogRef
 	ShadowQ sq; // this wave's queue behind the blob (16-byte aligned: blob_words is a multiple of 4)
@@ -1231,8 +1231,8 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			trace<TOPO>(L, p.orig, p.dir, p.ignore, active, hit, 0);
 			if (active) {
 				LogRef lg;
-				lg.cnt = log_cnt; lg.group = ((p_tag & 1u) << 2) | ((p_tag >> 1) & 3u);
-				lg.base_rec = (p.rec_index & ~63u) - ((p_tag >> 3) << 6);
+				lg.cnt = log_cnt; lg.group = (p_tag & 1u) * SSX_UNIT_COHORTS + ((p_tag >> 1) & (SSX_UNIT_COHORTS - 1u));
+				lg.base_rec = (p.rec_index & ~63u) - ((p_tag >> 8) << 6);
 				uint32_t level_word;
 				if (!path_step<NARROW>(L, sq, a, lg, p, hit, pushed, level_word)) {
 					// last level reached: lambda_0, the tail word (hit flag, number of continued levels, where the chain of
@@ -1256,7 +1256,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
 			if (u < total_units) {
 				unit_setup(a, u, cur); cur_tag ^= 1u; next_item = 0; cur_valid = true;
-				if (lane < 8u) log_cnt[8u * cur_tag + lane] = 0u; // the logs of its cohorts are empty (the last unit with this tag has been folded)
+				if (lane < 2u * SSX_UNIT_COHORTS) log_cnt[2u * SSX_UNIT_COHORTS * cur_tag + lane] = 0u; // the logs of its cohorts are empty (the last unit with this tag has been folded)
 			}
 			else more = false;
 		}
@@ -1281,7 +1281,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 					p.depth = 0;
 					p.prev_slot = SSX_NO_SLOT;
 					p.hit_anything = false;
-					p_tag = cur_tag | ((kq / SSX_COHORT_KS) << 1) | ((kq % SSX_COHORT_KS) << 3);
+					p_tag = cur_tag | ((kq / SSX_COHORT_KS) << 1) | ((kq % SSX_COHORT_KS) << 8);
 					active = true;
 				}
 			}
