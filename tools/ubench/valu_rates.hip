@@ -82,6 +82,47 @@ KERNEL(k_pk_add_f32, D8, OP1("v_pk_add_f32"), SINKD)
 KERNEL(k_pk_fma_f32, D8, OP3("v_pk_fma_f32"), SINKD)
 KERNEL(k_lshl_b64, D8, asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a0)); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a1)); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a2)); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a3)); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a4)); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a5)); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a6)); asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(a7));, SINKD)
 
+
+// round 2 additions: which three-operand forms are cheap when one operand is a constant
+#define OPA(txt) asm volatile(txt : "+v"(a0) : "v"(b)); asm volatile(txt : "+v"(a1) : "v"(b)); asm volatile(txt : "+v"(a2) : "v"(b)); asm volatile(txt : "+v"(a3) : "v"(b)); asm volatile(txt : "+v"(a4) : "v"(b)); asm volatile(txt : "+v"(a5) : "v"(b)); asm volatile(txt : "+v"(a6) : "v"(b)); asm volatile(txt : "+v"(a7) : "v"(b));
+KERNEL(k_fma_inl0, F8, OPA("v_fma_f32 %0, %0, %1, 0"), SINKF)
+KERNEL(k_fmaak_lit, F8, OPA("v_fmaak_f32 %0, %0, %1, 0x3f800001"), SINKF)
+KERNEL(k_fmaak_0, F8, OPA("v_fmaak_f32 %0, %0, %1, 0x0"), SINKF)
+KERNEL(k_alignbit_inl, F8, OPA("v_alignbit_b32 %0, %0, %1, 31"), SINKF)
+KERNEL(k_alignbit_v, F8, OPA("v_alignbit_b32 %0, %0, %1, %1"), SINKF)
+KERNEL(k_mul_u24, F8, OPA("v_mul_u32_u24 %0, %0, %1"), SINKF)
+KERNEL(k_lshl_add, F8, OPA("v_lshl_add_u32 %0, %0, 2, %1"), SINKF)
+KERNEL(k_bfe, F8, OPA("v_bfe_u32 %0, %0, 3, 8"), SINKF)
+KERNEL(k_and_or, F8, OPA("v_and_or_b32 %0, %0, %1, %1"), SINKF)
+KERNEL(k_cndmask_vcc, F8; asm volatile("s_mov_b64 vcc, 0x5555" ::: "vcc"), OPA("v_cndmask_b32_e32 %0, %0, %1, vcc"), SINKF)
+KERNEL(k_med3_inl, F8, OPA("v_med3_f32 %0, %0, -1.0, 1.0"), SINKF)
+KERNEL(k_min3_inl, F8, OPA("v_min3_f32 %0, %0, %1, 1.0"), SINKF)
+KERNEL(k_sub_u32, F8, OPA("v_sub_u32 %0, %0, %1"), SINKF)
+KERNEL(k_lshr_b32, F8, OPA("v_lshrrev_b32 %0, 3, %0"), SINKF)
+KERNEL(k_mov_b32, F8, OPA("v_mov_b32 %0, %1"), SINKF)
+KERNEL(k_fma_f64_inl, D8, OPA("v_fma_f64 %0, %0, %1, 1.0"), SINKD)
+#define OPCV(txt) asm volatile(txt : "+v"(a0) : "v"(d0)); asm volatile(txt : "+v"(a1) : "v"(d0)); asm volatile(txt : "+v"(a2) : "v"(d0)); asm volatile(txt : "+v"(a3) : "v"(d0)); asm volatile(txt : "+v"(a4) : "v"(d0)); asm volatile(txt : "+v"(a5) : "v"(d0)); asm volatile(txt : "+v"(a6) : "v"(d0)); asm volatile(txt : "+v"(a7) : "v"(d0));
+KERNEL(k_cvt_f32_f64, F8; double d0 = seed * 3.0 + threadIdx.x, OPCV("v_cvt_f32_f64 %0, %1"), SINKF)
+#define OPCW(txt) asm volatile(txt : "+v"(a0) : "v"(f0)); asm volatile(txt : "+v"(a1) : "v"(f0)); asm volatile(txt : "+v"(a2) : "v"(f0)); asm volatile(txt : "+v"(a3) : "v"(f0)); asm volatile(txt : "+v"(a4) : "v"(f0)); asm volatile(txt : "+v"(a5) : "v"(f0)); asm volatile(txt : "+v"(a6) : "v"(f0)); asm volatile(txt : "+v"(a7) : "v"(f0));
+KERNEL(k_cvt_f64_f32, D8; float f0 = seed * 3.0f + threadIdx.x, OPCW("v_cvt_f64_f32 %0, %1"), SINKD)
+
+// one compare, several selects on its VCC (a binary64 select is two; hero selects are four)
+#define OPCS2(A, B) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_cndmask_b32_e32 %1, %1, %2, vcc" : "+v"(A), "+v"(B) : "v"(b) : "vcc");
+KERNEL(k_cmp_sel2, F8, OPCS2(a0, a1) OPCS2(a2, a3) OPCS2(a4, a5) OPCS2(a6, a7) OPCS2(a0, a1) OPCS2(a2, a3) OPCS2(a4, a5) OPCS2(a6, a7), SINKF)
+#define OPCS4(A, B, C, D) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %4\n\tv_cndmask_b32_e32 %0, %0, %4, vcc\n\tv_cndmask_b32_e32 %1, %1, %4, vcc\n\tv_cndmask_b32_e32 %2, %2, %4, vcc\n\tv_cndmask_b32_e32 %3, %3, %4, vcc" : "+v"(A), "+v"(B), "+v"(C), "+v"(D) : "v"(b) : "vcc");
+KERNEL(k_cmp_sel4, F8, OPCS4(a0, a1, a2, a3) OPCS4(a4, a5, a6, a7) OPCS4(a0, a1, a2, a3) OPCS4(a4, a5, a6, a7) OPCS4(a0, a1, a2, a3) OPCS4(a4, a5, a6, a7) OPCS4(a0, a1, a2, a3) OPCS4(a4, a5, a6, a7), SINKF)
+// the same selects through an SGPR pair instead of VCC
+#define OPCS4S(A, B, C, D) asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %4\n\tv_cndmask_b32_e64 %0, %0, %4, s[20:21]\n\tv_cndmask_b32_e64 %1, %1, %4, s[20:21]\n\tv_cndmask_b32_e64 %2, %2, %4, s[20:21]\n\tv_cndmask_b32_e64 %3, %3, %4, s[20:21]" : "+v"(A), "+v"(B), "+v"(C), "+v"(D) : "v"(b) : "s20", "s21");
+KERNEL(k_cmp_sel4s, F8, OPCS4S(a0, a1, a2, a3) OPCS4S(a4, a5, a6, a7) OPCS4S(a0, a1, a2, a3) OPCS4S(a4, a5, a6, a7) OPCS4S(a0, a1, a2, a3) OPCS4S(a4, a5, a6, a7) OPCS4S(a0, a1, a2, a3) OPCS4S(a4, a5, a6, a7), SINKF)
+
+// ... VOP3 encoding of the same selects on VCC; and VOP2 selects separated by independent arithmetic
+#define OPCS4E(A, B, C, D) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %4\n\tv_cndmask_b32_e64 %0, %0, %4, vcc\n\tv_cndmask_b32_e64 %1, %1, %4, vcc\n\tv_cndmask_b32_e64 %2, %2, %4, vcc\n\tv_cndmask_b32_e64 %3, %3, %4, vcc" : "+v"(A), "+v"(B), "+v"(C), "+v"(D) : "v"(b) : "vcc");
+KERNEL(k_cmp_sel4e, F8, OPCS4E(a0, a1, a2, a3) OPCS4E(a4, a5, a6, a7) OPCS4E(a0, a1, a2, a3) OPCS4E(a4, a5, a6, a7) OPCS4E(a0, a1, a2, a3) OPCS4E(a4, a5, a6, a7) OPCS4E(a0, a1, a2, a3) OPCS4E(a4, a5, a6, a7), SINKF)
+#define OPCS2X(A, B, C) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %3\n\tv_cndmask_b32_e32 %0, %0, %3, vcc\n\tv_add_f32 %2, %2, %3\n\tv_cndmask_b32_e32 %1, %1, %3, vcc" : "+v"(A), "+v"(B), "+v"(C) : "v"(b) : "vcc");
+KERNEL(k_cmp_sel2x, F8, OPCS2X(a0, a1, a2) OPCS2X(a3, a4, a5) OPCS2X(a6, a7, a0) OPCS2X(a1, a2, a3) OPCS2X(a4, a5, a6) OPCS2X(a7, a0, a1) OPCS2X(a2, a3, a4) OPCS2X(a5, a6, a7), SINKF)
+#define OPCS2N(A, B) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\ts_nop 0\n\tv_cndmask_b32_e32 %1, %1, %2, vcc" : "+v"(A), "+v"(B) : "v"(b) : "vcc");
+KERNEL(k_cmp_sel2n, F8, OPCS2N(a0, a1) OPCS2N(a2, a3) OPCS2N(a4, a5) OPCS2N(a6, a7) OPCS2N(a0, a1) OPCS2N(a2, a3) OPCS2N(a4, a5) OPCS2N(a6, a7), SINKF)
+
 // LDS read rates with a per-lane address pattern like the permuted-vertex table
 __global__ void __launch_bounds__(256) k_ds_read_b128(float* out, float seed) {
 	__shared__ float4 buf[1024];
@@ -117,13 +158,19 @@ int main() {
 		{"v_pk_mul_f32", k_pk_mul_f32}, {"v_pk_add_f32", k_pk_add_f32}, {"v_pk_fma_f32", k_pk_fma_f32},
 		{"v_add_f64", k_add_f64}, {"v_mul_f64", k_mul_f64}, {"v_fma_f64", k_fma_f64}, {"v_rcp_f64", k_rcp_f64}, {"v_rsq_f64", k_rsq_f64},
 		{"v_lshlrev_b64", k_lshl_b64}, {"ds_read_b128(+4 v_add)", k_ds_read_b128},
+		{"v_fma_f32 v,v,0", k_fma_inl0}, {"v_fmaak_f32 literal", k_fmaak_lit}, {"v_fmaak_f32 0x0", k_fmaak_0}, {"v_alignbit v,v,31", k_alignbit_inl}, {"v_alignbit v,v,v", k_alignbit_v},
+		{"v_mul_u32_u24", k_mul_u24}, {"v_lshl_add_u32", k_lshl_add}, {"v_bfe_u32", k_bfe}, {"v_and_or_b32", k_and_or}, {"v_cndmask_e32 (vcc fixed)", k_cndmask_vcc},
+		{"v_med3_f32 v,-1,1", k_med3_inl}, {"v_min3_f32 v,v,1.0", k_min3_inl}, {"v_sub_u32", k_sub_u32}, {"v_lshrrev_b32", k_lshr_b32}, {"v_mov_b32", k_mov_b32},
+		{"cmp + 2 cndmask_e32 (16+8 instr -> per 8 groups)", k_cmp_sel2}, {"cmp + 4 cndmask_e32 (8 groups)", k_cmp_sel4}, {"cmp_e64 + 4 cndmask_e64 sgpr (8 groups)", k_cmp_sel4s},
+		{"cmp + 4 cndmask_e64 on vcc (8 groups)", k_cmp_sel4e}, {"cmp, sel, v_add, sel (8 groups of 4)", k_cmp_sel2x}, {"cmp, sel, s_nop, sel (8 groups)", k_cmp_sel2n},
+		{"v_fma_f64 v,v,1.0", k_fma_f64_inl}, {"v_cvt_f32_f64", k_cvt_f32_f64}, {"v_cvt_f64_f32", k_cvt_f64_f32},
 	};
 	float* d; hipMalloc(&d, 4096);
 	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
 	double clk = prop.clockRate * 1e3; // Hz
 	int cus = prop.multiProcessorCount;
 	printf("device %s, %d CUs, clock %.0f MHz\n", prop.gcnArchName, cus, clk / 1e6);
-	for (int wpS : {1, 2, 4}) {   // waves per SIMD
+	for (int wpS : {4}) {   // waves per SIMD (1 and 2 were measured in round 1: profiles/r01_valu_rates.log)
 		printf("--- %d wave(s) per SIMD: cycles per wave-instruction per SIMD (at nominal clock)\n", wpS);
 		for (auto& e : es) {
 			dim3 grid(cus * wpS), block(256);
