@@ -113,7 +113,7 @@ def hip_lib():
     """The HIP library.  There is no fallback: a missing library is an error."""
     global _hip
     if _hip is None:
-        path = os.environ.get("SSX_HIP_LIB_OVERRIDE") or _build.HIP_LIB  # override: tools/ablate.py timing builds only
+        path = os.environ.get("SSX_HIP_LIB_OVERRIDE") or _build.HIP_LIB  # override: A/B and profiling builds (tools/ab_bench.sh, tools/lanestat.py)
         if not os.path.exists(path):
             raise RuntimeError("%s is missing: run `python -m simple_spectral_amd.build` (needs hipcc). "
                                "simple_spectral_amd has no CPU or PyTorch fallback path." % path)

@@ -57,10 +57,11 @@ def check_toolchain():
         if os.path.exists(cand):
             version = open(cand).read().strip()
             break
-    if version and version.split(".")[0] not in TESTED_ROCM_MAJOR and os.environ.get("SSX_ALLOW_UNTESTED_ROCM") != "1":
+    # fail closed: a toolchain whose version cannot be read is as untested as one of another major version
+    if (not version or version.split(".")[0] not in TESTED_ROCM_MAJOR) and os.environ.get("SSX_ALLOW_UNTESTED_ROCM") != "1":
         raise RuntimeError("ROCm %s is not a tested toolchain for libssx_hip.so (tested majors: %s): the kernel's same-wave memory "
                            "ordering relies on validated compiler/hardware behaviour.  Run the GPU parity tests and add the version to "
-                           "simple_spectral_amd/build.py, or set SSX_ALLOW_UNTESTED_ROCM=1." % (version, ", ".join(TESTED_ROCM_MAJOR)))
+                           "simple_spectral_amd/build.py, or set SSX_ALLOW_UNTESTED_ROCM=1." % (version or "(version unreadable)", ", ".join(TESTED_ROCM_MAJOR)))
     return version
 
 

@@ -23,6 +23,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
+// environment switches of the A/B runs and tests: set and not "0" / empty
+bool env_on(const char* name) { const char* e = getenv(name); return e && e[0] != '\0' && e[0] != '0'; }
+
 struct HostError { int code; std::string msg; };
 
 std::string fmt(const char* f, ...) {
@@ -167,7 +170,7 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 		for (uint32_t q = 0; q < s->n_quads && same; ++q) for (int v = 0; v < 4; ++v) same = same && t.vid[q][v] == vid[q][v];
 		if (same) h.topology = t.id;
 	}
-	if (getenv("SSX_GENERIC_KERNEL")) h.topology = 0; // A/B measurements and tests of the generic loop on the built-in scenes
+	if (env_on("SSX_GENERIC_KERNEL")) h.topology = 0; // A/B measurements and tests of the generic loop on the built-in scenes
 
 	uint32_t off = (uint32_t)(sizeof(SsxBlobHeader) / 4);
 	h.off_quads = off;     off = align4(off + s->n_quads * (uint32_t)(sizeof(SsxBlobQuad) / 4));
@@ -462,7 +465,7 @@ int pick_queue(ssx_ctx* ctx, uint32_t topology, uint32_t blob_words, uint32_t* q
 	if (path_lds_bytes(blob_words, SSX_QUEUE_WORDS_WIDE) <= 65536u)
 		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&wide, (const void*)path_kernel_of(topology, false), 256, path_lds_bytes(blob_words, SSX_QUEUE_WORDS_WIDE)));
 	SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&narrow, (const void*)path_kernel_of(topology, true), 256, path_lds_bytes(blob_words, SSX_QUEUE_WORDS_NARROW)));
-	const bool use_narrow = narrow > wide || getenv("SSX_NARROW_QUEUE") != nullptr; // the variable: tests and A/B runs
+	const bool use_narrow = narrow > wide || env_on("SSX_NARROW_QUEUE"); // the variable: tests and A/B runs
 	*queue_words = use_narrow ? SSX_QUEUE_WORDS_NARROW : SSX_QUEUE_WORDS_WIDE;
 	if (blocks_per_cu) *blocks_per_cu = use_narrow ? narrow : wide;
 	return SSX_OK;

@@ -61,6 +61,15 @@ __device__ __forceinline__ float dot3(V3 a, V3 b) { float tx = a.x * b.x, ty = a
 // glm::inversesqrt(x) = 1/sqrt(x): two roundings, each reproduced exactly (ssx_exact.h) in 11 instead of 28 instructions
 __device__ __forceinline__ float inversesqrt_(float x) { return ssx_exact::rcp(ssx_exact::sqrt_normal(x)); }
 __device__ __forceinline__ V3 normalize3(V3 v) { float s = inversesqrt_(dot3(v, v)); return mk(v.x * s, v.y * s, v.z * s); }
+// The same for a vector of ANY length: ssx_exact::sqrt_normal is proven for x >= 2^-100 (and 0); a squared length below
+// that -- a hit point within 2^-50 of a light vertex, possible only where both lie next to the origin -- takes the plain
+// IEEE expansions (rare, lane-divergent branch; NaN takes neither side and propagates as before).
+__device__ __forceinline__ V3 normalize3_any(V3 v) {
+	const float d = dot3(v, v);
+	float s = inversesqrt_(d);
+	if (d < 0x1p-100f) s = 1.0f / __builtin_sqrtf(d);
+	return mk(v.x * s, v.y * s, v.z * s);
+}
 __device__ __forceinline__ float fmax_glm(float a, float b) { return (a < b) ? b : a; }
 __device__ __forceinline__ float fmin_glm(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float clamp_glm(float x, float lo, float hi) { return fmin_glm(fmax_glm(x, lo), hi); }
@@ -739,9 +748,9 @@ __device__ __forceinline__ void sample_light(const Lds& L, Rng& rng, V3 from, V3
 	const float* p1 = first ? Q.pos[1] : Q.pos[2];
 	const float* p2 = first ? Q.pos[2] : Q.pos[3];
 	SphTri st;
-	sphtri_make(normalize3(sub(mk(p0[0], p0[1], p0[2]), from)),
-	            normalize3(sub(mk(p1[0], p1[1], p1[2]), from)),
-	            normalize3(sub(mk(p2[0], p2[1], p2[2]), from)), st);
+	sphtri_make(normalize3_any(sub(mk(p0[0], p0[1], p0[2]), from)),
+	            normalize3_any(sub(mk(p1[0], p1[1], p1[2]), from)),
+	            normalize3_any(sub(mk(p2[0], p2[1], p2[2]), from)), st);
 	dir = rand_toward_sphericaltri(rng, st);
 	pdf = ssx_exact::rcp(st.area);
 	pdf *= 0.5f;
