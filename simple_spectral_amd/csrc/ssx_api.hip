@@ -51,6 +51,7 @@ struct ssx_ctx {
 	double* d_accum = nullptr;  size_t accum_pixels = 0;
 	uint32_t* d_unit_counter = nullptr; // work-unit counter of the path kernel's persistent waves
 	int resident_blocks = 0;            // 256-lane path-kernel workgroups the GPU holds at once
+	int gen_blocks = 0;                 // the same for the generate kernel
 	uint32_t queue_words = SSX_QUEUE_WORDS_WIDE; // entry size of the shadow-ray queues the launches use (pick_queue)
 	uint8_t* d_samples = nullptr; size_t sample_slots = 0; // per-sample arrays (ssx_blob.h), one allocation; record capacity
 	float* d_out = nullptr;     size_t out_pixels = 0;
@@ -329,7 +330,7 @@ int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
 // Every launch writes its samples to [tile slot][k][64] float4 (16 B per sample) and the ordered
 // accumulate pass consumes them; the buffer bounds how many samples per pixel one launch may cover.
 constexpr size_t kSampleBufferBudget = (size_t)64 << 30; // bytes of per-sample arrays one launch may use (288 GB HBM; 512^2 x 256 spp = 38 GB)
-constexpr size_t kBytesPerSampleInFlight = SSX_BYTES_PER_SAMPLE; // 620: ray 16 + stream 16 + 10 levels x (16 + 16 + 1) + 9 x (16 + 8 + 4) + 6
+constexpr size_t kBytesPerSampleInFlight = SSX_BYTES_PER_SAMPLE; // 636: ray 16 + stream 16 + camera hit 16 + 10 levels x (16 + 16 + 1) + 9 x (16 + 8 + 4) + 6
 constexpr uint32_t kMinUnits = 3072;                   // one wave work unit per wave slot of the GPU (256 CUs x 4 SIMDs x 3 waves)
 
 struct LaunchPlan { SsxKernelArgs args; size_t lds_bytes; uint32_t max_spp_per_launch; };
@@ -381,6 +382,7 @@ int ensure_samples(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t n_k) {
 void bind_arrays(SsxKernelArgs& a, uint8_t* base, uint64_t cap) {
 	a.ray = reinterpret_cast<float4*>(base);                      base += cap * 16u;
 	a.st = reinterpret_cast<uint4*>(base);                        base += cap * 16u;
+	a.hit = reinterpret_cast<float4*>(base);                      base += cap * 16u;
 	a.direct = reinterpret_cast<float4*>(base);                   base += cap * 16u * SSX_MAX_LEVELS;
 	a.nee = reinterpret_cast<float4*>(base);                      base += cap * 16u * SSX_MAX_LEVELS;
 	a.fs = reinterpret_cast<float4*>(base);                       base += cap * 16u * SSX_MAX_FRAMES;
@@ -473,13 +475,28 @@ int pick_queue(ssx_ctx* ctx, uint32_t topology, uint32_t blob_words, uint32_t* q
 
 int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stream, bool calibration = false) {
 	if (ctx->timing) { int r = timing_events(ctx, &b.tev); if (r) return r; SSX_HIP(ctx, hipEventRecord(b.tev[0], stream)); }
-	hipLaunchKernelGGL(ssx_generate_kernel, dim3((uint32_t)((b.n_rec + 255u) / 256u)), dim3(256), 0, stream, b.a);
-	SSX_HIP(ctx, hipGetLastError());
+	// the calibration render runs the generic kernels, which read the per-quad vertex table: they stage the whole blob
+	if (calibration) b.a.blob_words = ctx->blob_words;
+	{
+		// camera rays + their closest hits: persistent workgroups striding over the record waves (they stage the blob)
+		const uint32_t topo = calibration ? 0u : ctx->topology;
+		auto gen_kernel = topo == 1u ? ssx_generate_kernel_cornell : (topo == 2u ? ssx_generate_kernel_plane : ssx_generate_kernel);
+		const size_t gen_lds = ((size_t)b.a.blob_words + SSX_LDS_PREFIX_WORDS) * 4;
+		if (ctx->gen_blocks == 0 || calibration) {
+			int per_cu = 0;
+			hipDeviceProp_t prop;
+			SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gen_kernel, 256, gen_lds));
+			SSX_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+			ctx->gen_blocks = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
+		}
+		const uint64_t want = (b.n_rec + 255u) / 256u;
+		hipLaunchKernelGGL(gen_kernel, dim3((uint32_t)(want < (uint64_t)ctx->gen_blocks ? want : (uint64_t)ctx->gen_blocks)), dim3(256), gen_lds, stream, b.a);
+		SSX_HIP(ctx, hipGetLastError());
+		if (calibration) ctx->gen_blocks = 0;
+	}
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[1], stream));
 	// persistent waves: as many workgroups as the GPU holds at once (or fewer, for a small launch); they
 	// fetch work units from a counter
-	// the calibration render runs the generic kernel, which reads the per-quad vertex table: it stages the whole blob
-	if (calibration) b.a.blob_words = ctx->blob_words;
 	if (!ctx->d_unit_counter) SSX_HIP(ctx, hipMalloc((void**)&ctx->d_unit_counter, sizeof(uint32_t)));
 	if (ctx->resident_blocks == 0 || calibration) {
 		int per_cu = 0;
@@ -773,7 +790,7 @@ int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 		ctx->topology = bh->topology;
 		ctx->path_blob_words = bh->topology ? bh->words_without_perm : ctx->blob_words;
 	}
-	ctx->resident_blocks = 0; // depends on the blob's LDS footprint
+	ctx->resident_blocks = 0; ctx->gen_blocks = 0; // depend on the blob's LDS footprint
 	ctx->have_scene = true;
 	return calibrate(ctx);
 }

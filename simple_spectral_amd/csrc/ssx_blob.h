@@ -87,6 +87,7 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 // group_spp samples, <= 512 records) owns the contiguous records [rec_base, rec_base + 64*n_kq).
 //   ray[r]   float4  generate: {camera ray dir.xyz, lambda_0}; the fold overwrites it with {X, Y, Z, alpha}
 //                    ({R, G, B, alpha} in RGB mode), which the accumulate pass reads
+//   hit[r]   float4  generate: the camera ray's closest hit {dist, hitrec.st.x, .y, 2*quad + which as int bits (-1: none)}
 //   st[r]    uint4   generate: PCG32 {state, inc}; at the end of the path: {lambda_0 bits, tail word, final PCG32
 //                    state} (the final state = draws consumed, for the per-sample tests).  Tail word (D = number
 //                    of continued levels = the path's last level): hit_anything | level D has an emission term << 1
@@ -122,7 +123,7 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 #endif
 #define SSX_UNIT_COHORTS (SSX_MAX_UNIT_KS / SSX_COHORT_KS)  // a power of two
 #define SSX_WAVE_COUNTER_WORDS (4u * SSX_UNIT_COHORTS) // per wave, behind the shadow-ray queues: fill counts [unit tag 2][cohort][fs, nee]
-#define SSX_BYTES_PER_SAMPLE (16u + 16u + (2u * 16u + 1u) * SSX_MAX_LEVELS + (16u + 8u + 4u) * SSX_MAX_FRAMES + 6u) // 6: keeps the arrays 16-byte aligned
+#define SSX_BYTES_PER_SAMPLE (16u + 16u + 16u + (2u * 16u + 1u) * SSX_MAX_LEVELS + (16u + 8u + 4u) * SSX_MAX_FRAMES + 6u) // 6: keeps the arrays 16-byte aligned
 
 struct SsxKernelArgs {
 	const uint32_t* blob;   // device copy of the scene blob
@@ -139,6 +140,7 @@ struct SsxKernelArgs {
 	uint64_t seed;
 	float4* ray;              // per-sample arrays, see above
 	uint4* st;
+	float4* hit;
 	float4* direct;
 	float4* nee;
 	float4* fs;

@@ -798,7 +798,11 @@ struct Path {
 	uint32_t depth;
 	uint32_t rec_index; // record of this sample in the per-sample arrays
 	uint32_t prev_slot; // slot of the previous level's entry in the unit's log (SSX_NO_SLOT at level 0), ssx_blob.h
-	bool hit_anything;
+	// what the lane's current ray (orig, dir) hit -- every running path has a hit waiting to be shaded: the camera
+	// ray's comes with the sample (ssx_generate_kernel traces it), a continuation ray's from the trace behind path_step
+	int hit_tri;        // 2*quad + which
+	float hit_dist;
+	float hit_st_x, hit_st_y; // hitrec.st (geometry.cpp:91-95), evaluated where the quad's albedo is a texture (its only reader)
 };
 
 // Where the lane's path appends its level entries: the logs of its COHORT -- the SSX_COHORT_KS consecutive samples
@@ -877,21 +881,19 @@ __device__ __forceinline__ void hit_st(const SsxBlobQuad& Q, uint32_t which, con
 	st_y = (bx * s0[1] + by * s1[1]) + bz * s2[1];
 }
 
-// One level of the recursion L() (renderer.cpp:147-255) for the lane's current ray: closest hit,
+// One level of the recursion L() (renderer.cpp:147-255) for the lane's current ray and the hit it found (p.hit_*):
 // emission (camera ray only), next-event estimation with its shadow ray, BSDF sample.  Writes the
 // level's emission term if it has one (`direct`), parks its shadow ray (whose flush writes `nee`) and,
 // when the path continues, appends the level's entry (the factors of the continuation and the chain word) to
 // the unit's log; returns true when it continues (p then holds the next ray), else level_word describes the
 // path's last level for the tail word.
 template <bool NARROW>
-__device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const SsxKernelArgs& a, const LogRef& lg, Path& p, const HitInfo& hit, bool& pushed, uint32_t& level_word) {
+__device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const SsxKernelArgs& a, const LogRef& lg, Path& p, bool& pushed, uint32_t& level_word) {
 	const SsxBlobHeader& h = L.hdr();
 	// what the level's entry (or the path's tail word) says about this level: slot of its next-event term << 13 | has an emission term << 26
 	level_word = SSX_NO_SLOT << 13;
-	if (hit.tri < 0) return false; // this level's radiance is 0: no term of either kind
-	SSX_STAT(4); // lanes with a hit
-	p.hit_anything = true;
-	const uint32_t hq = (uint32_t)hit.tri >> 1, which = (uint32_t)hit.tri & 1u;
+	SSX_STAT(4); // lanes shading a hit
+	const uint32_t hq = (uint32_t)p.hit_tri >> 1, which = (uint32_t)p.hit_tri & 1u;
 	const SsxBlobQuad& Q = L.quad(hq);
 	const SsxBlobQuad& M = Q; // the material's fields live in the quad record
 	V3 N = mk(Q.normal[which][0], Q.normal[which][1], Q.normal[which][2]);
@@ -914,12 +916,10 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	// :178 `if (depth+1u<MAX_DEPTH)`: with ELS a ray at depth MAX_DEPTH-1 is never started (below);
 	// without it that ray exists (its hit may emit) and ends here
 	if (p.depth + 1u >= SSX_MAX_DEPTH_) return false;
-	V3 hit_pos = add(p.orig, scl(hit.dist, p.dir)); // Ray::at
-	// hitrec.st (geometry.cpp:91-95) is read only by textured albedo
-	float st_x = 0.0f, st_y = 0.0f;
-	if (M.albedo_mode != 0u) { SSX_STAT(6); hit_st(Q, which, hit, st_x, st_y); } else { SSX_STAT(7); } // textured / constant albedo
+	V3 hit_pos = add(p.orig, scl(p.hit_dist, p.dir)); // Ray::at
+	if (M.albedo_mode != 0u) { SSX_STAT(6); } else { SSX_STAT(7); } // textured / constant albedo
 	// albedo(lambda) is shared by evaluate_bsdf and interact_bsdf (material.cpp:120-143)
-	Hero alb = material_albedo(L, Q, st_x, st_y, p.lambda_0);
+	Hero alb = material_albedo(L, Q, p.hit_st_x, p.hit_st_y, p.lambda_0);
 	float f_lamb[4];
 #pragma unroll
 	for (int k = 0; k < 4; ++k) f_lamb[k] = SSX_DIV_CONST(alb.v[k], SSX_PI_F);
@@ -1142,25 +1142,55 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 
 } // namespace
 
-// Stage 1 of 3: one lane per sample.  Camera ray + hero wavelength (f64 camera maths of
-// renderer.cpp:113-138) for every (owned pixel, k in [k0,k1)) into ray[] / st[],
-// record order [tile slot][k-k0][pixel in tile] so a wave writes 64 consecutive records.
-extern "C" __global__ void __launch_bounds__(256) ssx_generate_kernel(SsxKernelArgs a) {
-	const SsxBlobHeader& h = *reinterpret_cast<const SsxBlobHeader*>(a.blob); // uniform: scalar loads
-	const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Stage 1 of 3: one lane per sample.  Camera ray + hero wavelength (f64 camera maths of renderer.cpp:113-138) for every
+// (owned pixel, k in [k0,k1)), AND the camera ray's closest hit (the first Scene::intersect of L(), renderer.cpp:163):
+// the 64 rays of a wave go through one pixel tile, so here they are coherent -- every lane holds a ray, pass 2 runs few
+// trips -- whereas in the path loop a fresh camera ray would occupy a lane of a wave whose other lanes carry bounce rays,
+// and a path that ends by leaving the scene would idle through the shading of its last iteration.  The path kernel's lanes
+// therefore only ever hold rays whose hit is known: every lane that shades has something to shade.
+//   ray[r] = {dir.xyz, lambda_0}   st[r] = PCG32 {state, inc} after the sample's five draws
+//   hit[r] = {dist, st.x, st.y, 2*quad + which as int bits (-1: the ray left the scene)}
+// A sample whose camera ray hits nothing is complete: st[r] gets its end-of-path form at once ({lambda_0, tail word with
+// no hit and no levels, final PCG32 state}) and the path kernel never runs it; the fold turns it into {0, 0, 0, 0}.
+// Record order [tile slot][k-k0][pixel in tile]: a wave writes 64 consecutive records.  Persistent workgroups (they stage
+// the scene tables into LDS for trace()) striding over the record waves.
+template <int TOPO>
+__device__ __forceinline__ void generate_body(const SsxKernelArgs& a) {
+	Lds L; L.w = stage_lds(a);
+	const SsxBlobHeader& h = L.hdr();
+	const V3 cam = mk(h.cam_pos[0], h.cam_pos[1], h.cam_pos[2]);
 	const uint32_t n_k = a.k1 - a.k0;
-	const uint32_t lane = (uint32_t)(gid & 63u);
-	const uint64_t sk = gid >> 6;
-	const uint32_t slot = (uint32_t)(sk / n_k), kk = a.k0 + (uint32_t)(sk % n_k);
-	if (slot >= a.my_tiles) return;
-	const uint32_t tile = a.tile_first + slot * a.tile_stride;
-	const uint32_t i = (tile % a.tiles_x) * 8u + (lane & 7u), j = (tile / a.tiles_x) * 8u + (lane >> 3);
-	if (i >= a.width || j >= a.height) return;
-	float4 ray; uint4 st;
-	generate_sample(h, a, i, j, kk, ray, st);
-	a.ray[gid] = ray;
-	a.st[gid] = st;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint64_t n_waves = a.n_records >> 6;
+	for (uint64_t sk = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); sk < n_waves; sk += (uint64_t)gridDim.x * (blockDim.x >> 6)) {
+		const uint32_t slot = (uint32_t)(sk / n_k), kk = a.k0 + (uint32_t)(sk % n_k);
+		const uint32_t tile = a.tile_first + slot * a.tile_stride;
+		const uint32_t i = (tile % a.tiles_x) * 8u + (lane & 7u), j = (tile / a.tiles_x) * 8u + (lane >> 3);
+		const bool inside = i < a.width && j < a.height; // lanes outside a ragged image have no record
+		float4 ray = make_float4(0.0f, 0.0f, 1.0f, 0.0f); uint4 st = make_uint4(0u, 0u, 0u, 0u);
+		if (inside) generate_sample(h, a, i, j, kk, ray, st);
+		HitInfo hit;
+		trace<TOPO>(L, cam, mk(ray.x, ray.y, ray.z), -1, inside, hit, 16);
+		if (inside) {
+			float st_x = 0.0f, st_y = 0.0f;
+			if (hit.tri >= 0) {
+				const SsxBlobQuad& Q = L.quad((uint32_t)hit.tri >> 1);
+				if (Q.albedo_mode != 0u) hit_st(Q, (uint32_t)hit.tri & 1u, hit, st_x, st_y);
+			} else {
+				st = make_uint4(__float_as_uint(ray.w), (SSX_NO_SLOT << 6) | (SSX_NO_SLOT << 19), st.x, st.y); // see render_body: the tail word of a path that ends at level 0 without a hit
+			}
+			const uint64_t r = sk * 64u + lane;
+			a.ray[r] = ray;
+			a.st[r] = st;
+			a.hit[r] = make_float4(hit.dist, st_x, st_y, __int_as_float(hit.tri));
+		}
+	}
 }
+#define SSX_GENERATE_KERNEL(name, topo) \
+	extern "C" __global__ void __launch_bounds__(256) name(SsxKernelArgs a) { generate_body<topo>(a); }
+SSX_GENERATE_KERNEL(ssx_generate_kernel, 0)
+SSX_GENERATE_KERNEL(ssx_generate_kernel_cornell, 1)
+SSX_GENERATE_KERNEL(ssx_generate_kernel_plane, 2)
 
 // Stage 2 of 3: the path megakernel.  Work unit of one wave64 = one 8x8 tile (Framebuffer::Tile,
 // renderer.cpp:396-409) x a group of consecutive samples; its items (pixel of the tile, k) are
@@ -1206,11 +1236,13 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
 	const uint32_t total_units = a.my_tiles * a.n_groups;
-	const SsxBlobHeader& h = L.hdr();
-	const V3 cam = mk(h.cam_pos[0], h.cam_pos[1], h.cam_pos[2]);
+	// the camera position from the blob's copy in HBM: wave-uniform scalar loads (SGPRs; LDS reads would hold three VGPRs for the whole kernel)
+	const SsxBlobHeader& hg = *reinterpret_cast<const SsxBlobHeader*>(a.blob);
+	const V3 cam = mk(hg.cam_pos[0], hg.cam_pos[1], hg.cam_pos[2]);
 
 	Path p;
-	p.orig = cam; p.dir = mk(0.0f, 0.0f, 1.0f); p.ignore = -1; p.depth = 0; p.rec_index = 0; p.lambda_0 = 0.0f; p.hit_anything = false; p.prev_slot = SSX_NO_SLOT;
+	p.orig = cam; p.dir = mk(0.0f, 0.0f, 1.0f); p.ignore = -1; p.depth = 0; p.rec_index = 0; p.lambda_0 = 0.0f; p.prev_slot = SSX_NO_SLOT;
+	p.hit_tri = 0; p.hit_dist = 0.0f; p.hit_st_x = p.hit_st_y = 0.0f;
 	p.rng.state = 0; p.rng.inc = 1;
 	bool active = false;
 	uint32_t p_tag = 0; // which of the (at most two) units in flight the lane's sample belongs to, and its cohort there:
@@ -1229,30 +1261,51 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	bool cur_valid = false, old_pending = false, more = true;
 	uint32_t cur_tag = 0, old_tag = 0;
 	uint32_t next_item = 0; // wave-uniform
+	// the tail word (ssx_blob.h) of the lane's path ending at level p.depth: hit_anything (always: only samples whose camera
+	// ray hit something run here) | the level has an emission term << 1 | p.depth << 2 | slot of the entry of level
+	// p.depth-1 << 6 | slot of the level's next-event term << 19; lambda_0 and the final PCG32 state replace the sample's
+	// stream.  The fold happens when the sample's unit is complete.
+	auto end_path = [&](uint32_t level_word) {
+		const uint32_t tail = 1u | ((level_word >> 26) << 1) | (p.depth << 2) | (p.prev_slot << 6) | ((level_word >> 13) << 19);
+		a.st[p.rec_index] = make_uint4(__float_as_uint(p.lambda_0), tail, (uint32_t)p.rng.state, (uint32_t)(p.rng.state >> 32));
+		active = false;
+	};
 	for (;;) {
-		// One iteration: (1) one interaction of every running path; (2) hand the lanes that fell idle their next samples --
-		// before (3), so that the loads of the new camera rays are in flight during the shadow flush; (3) flush / fold.
-		const bool running = __any(active);
-		if (running) {
-			bool pushed = false;
-			HitInfo hit; // the primary rays of all lanes: traced in uniform control flow
-			if (active) SSX_STAT(13); // lanes with a path, per iteration
-			trace<TOPO>(L, p.orig, p.dir, p.ignore, active, hit, 0);
-			if (active) {
-				LogRef lg;
-				lg.cnt = log_cnt; lg.group = (p_tag & 1u) * SSX_UNIT_COHORTS + ((p_tag >> 1) & (SSX_UNIT_COHORTS - 1u));
-				lg.base_rec = (p.rec_index & ~63u) - ((p_tag >> 8) << 6);
-				uint32_t level_word;
-				if (!path_step<NARROW>(L, sq, a, lg, p, hit, pushed, level_word)) {
-					// last level reached: lambda_0, the tail word (hit flag, number of continued levels, where the chain of
-					// its levels starts, the last level's own terms: ssx_blob.h) and the final PCG32 state replace the
-					// sample's stream; the fold happens when its unit is complete
-					const uint32_t tail = (p.hit_anything ? 1u : 0u) | ((level_word >> 26) << 1) | (p.depth << 2) | (p.prev_slot << 6) | ((level_word >> 13) << 19);
-					a.st[p.rec_index] = make_uint4(__float_as_uint(p.lambda_0), tail, (uint32_t)p.rng.state, (uint32_t)(p.rng.state >> 32));
-					active = false;
-				}
-			}
-			sq.count += (uint32_t)__popcll(__ballot(pushed));
+		// One iteration:
+		// (1) every running path shades the hit it holds (one level of L()): it parks a shadow ray and either produces its
+		//     continuation ray or ends;
+		// (2) the parked shadow rays are traced when a wave's worth has gathered, and the previous unit is folded when its
+		//     last path is done -- here, where a lane's state is the path with its next ray and nothing else (the hit of a
+		//     ray lives only from (3)/(5) to (1));
+		// (3) when that made room, the next unit is fetched;
+		// (4) the continuation rays of all lanes are traced in uniform control flow; a ray that leaves the scene ends its
+		//     path there, so that no lane carries a miss into the next shading;
+		// (5) the lanes that fell idle in (1) or (4) take their next samples: camera ray, stream and the camera ray's hit
+		//     come from ssx_generate_kernel.
+		bool pushed = false;
+		if (active) {
+			SSX_STAT(13); // lanes with a path, per iteration
+			LogRef lg;
+			lg.cnt = log_cnt; lg.group = (p_tag & 1u) * SSX_UNIT_COHORTS + ((p_tag >> 1) & (SSX_UNIT_COHORTS - 1u));
+			lg.base_rec = (p.rec_index & ~63u) - ((p_tag >> 8) << 6);
+			uint32_t level_word;
+			if (!path_step<NARROW>(L, sq, a, lg, p, pushed, level_word)) end_path(level_word);
+		}
+		sq.count += (uint32_t)__popcll(__ballot(pushed));
+		const bool busy = __any(active);
+		// The parked shadow rays are traced a full wave at a time; all of them when the previous unit's last paths are
+		// done (some may be its: they must be in before its fold) or when nothing is running at all.  One call site:
+		// a flush inlines a whole trace.
+		const bool fold_old = old_pending && !__any(active && (p_tag & 1u) == old_tag);
+		const bool drain = (fold_old && a.fuse_resolve) || !busy;
+		while (sq.count >= SSX_SQ_FLUSH_AT || (drain && sq.count)) {
+			const uint32_t take = min(sq.count, 64u);
+			sq.count -= take;
+			shadow_flush<TOPO, NARROW>(L, a, sq, sq.count, take);
+		}
+		if (fold_old) {
+			if (a.fuse_resolve) unit_fold<NARROW>(L, a, old);
+			old_pending = false;
 		}
 		// rotate: the current unit has no items left and the previous one is folded
 		if (cur_valid && next_item >= cur.n_items && !old_pending) {
@@ -1269,6 +1322,21 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			}
 			else more = false;
 		}
+		if (busy) {
+			HitInfo hit;
+			trace<TOPO>(L, p.orig, p.dir, p.ignore, active, hit, 0);
+			// (unconditional assignments: nothing of the previous hit stays live across the trace)
+			p.hit_tri = hit.tri; p.hit_dist = hit.dist;
+			float st_x = 0.0f, st_y = 0.0f;
+			if (active) {
+				if (hit.tri < 0) end_path(SSX_NO_SLOT << 13); // the ray left the scene: this level's radiance is 0, no term of either kind
+				else {
+					const SsxBlobQuad& Q = L.quad((uint32_t)hit.tri >> 1);
+					if (Q.albedo_mode != 0u) hit_st(Q, (uint32_t)hit.tri & 1u, hit, st_x, st_y);
+				}
+			}
+			p.hit_st_x = st_x; p.hit_st_y = st_y;
+		}
 		// hand out items to idle lanes
 		if (cur_valid && next_item < cur.n_items) {
 			const uint64_t idle = __ballot(!active);
@@ -1281,6 +1349,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 					p.rec_index = cur.rec_base + kq * 64u + in_tile;
 					const float4 ray = a.ray[p.rec_index];
 					const uint4 st = a.st[p.rec_index];
+					const float4 ht = a.hit[p.rec_index];
 					p.dir = mk(ray.x, ray.y, ray.z);
 					p.lambda_0 = ray.w;
 					p.rng.state = ((uint64_t)st.y << 32) | st.x;
@@ -1289,29 +1358,15 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 					p.ignore = -1;
 					p.depth = 0;
 					p.prev_slot = SSX_NO_SLOT;
-					p.hit_anything = false;
+					p.hit_dist = ht.x; p.hit_st_x = ht.y; p.hit_st_y = ht.z; p.hit_tri = __float_as_int(ht.w);
 					p_tag = cur_tag | ((kq / SSX_COHORT_KS) << 1) | ((kq % SSX_COHORT_KS) << 8);
-					active = true;
+					active = p.hit_tri >= 0; // a camera ray that left the scene: the sample was complete when it was generated
 				}
 			}
 			next_item = min(cur.n_items, next_item + (uint32_t)__popcll(idle));
 		}
-		const bool busy = __any(active);
-		// The parked shadow rays are traced a full wave at a time; all of them when the previous unit's last paths are
-		// done (some may be its: they must be in before its fold) or when nothing is running at all.  One call site:
-		// a flush inlines a whole trace.
-		const bool fold_old = old_pending && !__any(active && (p_tag & 1u) == old_tag);
-		const bool drain = (fold_old && a.fuse_resolve) || !busy;
-		while (sq.count >= SSX_SQ_FLUSH_AT || (drain && sq.count)) {
-			const uint32_t take = min(sq.count, 64u);
-			sq.count -= take;
-			shadow_flush<TOPO, NARROW>(L, a, sq, sq.count, take);
-		}
-		if (fold_old) {
-			if (a.fuse_resolve) unit_fold<NARROW>(L, a, old);
-			old_pending = false;
-		}
-		if (!busy && !cur_valid && !more) break; // nothing runs, nothing left to hand out
+		// nothing runs, nothing is left to hand out, nothing waits for its flush or fold
+		if (!__any(active) && !cur_valid && !more && !old_pending && sq.count == 0u) break;
 	}
 }
 
@@ -1325,10 +1380,12 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(waves))) name(SsxKernelArgs a) { render_body<topo, narrow>(a); }
 SSX_PATH_KERNEL(ssx_render_kernel, 0, false, SSX_WAVES_PER_EU)
 SSX_PATH_KERNEL(ssx_render_kernel_cornell, 1, false, SSX_WAVES_PER_EU)
+#ifndef SSX_PROBE_BUILD // tools/kernel_resources.py --probe: the two kernels above only (register pressure experiments)
 SSX_PATH_KERNEL(ssx_render_kernel_plane, 2, false, SSX_WAVES_PER_EU)
 SSX_PATH_KERNEL(ssx_render_kernel_nq, 0, true, SSX_WAVES_PER_EU)
 SSX_PATH_KERNEL(ssx_render_kernel_cornell_nq, 1, true, SSX_WAVES_PER_EU)
 SSX_PATH_KERNEL(ssx_render_kernel_plane_nq, 2, true, SSX_WAVES_PER_EU)
+#endif
 // The generic kernel under another name for the calibration render of ssx_upload_scene (64x64x4 samples), so that
 // kernel traces and statistics of ssx_render_kernel* contain real launches only.  Narrow queue entries: it stages the
 // whole blob, which may only fit with them.
