@@ -35,11 +35,11 @@ FLOP_PER_SAMPLE = {"cornell-srgb": 1.28e4, "cornell": 1.28e4, "plane-srgb": 2.8e
 # for the Cornell box, 1.0 for the plane), R = parked shadow rays per sample (3.08 Cornell, 1.36 plane: lane
 # statistics of the profiling build, profiles/*/lanestat.log) and E = levels with an emission term (~0.01:
 # camera rays that hit the light):
-#   generate  : write ray 16 + stream 16
-#   path      : read ray 16 + stream 16; per continued level append fs 16 + np 8 + chain word 4; emission term 16 E;
+#   generate  : write camera ray 16 + stream 16 + camera hit 16
+#   path      : read the three 48; per continued level append fs 16 + np 8 + chain word 4; emission term 16 E;
 #               at the end write {lambda, tail word, final stream state} 16
 #   shadow    : R x write nee 16 (write-only: contribution or zeros)
-#   fold      : read stream 16 + (fs 16 + np 8 + chain word 4) L + nee 16 R + emission 16 E; write XYZA 16
+#   fold      : read tail 16 + (fs 16 + np 8 + chain word 4) L + nee 16 R + emission 16 E; write XYZA 16
 #   accumulate: read XYZA 16
 LEVELS = {"cornell-srgb": 4.07, "cornell": 4.07, "plane-srgb": 1.0}
 SHADOW = {"cornell-srgb": 3.08, "cornell": 3.08, "plane-srgb": 1.36}
@@ -53,8 +53,8 @@ def algorithmic_bytes_per_sample(scene, path_kernel_only=False, levels=None):
     L = levels if levels else LEVELS.get(scene, 4.07)
     R = SHADOW.get(scene, 3.08)
     E = 0.01
-    path = (32 + 28 * L + 16 * E + 16) + 16 * R + (16 + 28 * L + 16 * R + 16 * E + 16)   # path loop + shadow flush + fold
-    return path if path_kernel_only else 32 + path + 16
+    path = (48 + 28 * L + 16 * E + 16) + 16 * R + (16 + 28 * L + 16 * R + 16 * E + 16)   # path loop + shadow flush + fold
+    return path if path_kernel_only else 48 + path + 16
 
 
 def host_cpu_info():
@@ -282,11 +282,15 @@ def main():
             host_img.copy_(out, non_blocking=True)
     fence()
     elapsed_host = time.perf_counter() - t1
-    kernel_ms = stage_ms["path"]  # the dominant kernel (ssx_render_kernel), mean per launch
+    # The integrator is two kernels since round 3: ssx_generate_kernel* (camera rays AND their closest hits, traced
+    # coherently) and the path megakernel (everything behind the first hit).  The algorithmic flop figure of SURVEY 8(d)
+    # covers both, so the roofline is quoted over both durations (rocprofv3: the two rows of kernel_stats.csv).
+    path_ms = stage_ms["path"]
+    kernel_ms = stage_ms["path"] + stage_ms["generate"]
     if use_dist:
-        tt = torch.tensor([elapsed, kernel_ms, elapsed_host], dtype=torch.float64, device="cpu" if test_one_gpu else "cuda")
+        tt = torch.tensor([elapsed, kernel_ms, elapsed_host, path_ms], dtype=torch.float64, device="cpu" if test_one_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms, elapsed_host = float(tt[0]), float(tt[1]), float(tt[2])
+        elapsed, kernel_ms, elapsed_host, path_ms = float(tt[0]), float(tt[1]), float(tt[2]), float(tt[3])
     if os.environ.get("SSX_BENCH_DUMP"):  # tests: rank 0's combined image
         if rank == 0:
             import numpy as np
@@ -319,7 +323,8 @@ def main():
                          "traffic": traffic,
                          "traffic_source": "replayed from profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, corrected by factors calibrated on known byte counts in the same access patterns; NOT measured in this run" if traffic else None,
                          "traffic_detail": traffic_detail,
-                         "kernel": plan.get("kernel") or "ssx_render_kernel", "kernel_ms": round(kernel_ms, 3),
+                         "kernel": "%s + %s" % ((plan.get("kernel") or "ssx_render_kernel").replace("render", "generate").replace("_nq", ""), plan.get("kernel") or "ssx_render_kernel"),
+                         "kernel_ms": round(kernel_ms, 3), "path_kernel_ms": round(path_ms, 3),
                          "pipeline_ms": round(pipeline_ms, 3), "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
                          "flop_per_sample": flop,
                          "note": "FP32 VALU-issue bound (no MFMA: traversal/sampling); peak = 157.3/2 TFLOP/s because the parity contract forbids FMA contraction. HBM is busy but not the limiter: see hbm.",
@@ -327,10 +332,11 @@ def main():
                                  "path_kernel_algorithmic_bytes_per_sample": round(algorithmic_bytes_per_sample(args.scene, True, L), 1),
                                  "traffic_over_path_kernel_algorithmic": round(traffic / (per_gpu_samples * algorithmic_bytes_per_sample(args.scene, True, L)), 3) if traffic else None,
                                  "algorithmic_GBps": round(hbm_bytes / (pipeline_ms * 1e-3) / 1e9, 1),
-                                 "measured_GBps": round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None,
+                                 "measured_GBps": round(traffic / (path_ms * 1e-3) / 1e9, 1) if traffic else None,
                                  "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                  "frac_algorithmic": round(hbm_bytes / (pipeline_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                                 "frac_measured": round(traffic / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else None},
+                                 "frac_measured": round(traffic / (path_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if traffic else None},
+                         "device_scratch_bytes": r.scratch_info(),
                          "vgprs": info["vgprs"], "scratch_bytes": info["scratch_bytes"], "lds_bytes": info["lds_bytes"],
                          "plan": plan},
         }

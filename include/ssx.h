@@ -196,8 +196,8 @@ const char* ssx_last_error(const ssx_ctx* ctx);
 
 /* Measurement aid: when enabled, HIP events are recorded on the launch stream around the stages
  * of every launch; ssx_get_timing waits for them and returns (and clears) the summed milliseconds
- * {generate, path megakernel, resolve, accumulate} since the last call.  (When the resolve stage --
- * fold of the recursion + XYZ -- runs inside the path kernel, see ssx_plan_info, its slot reads ~0.) */
+ * {generate (camera rays + their hits), path megakernel, resolve, accumulate} since the last call.  (The resolve
+ * stage -- fold of the recursion + XYZ -- runs inside the path kernel: its slot reads ~0.) */
 int ssx_set_timing(ssx_ctx* ctx, int enable);
 int ssx_get_timing(ssx_ctx* ctx, float stage_ms[4]);
 
@@ -205,10 +205,14 @@ int ssx_get_timing(ssx_ctx* ctx, float stage_ms[4]);
 int ssx_abi_version(void);
 int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* scratch_bytes, int* max_blocks_per_cu);
 /* What ssx_upload_scene's calibration render (64x64x4 samples of the scene, fixed seed) found: frames
- * (continued interactions) per sample; and whether the fold of the recursion runs at the end of each
- * wave's unit inside the path kernel (1: the rule) or as a streaming kernel of its own (0: with
- * SSX_FUSE_RESOLVE=0 in the environment at upload).  A performance choice only: both give the same bits. */
+ * (continued interactions) per sample.  fold_in_path_kernel is always 1: the fold of the recursion runs at
+ * the end of each wave's work unit inside the path kernel (the stand-alone fold kernel of earlier versions
+ * is gone: the levels live in per-wave logs that are recycled while the kernel runs). */
 int ssx_plan_info(ssx_ctx* ctx, float* frames_per_sample, int* fold_in_path_kernel);
+/* Device scratch the context holds right now: the per-sample arrays of the largest launch so far (48 bytes per sample in
+ * flight: camera ray / result, stream / tail word, camera hit) and the persistent waves' level logs (a fixed size per
+ * device and unit size: wave slots x 2 units x cohorts x 128 records x 582 bytes). */
+int ssx_scratch_info(ssx_ctx* ctx, uint64_t* sample_bytes, uint64_t* log_bytes);
 /* Which path kernel the uploaded scene runs: 0 = the generic one (pass 1 of the intersection loops over the
  * quads), 1 / 2 = the kernel whose pass 1 is specialised to the mesh topology of the reference's Cornell box /
  * plane scene (the scene's quad corners coincide in exactly that pattern; positions are free).  A performance

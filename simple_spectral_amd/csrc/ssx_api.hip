@@ -46,14 +46,16 @@ struct ssx_ctx {
 	std::vector<uint8_t*> d_textures;
 	float* d_jh_data = nullptr;
 	bool rgb_mode = false;     // scene uploaded with uplift == SSX_MODE_RGB
-	bool fuse_resolve = true;  // fold inside the path kernel, or as its own streaming kernel (SSX_FUSE_RESOLVE=0)
+	bool fuse_resolve = true;  // false only during the calibration render (no fold: its tail words are read back)
 	float calib_frames = 0.0f; // frames per sample measured by the calibration render of ssx_upload_scene
 	double* d_accum = nullptr;  size_t accum_pixels = 0;
 	uint32_t* d_unit_counter = nullptr; // work-unit counter of the path kernel's persistent waves
 	int resident_blocks = 0;            // 256-lane path-kernel workgroups the GPU holds at once
 	int gen_blocks = 0;                 // the same for the generate kernel
+	uint32_t max_wave_slots = 0;        // most waves of the path kernel the GPU can hold: CUs x 16
 	uint32_t queue_words = SSX_QUEUE_WORDS_WIDE; // entry size of the shadow-ray queues the launches use (pick_queue)
 	uint8_t* d_samples = nullptr; size_t sample_slots = 0; // per-sample arrays (ssx_blob.h), one allocation; record capacity
+	uint8_t* d_logs = nullptr; size_t log_records = 0;     // the persistent waves' level logs (ssx_blob.h); log-record capacity
 	float* d_out = nullptr;     size_t out_pixels = 0;
 	float* d_peer = nullptr;    size_t peer_pixels = 0; // staging buffer of ssx_accumulate_peer
 	bool have_scene = false;
@@ -327,10 +329,11 @@ int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
 	return SSX_OK;
 }
 
-// Every launch writes its samples to [tile slot][k][64] float4 (16 B per sample) and the ordered
-// accumulate pass consumes them; the buffer bounds how many samples per pixel one launch may cover.
-constexpr size_t kSampleBufferBudget = (size_t)64 << 30; // bytes of per-sample arrays one launch may use (288 GB HBM; 512^2 x 256 spp = 38 GB)
-constexpr size_t kBytesPerSampleInFlight = SSX_BYTES_PER_SAMPLE; // 636: ray 16 + stream 16 + camera hit 16 + 10 levels x (16 + 16 + 1) + 9 x (16 + 8 + 4) + 6
+// Every launch keeps 48 bytes per sample ([tile slot][k][64]: camera ray / XYZA result, stream / tail, camera hit) until the
+// ordered accumulate pass has consumed them; the buffer bounds how many samples per pixel one launch may cover.  The
+// levels of the recursion live in the persistent waves' logs (ensure_logs), whose size does not depend on the launch.
+constexpr size_t kSampleBufferBudget = (size_t)16 << 30; // bytes of per-sample arrays one launch may use (512^2 x 256 spp = 3.2 GB; 16 GiB = 358 M samples ~ 110 ms of rendering)
+constexpr size_t kBytesPerSampleInFlight = SSX_BYTES_PER_SAMPLE;
 constexpr uint32_t kMinUnits = 3072;                   // one wave work unit per wave slot of the GPU (256 CUs x 4 SIMDs x 3 waves)
 
 struct LaunchPlan { SsxKernelArgs args; size_t lds_bytes; uint32_t max_spp_per_launch; };
@@ -358,8 +361,8 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 		if (avail < budget) budget = avail;
 	}
 	size_t cap = budget / per_spp;
-	// level indices l*n + r are 32-bit in the kernels
-	const size_t idx_cap = ((size_t)0xFFFFFFFFu / SSX_MAX_LEVELS) / ((size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u);
+	// record indices are 32-bit in the kernels
+	const size_t idx_cap = (size_t)0xFFFFFFFFu / ((size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u);
 	if (cap > idx_cap) cap = idx_cap;
 	pl.max_spp_per_launch = (uint32_t)(cap < 1 ? 1 : (cap > 65536 ? 65536 : cap));
 	return pl;
@@ -378,17 +381,38 @@ int ensure_samples(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t n_k) {
 	return SSX_OK;
 }
 
-// the per-sample arrays of one batch inside a region of `cap` records starting at `base` (ssx_blob.h)
-void bind_arrays(SsxKernelArgs& a, uint8_t* base, uint64_t cap) {
+// The persistent waves' level logs: one region per wave slot, unit tag and cohort (ssx_blob.h).  A CU holds at most 16
+// waves of the path kernel (4 per SIMD at 128 VGPRs), whichever variant runs.
+int ensure_logs(ssx_ctx* ctx, uint32_t unit_cohorts) {
+	if (ctx->max_wave_slots == 0) {
+		hipDeviceProp_t prop;
+		SSX_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+		ctx->max_wave_slots = (uint32_t)prop.multiProcessorCount * 16u;
+	}
+	const size_t need = (size_t)ctx->max_wave_slots * 2u * unit_cohorts * SSX_COHORT_RECORDS;
+	if (ctx->log_records < need) {
+		// normally sized once per scene (calibrate); growing later must not pull the logs from under a queued render
+		if (ctx->d_logs) { SSX_HIP(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->d_logs); }
+		ctx->d_logs = nullptr; ctx->log_records = 0;
+		hipError_t e = hipMalloc((void**)&ctx->d_logs, need * SSX_LOG_BYTES_PER_RECORD);
+		if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(ctx, SSX_ERR_DEVICE, fmt("out of device memory for the level logs (%zu bytes)", need * (size_t)SSX_LOG_BYTES_PER_RECORD)); }
+		SSX_HIP(ctx, e);
+		ctx->log_records = need;
+	}
+	return SSX_OK;
+}
+
+// the per-sample arrays of one batch inside a region of `cap` records starting at `base`, and the waves' logs (ssx_blob.h)
+void bind_arrays(SsxKernelArgs& a, uint8_t* base, uint64_t cap, uint8_t* logs, uint64_t log_cap) {
 	a.ray = reinterpret_cast<float4*>(base);                      base += cap * 16u;
 	a.st = reinterpret_cast<uint4*>(base);                        base += cap * 16u;
-	a.hit = reinterpret_cast<float4*>(base);                      base += cap * 16u;
-	a.direct = reinterpret_cast<float4*>(base);                   base += cap * 16u * SSX_MAX_LEVELS;
-	a.nee = reinterpret_cast<float4*>(base);                      base += cap * 16u * SSX_MAX_LEVELS;
-	a.fs = reinterpret_cast<float4*>(base);                       base += cap * 16u * SSX_MAX_FRAMES;
-	a.np = reinterpret_cast<float2*>(base);                       base += cap * 8u * SSX_MAX_FRAMES;
-	a.link = reinterpret_cast<uint32_t*>(base);                   base += cap * 4u * SSX_MAX_FRAMES;
-	a.vis = base;
+	a.hit = reinterpret_cast<float4*>(base);
+	a.fs = reinterpret_cast<float4*>(logs);                       logs += log_cap * 16u * SSX_MAX_FRAMES;
+	a.nee = reinterpret_cast<float4*>(logs);                      logs += log_cap * 16u * SSX_MAX_LEVELS;
+	a.direct = reinterpret_cast<float4*>(logs);                   logs += log_cap * 16u * SSX_MAX_LEVELS;
+	a.np = reinterpret_cast<float2*>(logs);                       logs += log_cap * 8u * SSX_MAX_FRAMES;
+	a.link = reinterpret_cast<uint32_t*>(logs);                   logs += log_cap * 4u * SSX_MAX_FRAMES;
+	a.vis = logs;
 }
 
 // adds the stage durations of the recorded batches to ctx->stage_ms
@@ -423,7 +447,14 @@ int timing_events(ssx_ctx* ctx, hipEvent_t** out) {
 // One batch = samples [k0,k1) of every owned pixel, with its per-sample arrays at record offset
 // rec_off of the buffers.  front = generate -> path megakernel; back = resolve (fold + XYZ) ->
 // ordered f64 accumulation.
-struct Batch { SsxKernelArgs a; uint32_t units; uint64_t n_rec; hipEvent_t* tev; };
+struct Batch { SsxKernelArgs a; uint32_t units; uint64_t n_rec; hipEvent_t* tev; int rc; };
+
+// samples per pixel of a work unit for the uploaded scene (before make_batch halves it for small launches)
+uint32_t unit_spp_of(const ssx_ctx* ctx) {
+	uint32_t g = ctx->calib_frames >= 2.0f ? SSX_MAX_UNIT_KS / 2u : SSX_MAX_UNIT_KS;
+	if (const char* e = getenv("SSX_UNIT_SPP")) { const int v = atoi(e); if (v >= 1 && v <= (int)SSX_MAX_UNIT_KS) g = (uint32_t)v; } // A/B runs
+	return g;
+}
 
 Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1, uint64_t rec_off) {
 	Batch b{};
@@ -434,19 +465,22 @@ Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1, u
 	a.n_records = (uint64_t)a.my_tiles * n_k * 64u;
 	// rec_off = 0, or the first record of the second half of a double-buffered allocation: each half is a
 	// region of its own (capacity = records of a full batch >= this batch)
-	bind_arrays(a, ctx->d_samples + rec_off * kBytesPerSampleInFlight, rec_off ? rec_off : a.n_records);
 	// Samples per pixel and unit.  Long paths (Cornell: 4 continued levels per sample) run best with 4 -- 256 items keep the
 	// refill busy, less of a unit's logs is in flight per wave, and short units balance the end of the launch: 3052 against
 	// 3016 Msamples/s with 8, 3031 with 2, 2899 with 16 (one box) --, short ones (plane-srgb: 1 level) with 8: 10.07 against
 	// 9.89 Gsamples/s.  Halved while the launch is so small that SIMDs would be left without a wave (3 waves x 1024 SIMDs).
-	uint32_t g = ctx->calib_frames >= 2.0f ? SSX_MAX_UNIT_KS / 2u : SSX_MAX_UNIT_KS;
-	if (const char* e = getenv("SSX_UNIT_SPP")) { const int v = atoi(e); if (v >= 1 && v <= (int)SSX_MAX_UNIT_KS) g = (uint32_t)v; } // A/B runs
+	uint32_t g = unit_spp_of(ctx);
 	while (g > 1u && (uint64_t)((n_k + g - 1u) / g) * a.my_tiles < kMinUnits) g >>= 1;
 	a.group_spp = g;
 	if (a.group_spp > n_k) a.group_spp = n_k;
 	a.n_groups = (n_k + a.group_spp - 1) / a.group_spp;
+	a.unit_cohorts = (a.group_spp + SSX_COHORT_KS - 1u) / SSX_COHORT_KS;
 	b.units = a.my_tiles * a.n_groups;
 	b.n_rec = a.n_records;
+	// rec_off = 0, or the first record of the second half of a double-buffered allocation: each half is a region of its own
+	// (capacity = records of a full batch >= this batch).  The logs are shared by all batches: path kernels run one after the other.
+	b.rc = ensure_logs(ctx, a.unit_cohorts);
+	if (b.rc == SSX_OK) bind_arrays(a, ctx->d_samples + rec_off * kBytesPerSampleInFlight, rec_off ? rec_off : a.n_records, ctx->d_logs, ctx->log_records);
 	return b;
 }
 
@@ -474,6 +508,7 @@ int pick_queue(ssx_ctx* ctx, uint32_t topology, uint32_t blob_words, uint32_t* q
 }
 
 int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stream, bool calibration = false) {
+	if (b.rc) return b.rc; // make_batch could not get the waves' logs
 	if (ctx->timing) { int r = timing_events(ctx, &b.tev); if (r) return r; SSX_HIP(ctx, hipEventRecord(b.tev[0], stream)); }
 	// the calibration render runs the generic kernels, which read the per-quad vertex table: they stage the whole blob
 	if (calibration) b.a.blob_words = ctx->blob_words;
@@ -517,7 +552,8 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_unit_counter, 0, sizeof(uint32_t), stream));
 	b.a.unit_counter = ctx->d_unit_counter;
 	const uint32_t want_blocks = (b.units + 3u) / 4u;
-	const uint32_t blocks = want_blocks < (uint32_t)ctx->resident_blocks ? want_blocks : (uint32_t)ctx->resident_blocks;
+	uint32_t blocks = want_blocks < (uint32_t)ctx->resident_blocks ? want_blocks : (uint32_t)ctx->resident_blocks;
+	if (blocks * 4u > ctx->max_wave_slots) blocks = ctx->max_wave_slots / 4u; // every wave of the grid owns a log region
 	hipLaunchKernelGGL(calibration ? ssx_calibrate_kernel : path_kernel, dim3(blocks), dim3(256), path_lds, stream, b.a);
 	SSX_HIP(ctx, hipGetLastError());
 	if (calibration) ctx->resident_blocks = 0; // computed for the calibration kernel: recompute for the path kernel
@@ -527,11 +563,7 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 
 int enqueue_back(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stream) {
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[3], stream));
-	if (!b.a.fuse_resolve) { // otherwise the fold ran at the end of every wave's unit inside the path kernel (slot reads ~0)
-		const uint64_t want = (b.n_rec + 255u) / 256u;
-		hipLaunchKernelGGL(ssx_resolve_kernel, dim3((uint32_t)(want < 8192u ? want : 8192u)), dim3(256), pl.lds_bytes, stream, b.a);
-		SSX_HIP(ctx, hipGetLastError());
-	}
+	// (the fold of the recursion ran inside the path kernel; the "resolve" timing slot stays ~0)
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[4], stream));
 	hipLaunchKernelGGL(ssx_accumulate_kernel, dim3((b.a.my_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, b.a, ctx->d_accum);
 	SSX_HIP(ctx, hipGetLastError());
@@ -577,15 +609,12 @@ int launch_pipelined(ssx_ctx* ctx, LaunchPlan& pl, uint32_t spp, uint32_t batch,
 }
 
 // A 64x64x4-sample render of the scene at upload time counts the continued levels per sample (plan_info: what the
-// benchmark prices the algorithmic HBM bytes with).  It used to decide where the fold runs -- inside the path kernel,
-// where its loads hide under other waves' arithmetic, or as a streaming kernel of its own, which won for very short
-// paths (plane-srgb) while the levels lived in [level][record] arrays.  With the levels in per-cohort logs the fold
-// inside the path kernel wins there too (plane-srgb 1024^2 spp 1024: 9.91 against 9.68 Gsamples/s), so it is the
-// rule; SSX_FUSE_RESOLVE=0 selects the separate kernel (same arithmetic, same bits: the tests run both).
+// benchmark prices the algorithmic HBM bytes with, and what picks the unit size in make_batch).  It runs without the fold,
+// so that st[] keeps the tail words, which are read back.
 int calibrate(ssx_ctx* ctx) {
 	ssx_render_params cp{};
 	cp.struct_size = sizeof cp; cp.width = 64; cp.height = 64; cp.spp = 4; cp.tile_stride = 1;
-	ctx->fuse_resolve = false; // st[] keeps {lambda_0, hit | levels | masks, ...}: the level counts are read back below
+	ctx->fuse_resolve = false; // no fold: st[] keeps {lambda_0, tail word, ...}, the level counts are read back below
 	LaunchPlan pl = make_plan(ctx, &cp);
 	int rc = ensure_samples(ctx, pl, cp.spp);
 	if (rc) return rc;
@@ -601,8 +630,8 @@ int calibrate(ssx_ctx* ctx) {
 	for (const uint4& r : recs) frames += (r.y >> 2) & 0xFu;
 	ctx->calib_frames = (float)((double)frames / (double)recs.size());
 	ctx->fuse_resolve = true;
-	if (const char* e = getenv("SSX_FUSE_RESOLVE")) ctx->fuse_resolve = e[0] != '0';
-	return SSX_OK;
+	// the waves' level logs for the unit size this scene renders with: allocated here, once (the device is idle)
+	return ensure_logs(ctx, (unit_spp_of(ctx) + SSX_COHORT_KS - 1u) / SSX_COHORT_KS);
 }
 
 // `spp` = the samples per pixel actually accumulated (Options::spp, or fewer after ssx_render_stop)
@@ -706,6 +735,7 @@ void ssx_destroy(ssx_ctx* ctx) {
 	if (ctx->d_accum) (void)hipFree(ctx->d_accum);
 	if (ctx->d_unit_counter) (void)hipFree(ctx->d_unit_counter);
 	if (ctx->d_samples) (void)hipFree(ctx->d_samples);
+	if (ctx->d_logs) (void)hipFree(ctx->d_logs);
 	if (ctx->ev_device_done) (void)hipEventDestroy(ctx->ev_device_done);
 	if (ctx->d_out) (void)hipFree(ctx->d_out);
 	if (ctx->d_peer) (void)hipFree(ctx->d_peer);
@@ -1028,6 +1058,13 @@ int ssx_lanestat(unsigned long long* out, int reset) {
 	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lanestat), 2 * SSX_NSTAT * sizeof(unsigned long long));
 }
 #endif
+
+int ssx_scratch_info(ssx_ctx* ctx, uint64_t* sample_bytes, uint64_t* log_bytes) {
+	if (!ctx) return SSX_ERR_ARG;
+	if (sample_bytes) *sample_bytes = (uint64_t)ctx->sample_slots * kBytesPerSampleInFlight;
+	if (log_bytes) *log_bytes = (uint64_t)ctx->log_records * SSX_LOG_BYTES_PER_RECORD;
+	return SSX_OK;
+}
 
 int ssx_kernel_variant(ssx_ctx* ctx) { return (ctx && ctx->have_scene) ? (int)ctx->topology : -1; }
 

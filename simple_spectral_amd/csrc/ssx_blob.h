@@ -84,7 +84,7 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 };
 
 // Per-sample state in HBM.  Records r = [tile slot][k-k0][pixel in tile]; a wave's work unit (8x8 tile x
-// group_spp samples, <= 512 records) owns the contiguous records [rec_base, rec_base + 64*n_kq).
+// group_spp samples, <= 512 records) owns the contiguous records [rec_base, rec_base + 64*n_kq).  48 bytes per sample:
 //   ray[r]   float4  generate: {camera ray dir.xyz, lambda_0}; the fold overwrites it with {X, Y, Z, alpha}
 //                    ({R, G, B, alpha} in RGB mode), which the accumulate pass reads
 //   hit[r]   float4  generate: the camera ray's closest hit {dist, hitrec.st.x, .y, 2*quad + which as int bits (-1: none)}
@@ -92,24 +92,30 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 //                    state} (the final state = draws consumed, for the per-sample tests).  Tail word (D = number
 //                    of continued levels = the path's last level): hit_anything | level D has an emission term << 1
 //                    | D << 2 | slot of level D-1's entry << 6 | slot of level D's next-event term << 19
-//   direct[l*n + r] float4  level l's emission term (camera ray hitting a light; every hit in the non-ELS build):
-//                    written only where it exists (rare)
 // The levels of the recursion are NOT stored per record (paths have 0..9 levels, a [level][record] array is
 // read and written in 128-byte lines of which the deep levels use one record in three): they go to LOGS,
 // entries appended in the order the wave produces them, so that the stores of one wave iteration and the fold's
 // reads fill whole lines.  One log per array and COHORT = the SSX_COHORT_KS consecutive samples per pixel of a
-// unit that one pass of the fold takes (128 records starting at base_rec): a pass reads its cohort's logs
-// front to back, once.
-//   entry of a continued level l of some path, at index base_rec*9 + slot (slot < 9 * 128):
+// unit that one pass of the fold takes (SSX_COHORT_RECORDS = 128 samples): a pass reads its cohort's logs front to
+// back, once.  The logs are SCRATCH OF THE PERSISTENT WAVES, not of the samples: wave slot w (workgroup x wave of
+// the path kernel's grid) owns the log records
+//     [((2 w + unit tag) * unit_cohorts + cohort) * 128, ... + 128)        (log_region() in ssx_kernels.hip)
+// for the two units it can have in flight (tag = the unit's parity in the wave's own sequence) and their
+// unit_cohorts = ceil(group_spp / SSX_COHORT_KS) cohorts each; a unit's regions are reused by the wave's next unit
+// with the same tag, which starts only after this one is folded.  582 bytes per log record; with 4096 resident
+// waves and units of 4 (8) samples per pixel the logs are 1.2 (2.4) GB however many samples a launch renders.
+//   entry of a continued level l of some path, at index log_rec*9 + slot (slot < 9 * 128):
 //     fs[.]    float4  f_s of the continuation       } rad_l = (emission_l + nee_l) + ((rad_{l+1} * n_dot_l) * f_s) / pdf
 //     np[.]    float2  {n_dot_l, pdf}                }
 //     link[.]  uint32  slot of level l-1's entry | slot of level l's next-event term << 13 | level l has an emission
 //                      term << 26   (slots are 13-bit, SSX_NO_SLOT = none): the fold walks a path's chain from its tail
-//   nee[base_rec*10 + slot]  float4  a level's next-event term, slot appended when its shadow ray is parked.  Wide queue
+//   nee[log_rec*10 + slot]  float4  a level's next-event term, slot appended when its shadow ray is parked.  Wide queue
 //                    entries: written when the ray is traced, the contribution ((emitted*n_dot_l)*f_s)/pdf if the light is
 //                    visible, zeros if not.  Narrow entries: the contribution, written when the ray is parked, and
-//   vis[base_rec*10 + slot]  uint8   written when the ray is traced: 1 if the light is visible, 0 if not; the term is
+//   vis[log_rec*10 + slot]  uint8   written when the ray is traced: 1 if the light is visible, 0 if not; the term is
 //                    vis ? nee : 0.  (All write-only until the fold.)
+//   direct[log_rec*10 + l*128 + sample in cohort] float4  level l's emission term (camera ray hitting a light; every hit
+//                    in the non-ELS build): written only where it exists (rare)
 // Levels 0..MAX_DEPTH-2 can continue (0..MAX_DEPTH-3 with explicit light sampling), the last level of a path is
 // at most MAX_DEPTH-1: 10 levels of `direct` / `nee`, 9 of `fs` / `np` / `link`.
 #define SSX_MAX_FRAMES 9u
@@ -118,12 +124,14 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 #ifndef SSX_COHORT_KS
 #define SSX_COHORT_KS 2u          // samples per pixel in a cohort: 128 records, 13-bit slots (10 * 128 < SSX_NO_SLOT)
 #endif
+#define SSX_COHORT_RECORDS (64u * SSX_COHORT_KS)
 #ifndef SSX_MAX_UNIT_KS
 #define SSX_MAX_UNIT_KS 8u        // most samples per pixel in a work unit: four cohorts (the host picks 4 or 8 per scene, make_batch)
 #endif
 #define SSX_UNIT_COHORTS (SSX_MAX_UNIT_KS / SSX_COHORT_KS)  // a power of two
 #define SSX_WAVE_COUNTER_WORDS (4u * SSX_UNIT_COHORTS) // per wave, behind the shadow-ray queues: fill counts [unit tag 2][cohort][fs, nee]
-#define SSX_BYTES_PER_SAMPLE (16u + 16u + 16u + (2u * 16u + 1u) * SSX_MAX_LEVELS + (16u + 8u + 4u) * SSX_MAX_FRAMES + 6u) // 6: keeps the arrays 16-byte aligned
+#define SSX_BYTES_PER_SAMPLE (16u + 16u + 16u)         // ray, st, hit
+#define SSX_LOG_BYTES_PER_RECORD ((16u + 8u + 4u) * SSX_MAX_FRAMES + (16u + 16u + 1u) * SSX_MAX_LEVELS) // fs, np, link; nee, direct, vis
 
 struct SsxKernelArgs {
 	const uint32_t* blob;   // device copy of the scene blob
@@ -150,6 +158,7 @@ struct SsxKernelArgs {
 	uint64_t n_records;       // my_tiles * (k1-k0) * 64
 	uint32_t* unit_counter;   // next work unit of the path kernel's persistent waves (zeroed before the launch)
 	uint32_t rgb_mode;        // 1: RENDER_MODE_RGB (scene uplift == SSX_MODE_RGB): no wavelength draw, no XYZ, plain mean
-	uint32_t fuse_resolve;    // 1: the path kernel folds each unit's samples itself; 0: ssx_resolve_kernel does
+	uint32_t fuse_resolve;    // 1: the path kernel folds each unit's samples when the unit is complete; 0: no fold (calibration render: only the tail words are read)
+	uint32_t unit_cohorts;    // cohorts per unit = ceil(group_spp / SSX_COHORT_KS): stride of the waves' log regions
 	uint32_t queue_words;     // words per entry of the shadow-ray queues: SSX_QUEUE_WORDS_WIDE or _NARROW (see above)
 };

@@ -809,14 +809,27 @@ struct Path {
 // per pixel of its work unit that one pass of the fold takes (ssx_blob.h).  A wave has at most two units in flight
 // (the one it hands out items of, and the previous one, whose last paths are still running), each with up to four
 // cohorts; their fill counts live in the wave's LDS words `cnt` ([unit tag][cohort][fs, nee]) and a lane takes a
-// slot with one LDS atomic (the order of the slots within one wave iteration is immaterial).
+// slot with one LDS atomic (the order of the slots within one wave iteration is immaterial).  The logs themselves
+// live in a region of HBM that belongs to this WAVE SLOT (workgroup x wave of the persistent grid), unit tag and
+// cohort: log_region() -- recycled by the next unit with the same tag once this one is folded.
 struct LogRef {
-	uint32_t* cnt;      // this wave's 16 counters
-	uint32_t group;     // the lane's counter pair: SSX_UNIT_COHORTS * unit tag + cohort
-	uint32_t base_rec;  // first record of the lane's cohort: its logs start at base_rec * 9 (fs, np, link) / base_rec * 10 (nee)
+	uint32_t* cnt;       // this wave's 16 counters (wave-uniform)
+	uint32_t wave_base;  // wave slot * 2 * unit_cohorts: the wave's first log region (wave-uniform)
+	uint32_t tagw;       // the lane's tag word (render_body: p_tag): cohort | unit tag << 2 | region within the wave's regions << 3 | k within the cohort << 8
+	// nothing else per lane: what the appends need is derived from the tag word where it is needed (the light sampling between
+	// the start of path_step and its appends runs at the kernel's register limit)
+	__device__ __forceinline__ uint32_t group() const { return tagw & (2u * SSX_UNIT_COHORTS - 1u); } // the lane's counter pair: SSX_UNIT_COHORTS * unit tag + cohort
+	// first log record of the lane's cohort: its logs start at log_rec * 9 (fs, np, link) / log_rec * 10 (nee, vis, direct)
+	__device__ __forceinline__ uint32_t log_rec() const { return (wave_base + ((tagw >> 3) & 7u)) * SSX_COHORT_RECORDS; }
+	// the lane's sample within its cohort: k in the cohort << 6 | pixel of the tile
+	__device__ __forceinline__ uint32_t rc(uint32_t rec_index) const { return ((tagw >> 8) << 6) | (rec_index & 63u); }
 };
+// first log record of cohort `cohort` of the unit with tag `tag` this wave has in flight (ssx_blob.h)
+__device__ __forceinline__ uint32_t log_region(const SsxKernelArgs& a, uint32_t wave_slot, uint32_t tag, uint32_t cohort) {
+	return ((wave_slot * 2u + tag) * a.unit_cohorts + cohort) * SSX_COHORT_RECORDS;
+}
 __device__ __forceinline__ uint32_t log_append(const LogRef& lg, uint32_t which) {
-	return __hip_atomic_fetch_add(lg.cnt + 2u * lg.group + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+	return __hip_atomic_fetch_add(lg.cnt + 2u * lg.group() + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
 // renderer.cpp:113-138: camera ray (f64, as the reference) and hero wavelength of sample k of
@@ -910,7 +923,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 #pragma unroll
 		for (int k = 0; k < 4; ++k) direct[k] += em.v[k];
 		// the level's emission term, read back by the fold (levels without it have none: 0 + x == x)
-		a.direct[p.depth * (uint32_t)a.n_records + p.rec_index] = make_float4(direct[0], direct[1], direct[2], direct[3]); // < 2^32 per launch (host budget)
+		a.direct[lg.log_rec() * SSX_MAX_LEVELS + p.depth * SSX_COHORT_RECORDS + lg.rc(p.rec_index)] = make_float4(direct[0], direct[1], direct[2], direct[3]);
 		level_word |= 1u << 26;
 	}
 	// :178 `if (depth+1u<MAX_DEPTH)`: with ELS a ray at depth MAX_DEPTH-1 is never started (below);
@@ -949,7 +962,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 				const uint32_t slot = q.count + __builtin_amdgcn_mbcnt_hi((uint32_t)(pushing >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushing, 0u));
 				// the contribution's place in its cohort's log (parking order = flush order: a flush writes runs of consecutive bytes)
 				const uint32_t nslot = log_append(lg, 1u);
-				const uint32_t ni = lg.base_rec * SSX_MAX_LEVELS + nslot;
+				const uint32_t ni = lg.log_rec() * SSX_MAX_LEVELS + nslot;
 				if (NARROW) {
 					a.nee[ni] = make_float4(c[0], c[1], c[2], c[3]);
 					float4* E = q.e + 2u * slot;
@@ -998,7 +1011,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	// the factors of the continuation for the backward fold (resolve_record, when the wave's unit is complete)
 	SSX_STAT(12); // continuing lanes
 	const uint32_t slot = log_append(lg, 0u);
-	const uint32_t entry = lg.base_rec * SSX_MAX_FRAMES + slot;
+	const uint32_t entry = lg.log_rec() * SSX_MAX_FRAMES + slot;
 	a.fs[entry] = make_float4(f_s[0], f_s[1], f_s[2], f_s[3]);
 	a.np[entry] = make_float2(n_dot_l, pdf_w_i);
 	a.link[entry] = p.prev_slot | level_word;
@@ -1069,10 +1082,10 @@ __device__ __forceinline__ float4 nee_term(const SsxKernelArgs& a, uint32_t i, b
 	if (!NARROW) return c;
 	return make_float4(v ? c.x : 0.0f, v ? c.y : 0.0f, v ? c.z : 0.0f, v ? c.w : 0.0f);
 }
-// fs_base / nee_base: index of slot 0 of the cohort's logs (base_rec * 9, base_rec * 10)
+// fs_base / nee_base: index of slot 0 of the cohort's logs (log_rec * 9, log_rec * 10); rc0: the lane's pixel of the tile
+// (its first sample within the cohort; way s is sample rc0 + 64 s)
 template <uint32_t WAYS, bool NARROW>
-__device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count, uint32_t fs_base, uint32_t nee_base) {
-	const uint32_t n = (uint32_t)a.n_records;
+__device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count, uint32_t fs_base, uint32_t nee_base, uint32_t rc0) {
 	float rad[WAYS][4];
 	uint32_t depth[WAYS]; // hit_anything << 4 | number of continued levels
 	uint32_t K[WAYS]; // chain word of the level about to be folded: its entry's `link` (parent slot | nee slot << 13 | emission << 26)
@@ -1090,7 +1103,7 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 			at[s] = (y >> 6) & SSX_NO_SLOT;
 			// the last level's radiance: 0 + its emission term (if any) + its next-event term (if it parked a shadow ray)
 			const uint32_t ns = y >> 19;
-			const float4 last = ((y >> 1) & 1u) ? a.direct[dep * n + r0 + s * stride] : zero4;
+			const float4 last = ((y >> 1) & 1u) ? a.direct[nee_base + dep * SSX_COHORT_RECORDS + rc0 + s * 64u] : zero4;
 			const float4 ne = nee_term<NARROW>(a, nee_base + ns, ns != SSX_NO_SLOT);
 			if (dep) K[s] = a.link[fs_base + at[s]];
 			rad[s][0] = last.x + ne.x; rad[s][1] = last.y + ne.y; rad[s][2] = last.z + ne.z; rad[s][3] = last.w + ne.w;
@@ -1109,7 +1122,7 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 				const bool has_ne = ns != SSX_NO_SLOT;
 				D[s] = nee_term<NARROW>(a, nee_base + ns, has_ne);
 				if ((K[s] >> 26) & 1u) { // rare: an emission term below the last level (non-ELS build)
-					const float4 em = a.direct[d * n + r0 + s * stride];
+					const float4 em = a.direct[nee_base + d * SSX_COHORT_RECORDS + rc0 + s * 64u];
 					D[s] = has_ne ? make_float4(em.x + D[s].x, em.y + D[s].y, em.z + D[s].z, em.w + D[s].w) : em;
 				}
 				// the chain word of the level below, one round trip ahead of its use
@@ -1219,14 +1232,16 @@ __device__ __forceinline__ void unit_setup(const SsxKernelArgs& a, uint32_t unit
 // this wave wrote during the unit) overlap with the arithmetic of the other waves on the SIMD, which
 // a separate HBM-bound pass after the kernel could not (ssx_resolve_kernel: kept as an option, SSX_FUSE_RESOLVE=0).
 template <bool NARROW>
-__device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, const WorkUnit& u) {
+__device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, const WorkUnit& u, uint32_t wave_slot, uint32_t tag) {
 	// see "Memory-ordering contract" above: wait for this wave's stores, drop the CU's L1 lines
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	const uint32_t lane = threadIdx.x & 63u;
 	if ((lane & 7u) < u.tw && (lane >> 3) < u.th)
-		for (uint32_t kq = 0; kq < u.n_kq; kq += SSX_RESOLVE_WAYS)
-			resolve_records<SSX_RESOLVE_WAYS, NARROW>(L, a, u.rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, u.n_kq - kq), (u.rec_base + kq * 64u) * SSX_MAX_FRAMES, (u.rec_base + kq * 64u) * SSX_MAX_LEVELS); // one cohort per pass
+		for (uint32_t kq = 0; kq < u.n_kq; kq += SSX_RESOLVE_WAYS) { // one cohort per pass
+			const uint32_t log_rec = log_region(a, wave_slot, tag, kq / SSX_COHORT_KS);
+			resolve_records<SSX_RESOLVE_WAYS, NARROW>(L, a, u.rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, u.n_kq - kq), log_rec * SSX_MAX_FRAMES, log_rec * SSX_MAX_LEVELS, lane);
+		}
 }
 
 template <int TOPO, bool NARROW>
@@ -1235,6 +1250,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	Lds L; L.w = lds_words;
 
 	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t wave_slot = blockIdx.x * 4u + wave; // this wave's place in the persistent grid: owner of a region of the level logs
 	const uint32_t total_units = a.my_tiles * a.n_groups;
 	// the camera position from the blob's copy in HBM: wave-uniform scalar loads (SGPRs; LDS reads would hold three VGPRs for the whole kernel)
 	const SsxBlobHeader& hg = *reinterpret_cast<const SsxBlobHeader*>(a.blob);
@@ -1245,8 +1261,8 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	p.hit_tri = 0; p.hit_dist = 0.0f; p.hit_st_x = p.hit_st_y = 0.0f;
 	p.rng.state = 0; p.rng.inc = 1;
 	bool active = false;
-	uint32_t p_tag = 0; // which of the (at most two) units in flight the lane's sample belongs to, and its cohort there:
-	                    // unit tag | cohort << 1 | (sample's position in the cohort) << 8
+	uint32_t p_tag = 0; // which of the (at most two) units in flight the lane's sample belongs to, and its cohort there (LogRef::tagw):
+	                    // cohort | unit tag << 2 | (unit tag * unit_cohorts + cohort) << 3 | (sample's position in the cohort) << 8
 	constexpr uint32_t queue_words = SSX_QUEUE_ENTRIES * (NARROW ? SSX_QUEUE_WORDS_NARROW : SSX_QUEUE_WORDS_WIDE); // per wave (ssx_blob.h)
 	uint32_t* const log_cnt = lds_words + a.blob_words + 4u * queue_words + wave * SSX_WAVE_COUNTER_WORDS; // see LogRef
 	ShadowQ sq; // this wave's queue behind the blob (16-byte aligned: blob_words is a multiple of 4)
@@ -1255,8 +1271,8 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	// Persistent waves: units are fetched from a global counter, and the next unit's items are handed
 	// out as soon as the current one has none left -- its last paths finish alongside the new ones
 	// instead of on a draining wave (10 % of all wave iterations with one unit per wave).  `cur` feeds
-	// idle lanes; `old` is the previous unit, still waiting for its last lanes and then for its fold (when the
-	// fold is a kernel of its own, a.fuse_resolve == 0, `old` is tracked all the same: its lanes append to its logs).
+	// idle lanes; `old` is the previous unit, still waiting for its last lanes and then for its fold (a.fuse_resolve == 0,
+	// the calibration render, which only counts levels, skips the fold itself; `old` is tracked all the same).
 	WorkUnit cur, old;
 	bool cur_valid = false, old_pending = false, more = true;
 	uint32_t cur_tag = 0, old_tag = 0;
@@ -1286,8 +1302,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		if (active) {
 			SSX_STAT(13); // lanes with a path, per iteration
 			LogRef lg;
-			lg.cnt = log_cnt; lg.group = (p_tag & 1u) * SSX_UNIT_COHORTS + ((p_tag >> 1) & (SSX_UNIT_COHORTS - 1u));
-			lg.base_rec = (p.rec_index & ~63u) - ((p_tag >> 8) << 6);
+			lg.cnt = log_cnt; lg.wave_base = wave_slot * 2u * a.unit_cohorts; lg.tagw = p_tag;
 			uint32_t level_word;
 			if (!path_step<NARROW>(L, sq, a, lg, p, pushed, level_word)) end_path(level_word);
 		}
@@ -1296,7 +1311,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		// The parked shadow rays are traced a full wave at a time; all of them when the previous unit's last paths are
 		// done (some may be its: they must be in before its fold) or when nothing is running at all.  One call site:
 		// a flush inlines a whole trace.
-		const bool fold_old = old_pending && !__any(active && (p_tag & 1u) == old_tag);
+		const bool fold_old = old_pending && !__any(active && ((p_tag >> 2) & 1u) == old_tag);
 		const bool drain = (fold_old && a.fuse_resolve) || !busy;
 		while (sq.count >= SSX_SQ_FLUSH_AT || (drain && sq.count)) {
 			const uint32_t take = min(sq.count, 64u);
@@ -1304,7 +1319,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			shadow_flush<TOPO, NARROW>(L, a, sq, sq.count, take);
 		}
 		if (fold_old) {
-			if (a.fuse_resolve) unit_fold<NARROW>(L, a, old);
+			if (a.fuse_resolve) unit_fold<NARROW>(L, a, old, wave_slot, old_tag);
 			old_pending = false;
 		}
 		// rotate: the current unit has no items left and the previous one is folded
@@ -1359,7 +1374,8 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 					p.depth = 0;
 					p.prev_slot = SSX_NO_SLOT;
 					p.hit_dist = ht.x; p.hit_st_x = ht.y; p.hit_st_y = ht.z; p.hit_tri = __float_as_int(ht.w);
-					p_tag = cur_tag | ((kq / SSX_COHORT_KS) << 1) | ((kq % SSX_COHORT_KS) << 8);
+					const uint32_t cohort = kq / SSX_COHORT_KS;
+					p_tag = cohort | (cur_tag << 2) | ((cur_tag * a.unit_cohorts + cohort) << 3) | ((kq % SSX_COHORT_KS) << 8);
 					active = p.hit_tri >= 0; // a camera ray that left the scene: the sample was complete when it was generated
 				}
 			}
@@ -1390,29 +1406,6 @@ SSX_PATH_KERNEL(ssx_render_kernel_plane_nq, 2, true, SSX_WAVES_PER_EU)
 // kernel traces and statistics of ssx_render_kernel* contain real launches only.  Narrow queue entries: it stages the
 // whole blob, which may only fit with them.
 SSX_PATH_KERNEL(ssx_calibrate_kernel, 0, true, 3)
-
-// The fold as a pass of its own (one lane per sample, persistent blocks, streaming reads), used
-// instead of the path kernel's tail when SsxKernelArgs::fuse_resolve is 0.
-extern "C" __global__ void __launch_bounds__(256) ssx_resolve_kernel(SsxKernelArgs a) {
-	Lds L; L.w = stage_lds(a);
-	for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.n_records; r += (uint64_t)gridDim.x * blockDim.x) {
-		if (a.width % 8u != 0u || a.height % 8u != 0u) { // records of lanes outside a ragged image were never generated
-			const uint32_t lane = (uint32_t)(r & 63u);
-			const uint32_t n_k = a.k1 - a.k0;
-			const uint32_t slot = (uint32_t)((r >> 6) / n_k);
-			const uint32_t tile = a.tile_first + slot * a.tile_stride;
-			const uint32_t i = (tile % a.tiles_x) * 8u + (lane & 7u), j = (tile / a.tiles_x) * 8u + (lane >> 3);
-			if (i >= a.width || j >= a.height) continue;
-		}
-		// the cohort of record r (unit_setup, LogRef): records of one tile slot are k-major, units are groups of group_spp
-		// consecutive k, cohorts groups of SSX_COHORT_KS consecutive k of a unit
-		const uint32_t n_k = a.k1 - a.k0;
-		const uint32_t rk = (uint32_t)(r >> 6), kk = rk % n_k;
-		const uint32_t base_rec = (rk - (kk % a.group_spp) % SSX_COHORT_KS) * 64u; // first record of r's cohort
-		if (a.queue_words == SSX_QUEUE_WORDS_NARROW) resolve_records<1u, true>(L, a, (uint32_t)r, 0u, 1u, base_rec * SSX_MAX_FRAMES, base_rec * SSX_MAX_LEVELS);
-		else resolve_records<1u, false>(L, a, (uint32_t)r, 0u, 1u, base_rec * SSX_MAX_FRAMES, base_rec * SSX_MAX_LEVELS);
-	}
-}
 
 // Stage 3 of 3: one lane per pixel.  renderer.cpp:292-295: avg += sample*0.001f (float multiply,
 // widened) in ascending k -- the reference's accumulation order, whichever lane of the path

@@ -248,8 +248,14 @@ class Renderer:
         self._check(self._lib.ssx_plan_info(self._ctx, C.byref(f), C.byref(k)))
         variant = {0: "generic", 1: "cornell topology", 2: "plane topology"}.get(self._lib.ssx_kernel_variant(self._ctx), "?")
         name = self._lib.ssx_kernel_name(self._ctx)
-        return {"frames_per_sample": round(f.value, 3), "fold": "path kernel" if k.value else "resolve kernel", "pass1": variant,
+        return {"frames_per_sample": round(f.value, 3), "fold": "path kernel", "pass1": variant,
                 "kernel": name.decode() if name else None}
+
+    def scratch_info(self):
+        """Device scratch held: bytes of per-sample arrays (largest launch so far) and of the persistent waves' level logs."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.ssx_scratch_info(self._ctx, C.byref(a), C.byref(b)))
+        return {"sample_bytes": a.value, "log_bytes": b.value}
 
     def save(self, path):
         fb = np.ascontiguousarray(self.framebuffer, dtype=np.float32)
