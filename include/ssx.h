@@ -209,6 +209,11 @@ int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* s
  * the end of each wave's work unit inside the path kernel (the stand-alone fold kernel of earlier versions
  * is gone: the levels live in per-wave logs that are recycled while the kernel runs). */
 int ssx_plan_info(ssx_ctx* ctx, float* frames_per_sample, int* fold_in_path_kernel);
+/* More of what the calibration render found, and the choice made from it: rays per sample that left the scene (camera and
+ * continuation rays), and whether the camera rays are traced ahead of the path loop by the generate kernel (1: where at
+ * least ~0.3 rays per sample leave the scene, e.g. the open Cornell box) or inside it like every other ray (0).  A
+ * performance choice only: same bits.  The environment variable SSX_PRE_HITS=0/1 at upload overrides it. */
+int ssx_calibration_info(ssx_ctx* ctx, float* frames_per_sample, float* rays_left_per_sample, int* camera_rays_pretraced);
 /* Device scratch the context holds right now: the per-sample arrays of the largest launch so far (48 bytes per sample in
  * flight: camera ray / result, stream / tail word, camera hit) and the persistent waves' level logs (a fixed size per
  * device and unit size: wave slots x 2 units x cohorts x 128 records x 582 bytes). */

@@ -48,6 +48,8 @@ struct ssx_ctx {
 	bool rgb_mode = false;     // scene uploaded with uplift == SSX_MODE_RGB
 	bool fuse_resolve = true;  // false only during the calibration render (no fold: its tail words are read back)
 	float calib_frames = 0.0f; // frames per sample measured by the calibration render of ssx_upload_scene
+	float calib_left = 0.0f;   // rays per sample that left the scene in it (camera and continuation rays)
+	bool pre_hits = false;     // camera rays traced by the generate kernel (SsxKernelArgs::pre_hits): where calib_left pays for it
 	double* d_accum = nullptr;  size_t accum_pixels = 0;
 	uint32_t* d_unit_counter = nullptr; // work-unit counter of the path kernel's persistent waves
 	int resident_blocks = 0;            // 256-lane path-kernel workgroups the GPU holds at once
@@ -68,14 +70,11 @@ struct ssx_ctx {
 	int worker_rc = 0;
 	ssx_render_params cur{};
 
-	// resolve/accumulate of one batch run on aux_stream while the next batch's generate/path
-	// kernels run on the caller's stream (the former is HBM-bound, the latter VALU-bound)
-	hipStream_t aux_stream = nullptr;
-	hipEvent_t ev_start = nullptr, ev_front[2] = {}, ev_back[2] = {};
+	uint32_t* d_tile_done = nullptr; size_t tile_done_slots = 0; // per tile slot: samples per pixel accumulated in the running launch (ssx_blob.h)
 
 	// optional per-kernel timing (ssx_set_timing): events around each stage of each batch
 	bool timing = false;
-	std::vector<hipEvent_t> ev_pool;   // 6 per batch: gen0, gen1=path0, path1 | res0, res1=acc0, acc1
+	std::vector<hipEvent_t> ev_pool;   // 6 per batch: gen0, gen1=path0, path1 | three more that close the (empty) resolve and accumulate slots
 	size_t ev_used = 0;
 	float stage_ms[4] = { 0, 0, 0, 0 };
 
@@ -351,6 +350,7 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	a.seed = p->seed;
 	a.rgb_mode = ctx->rgb_mode ? 1u : 0u;
 	a.fuse_resolve = ctx->fuse_resolve ? 1u : 0u;
+	a.pre_hits = ctx->pre_hits ? 1u : 0u;
 	a.my_tiles = a.n_tiles > p->tile_first ? (a.n_tiles - p->tile_first + p->tile_stride - 1u) / p->tile_stride : 0u;
 	pl.lds_bytes = ((size_t)ctx->path_blob_words + SSX_LDS_PREFIX_WORDS) * 4;
 	size_t per_spp = (size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u * kBytesPerSampleInFlight;
@@ -390,6 +390,7 @@ int ensure_logs(ssx_ctx* ctx, uint32_t unit_cohorts) {
 		ctx->max_wave_slots = (uint32_t)prop.multiProcessorCount * 16u;
 	}
 	const size_t need = (size_t)ctx->max_wave_slots * 2u * unit_cohorts * SSX_COHORT_RECORDS;
+	if (need * SSX_LOG_BYTES_PER_RECORD >= ((size_t)1 << 32)) return fail(ctx, SSX_ERR_DEVICE, "level logs beyond 4 GiB: the kernels address them with 32-bit offsets");
 	if (ctx->log_records < need) {
 		// normally sized once per scene (calibrate); growing later must not pull the logs from under a queued render
 		if (ctx->d_logs) { SSX_HIP(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->d_logs); }
@@ -407,12 +408,7 @@ void bind_arrays(SsxKernelArgs& a, uint8_t* base, uint64_t cap, uint8_t* logs, u
 	a.ray = reinterpret_cast<float4*>(base);                      base += cap * 16u;
 	a.st = reinterpret_cast<uint4*>(base);                        base += cap * 16u;
 	a.hit = reinterpret_cast<float4*>(base);
-	a.fs = reinterpret_cast<float4*>(logs);                       logs += log_cap * 16u * SSX_MAX_FRAMES;
-	a.nee = reinterpret_cast<float4*>(logs);                      logs += log_cap * 16u * SSX_MAX_LEVELS;
-	a.direct = reinterpret_cast<float4*>(logs);                   logs += log_cap * 16u * SSX_MAX_LEVELS;
-	a.np = reinterpret_cast<float2*>(logs);                       logs += log_cap * 8u * SSX_MAX_FRAMES;
-	a.link = reinterpret_cast<uint32_t*>(logs);                   logs += log_cap * 4u * SSX_MAX_FRAMES;
-	a.vis = logs;
+	a.logs = logs; a.log_cap = (uint32_t)log_cap; // fs | nee | direct | np | link | vis (ssx_kernels.hip: log_fs ...)
 }
 
 // adds the stage durations of the recorded batches to ctx->stage_ms
@@ -444,9 +440,8 @@ int timing_events(ssx_ctx* ctx, hipEvent_t** out) {
 	return SSX_OK;
 }
 
-// One batch = samples [k0,k1) of every owned pixel, with its per-sample arrays at record offset
-// rec_off of the buffers.  front = generate -> path megakernel; back = resolve (fold + XYZ) ->
-// ordered f64 accumulation.
+// One batch = samples [k0,k1) of every owned pixel: generate (camera rays, and their hits where the scene pre-traces them) ->
+// path megakernel (every further level, the fold of the recursion, flux -> XYZ and the ordered binary64 pixel sums).
 struct Batch { SsxKernelArgs a; uint32_t units; uint64_t n_rec; hipEvent_t* tev; int rc; };
 
 // samples per pixel of a work unit for the uploaded scene (before make_batch halves it for small launches)
@@ -456,15 +451,13 @@ uint32_t unit_spp_of(const ssx_ctx* ctx) {
 	return g;
 }
 
-Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1, uint64_t rec_off) {
+Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1) {
 	Batch b{};
 	b.a = pl.args;
 	SsxKernelArgs& a = b.a;
 	const uint32_t n_k = k1 - k0;
 	a.k0 = k0; a.k1 = k1;
 	a.n_records = (uint64_t)a.my_tiles * n_k * 64u;
-	// rec_off = 0, or the first record of the second half of a double-buffered allocation: each half is a
-	// region of its own (capacity = records of a full batch >= this batch)
 	// Samples per pixel and unit.  Long paths (Cornell: 4 continued levels per sample) run best with 4 -- 256 items keep the
 	// refill busy, less of a unit's logs is in flight per wave, and short units balance the end of the launch: 3052 against
 	// 3016 Msamples/s with 8, 3031 with 2, 2899 with 16 (one box) --, short ones (plane-srgb: 1 level) with 8: 10.07 against
@@ -477,10 +470,11 @@ Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1, u
 	a.unit_cohorts = (a.group_spp + SSX_COHORT_KS - 1u) / SSX_COHORT_KS;
 	b.units = a.my_tiles * a.n_groups;
 	b.n_rec = a.n_records;
-	// rec_off = 0, or the first record of the second half of a double-buffered allocation: each half is a region of its own
-	// (capacity = records of a full batch >= this batch).  The logs are shared by all batches: path kernels run one after the other.
+	// sample arrays and logs are shared by all batches of a render: their kernels run one after the other in stream order
 	b.rc = ensure_logs(ctx, a.unit_cohorts);
-	if (b.rc == SSX_OK) bind_arrays(a, ctx->d_samples + rec_off * kBytesPerSampleInFlight, rec_off ? rec_off : a.n_records, ctx->d_logs, ctx->log_records);
+	if (b.rc == SSX_OK) bind_arrays(a, ctx->d_samples, a.n_records, ctx->d_logs, ctx->log_records);
+	a.accum = ctx->d_accum;
+	a.tile_done = ctx->d_tile_done;
 	return b;
 }
 
@@ -532,7 +526,7 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[1], stream));
 	// persistent waves: as many workgroups as the GPU holds at once (or fewer, for a small launch); they
 	// fetch work units from a counter
-	if (!ctx->d_unit_counter) SSX_HIP(ctx, hipMalloc((void**)&ctx->d_unit_counter, sizeof(uint32_t)));
+	if (!ctx->d_unit_counter) SSX_HIP(ctx, hipMalloc((void**)&ctx->d_unit_counter, 2 * sizeof(uint32_t))); // [1]: rays that left the scene (calibration render)
 	if (ctx->resident_blocks == 0 || calibration) {
 		int per_cu = 0;
 		hipDeviceProp_t prop;
@@ -549,7 +543,15 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	b.a.queue_words = ctx->queue_words;
 	const size_t path_lds = path_lds_bytes(b.a.blob_words, b.a.queue_words);
 	auto path_kernel = path_kernel_of(ctx->topology, b.a.queue_words == SSX_QUEUE_WORDS_NARROW);
-	SSX_HIP(ctx, hipMemsetAsync(ctx->d_unit_counter, 0, sizeof(uint32_t), stream));
+	SSX_HIP(ctx, hipMemsetAsync(ctx->d_unit_counter, 0, 2 * sizeof(uint32_t), stream));
+	if (ctx->tile_done_slots < b.a.my_tiles) { // (grown here, synchronously: the first launch of a larger image)
+		if (ctx->d_tile_done) { SSX_HIP(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->d_tile_done); }
+		ctx->d_tile_done = nullptr; ctx->tile_done_slots = 0;
+		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_tile_done, (size_t)b.a.my_tiles * sizeof(uint32_t)));
+		ctx->tile_done_slots = b.a.my_tiles;
+	}
+	b.a.tile_done = ctx->d_tile_done;
+	SSX_HIP(ctx, hipMemsetAsync(ctx->d_tile_done, 0, (size_t)b.a.my_tiles * sizeof(uint32_t), stream));
 	b.a.unit_counter = ctx->d_unit_counter;
 	const uint32_t want_blocks = (b.units + 3u) / 4u;
 	uint32_t blocks = want_blocks < (uint32_t)ctx->resident_blocks ? want_blocks : (uint32_t)ctx->resident_blocks;
@@ -557,54 +559,24 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	hipLaunchKernelGGL(calibration ? ssx_calibrate_kernel : path_kernel, dim3(blocks), dim3(256), path_lds, stream, b.a);
 	SSX_HIP(ctx, hipGetLastError());
 	if (calibration) ctx->resident_blocks = 0; // computed for the calibration kernel: recompute for the path kernel
-	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[2], stream));
+	if (ctx->timing) for (int k = 2; k < 6; ++k) SSX_HIP(ctx, hipEventRecord(b.tev[k], stream)); // (fold and pixel sums ran inside the path kernel: their slots stay ~0)
 	return SSX_OK;
 }
 
-int enqueue_back(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stream) {
-	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[3], stream));
-	// (the fold of the recursion ran inside the path kernel; the "resolve" timing slot stays ~0)
-	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[4], stream));
-	hipLaunchKernelGGL(ssx_accumulate_kernel, dim3((b.a.my_tiles * 64u + 255u) / 256u), dim3(256), 0, stream, b.a, ctx->d_accum);
-	SSX_HIP(ctx, hipGetLastError());
-	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[5], stream));
-	return SSX_OK;
-}
-
-// everything in stream order (used by the asynchronous worker, which synchronises per chunk anyway)
+// samples [k0, k1) of every owned pixel, in stream order
 int launch_range(ssx_ctx* ctx, LaunchPlan& pl, uint32_t k0, uint32_t k1, hipStream_t stream) {
 	if (pl.args.my_tiles == 0 || k1 <= k0) return SSX_OK;
-	Batch b = make_batch(ctx, pl, k0, k1, 0);
-	int rc = enqueue_front(ctx, pl, b, stream);
-	if (rc) return rc;
-	return enqueue_back(ctx, pl, b, stream);
+	Batch b = make_batch(ctx, pl, k0, k1);
+	return enqueue_front(ctx, pl, b, stream);
 }
 
-// Samples [0,spp) in batches of `batch` spp, double-buffered: the back half of batch i (HBM-bound)
-// runs on ctx->aux_stream concurrently with the front half of batch i+1 (VALU-bound) on `stream`.
-// Accumulation order is preserved because the back halves execute in batch order on one stream.
-int launch_pipelined(ssx_ctx* ctx, LaunchPlan& pl, uint32_t spp, uint32_t batch, hipStream_t stream) {
-	if (pl.args.my_tiles == 0) return SSX_OK;
-	const uint64_t half = (uint64_t)pl.args.my_tiles * 64u * batch; // records per buffer half
-	if (!ctx->aux_stream) SSX_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-	auto mk = [&](hipEvent_t& e) -> int { if (!e) SSX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); return SSX_OK; };
-	int rc;
-	if ((rc = mk(ctx->ev_start)) || (rc = mk(ctx->ev_front[0])) || (rc = mk(ctx->ev_front[1])) || (rc = mk(ctx->ev_back[0])) || (rc = mk(ctx->ev_back[1]))) return rc;
-	SSX_HIP(ctx, hipEventRecord(ctx->ev_start, stream));          // orders aux after the caller's earlier work (accum memset)
-	SSX_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_start, 0));
-	uint32_t n = 0;
-	for (uint32_t k0 = 0; k0 < spp; k0 += batch, ++n) {
-		const uint32_t k1 = (spp - k0 < batch) ? spp : k0 + batch;
-		const uint32_t h = n & 1u;
-		if (n >= 2) SSX_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_back[h], 0)); // this half's previous tenant is resolved
-		Batch b = make_batch(ctx, pl, k0, k1, h * half);
-		if ((rc = enqueue_front(ctx, pl, b, stream))) return rc;
-		SSX_HIP(ctx, hipEventRecord(ctx->ev_front[h], stream));
-		SSX_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_front[h], 0));
-		if ((rc = enqueue_back(ctx, pl, b, ctx->aux_stream))) return rc;
-		SSX_HIP(ctx, hipEventRecord(ctx->ev_back[h], ctx->aux_stream));
+// Samples [0,spp) in batches of `batch` spp, back to back on `stream`: the pixel sums continue from batch to batch
+// (SsxKernelArgs::accum), the sample arrays and logs are reused.
+int launch_batches(ssx_ctx* ctx, LaunchPlan& pl, uint32_t spp, uint32_t batch, hipStream_t stream) {
+	for (uint32_t k0 = 0; k0 < spp; k0 += batch) {
+		int rc = launch_range(ctx, pl, k0, (spp - k0 < batch) ? spp : k0 + batch, stream);
+		if (rc) return rc;
 	}
-	if (n) SSX_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_back[(n - 1) & 1u], 0)); // aux is serial: the last back half ends last
 	return SSX_OK;
 }
 
@@ -615,10 +587,11 @@ int calibrate(ssx_ctx* ctx) {
 	ssx_render_params cp{};
 	cp.struct_size = sizeof cp; cp.width = 64; cp.height = 64; cp.spp = 4; cp.tile_stride = 1;
 	ctx->fuse_resolve = false; // no fold: st[] keeps {lambda_0, tail word, ...}, the level counts are read back below
+	ctx->pre_hits = false;     // camera rays in the path loop: every ray that leaves the scene is counted there
 	LaunchPlan pl = make_plan(ctx, &cp);
 	int rc = ensure_samples(ctx, pl, cp.spp);
 	if (rc) return rc;
-	Batch b = make_batch(ctx, pl, 0, cp.spp, 0);
+	Batch b = make_batch(ctx, pl, 0, cp.spp);
 	const int timing = ctx->timing; ctx->timing = 0;
 	rc = enqueue_front(ctx, pl, b, ctx->stream, true);
 	ctx->timing = timing;
@@ -629,6 +602,14 @@ int calibrate(ssx_ctx* ctx) {
 	uint64_t frames = 0;
 	for (const uint4& r : recs) frames += (r.y >> 2) & 0xFu;
 	ctx->calib_frames = (float)((double)frames / (double)recs.size());
+	uint32_t counters[2] = { 0u, 0u };
+	SSX_HIP(ctx, hipMemcpy(counters, ctx->d_unit_counter, sizeof counters, hipMemcpyDeviceToHost));
+	ctx->calib_left = (float)((double)counters[1] / (double)recs.size());
+	// Tracing the camera rays ahead of the path loop (ssx_generate_kernel*) costs one coherent trace per sample (~650 wave
+	// instructions per 64 samples) and saves, per ray that leaves the scene, the lane-iteration such a ray otherwise idles
+	// through (a trace + a shading, ~2300 per 64 lanes): it pays from ~0.3 such rays per sample (Cornell box: 0.87; plane-srgb: 0).
+	ctx->pre_hits = ctx->calib_left >= 0.3f;
+	if (const char* e = getenv("SSX_PRE_HITS")) ctx->pre_hits = e[0] != '0'; // A/B runs and tests
 	ctx->fuse_resolve = true;
 	// the waves' level logs for the unit size this scene renders with: allocated here, once (the device is idle)
 	return ensure_logs(ctx, (unit_spp_of(ctx) + SSX_COHORT_KS - 1u) / SSX_COHORT_KS);
@@ -740,8 +721,7 @@ void ssx_destroy(ssx_ctx* ctx) {
 	if (ctx->d_out) (void)hipFree(ctx->d_out);
 	if (ctx->d_peer) (void)hipFree(ctx->d_peer);
 	for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-	for (hipEvent_t e : { ctx->ev_start, ctx->ev_front[0], ctx->ev_front[1], ctx->ev_back[0], ctx->ev_back[1] }) if (e) (void)hipEventDestroy(e);
-	if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+	if (ctx->d_tile_done) (void)hipFree(ctx->d_tile_done);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -850,18 +830,12 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	if ((rc = ensure_buffers(ctx, pixels, false))) return rc;
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, pixels * 4 * sizeof(double), stream));
 	LaunchPlan pl = make_plan(ctx, p);
-	// One batch when the whole render fits the buffer budget (measured best: the path kernel fills
-	// every SIMD's register file, so a concurrently enqueued resolve kernel only runs in its tail
-	// anyway); otherwise double-buffered batches of half the budget each.
+	// one batch when the whole render fits the buffer budget, else batches back to back
 	uint32_t batch = p->spp_per_launch ? p->spp_per_launch : p->spp;
 	if (batch > p->spp) batch = p->spp;
 	if (batch > pl.max_spp_per_launch) batch = pl.max_spp_per_launch;
-	if (batch < p->spp) {
-		const uint32_t cap = pl.max_spp_per_launch / 2u ? pl.max_spp_per_launch / 2u : 1u;
-		if (batch > cap) batch = cap;
-	}
-	if ((rc = ensure_samples(ctx, pl, batch * (batch < p->spp ? 2u : 1u)))) return rc;
-	if ((rc = launch_pipelined(ctx, pl, p->spp, batch, stream))) return rc;
+	if ((rc = ensure_samples(ctx, pl, batch))) return rc;
+	if ((rc = launch_batches(ctx, pl, p->spp, batch, stream))) return rc;
 	if ((rc = launch_finalize(ctx, p, p->spp, (float*)d_xyza_out, stream))) return rc;
 	SSX_HIP(ctx, hipEventRecord(ctx->ev_device_done, stream));
 	ctx->device_pending = true;
@@ -1030,9 +1004,9 @@ int ssx_debug_samples(ssx_ctx* ctx, const ssx_render_params* p, float* xyza, uin
 	if (p->spp > pl.max_spp_per_launch) return fail(ctx, SSX_ERR_ARG, "ssx_debug_samples: too many samples for one launch");
 	if ((rc = ensure_samples(ctx, pl, p->spp))) return rc;
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, pixels * 4 * sizeof(double), ctx->stream));
-	Batch b = make_batch(ctx, pl, 0, p->spp, 0);
+	Batch b = make_batch(ctx, pl, 0, p->spp);
+	b.a.keep_samples = 1u; // the fold leaves every sample's {X, Y, Z, alpha} in ray[]
 	if ((rc = enqueue_front(ctx, pl, b, ctx->stream))) return rc;
-	if ((rc = enqueue_back(ctx, pl, b, ctx->stream))) return rc; // fold (if not fused) + accumulate: ray[] holds XYZA afterwards
 	SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	std::vector<float4> ray((size_t)b.n_rec);
 	std::vector<uint4> st((size_t)b.n_rec);
@@ -1058,6 +1032,15 @@ int ssx_lanestat(unsigned long long* out, int reset) {
 	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lanestat), 2 * SSX_NSTAT * sizeof(unsigned long long));
 }
 #endif
+
+int ssx_calibration_info(ssx_ctx* ctx, float* frames_per_sample, float* rays_left_per_sample, int* camera_rays_pretraced) {
+	if (!ctx) return SSX_ERR_ARG;
+	if (!ctx->have_scene) return fail(ctx, SSX_ERR_STATE, "no scene uploaded");
+	if (frames_per_sample) *frames_per_sample = ctx->calib_frames;
+	if (rays_left_per_sample) *rays_left_per_sample = ctx->calib_left;
+	if (camera_rays_pretraced) *camera_rays_pretraced = ctx->pre_hits ? 1 : 0;
+	return SSX_OK;
+}
 
 int ssx_scratch_info(ssx_ctx* ctx, uint64_t* sample_bytes, uint64_t* log_bytes) {
 	if (!ctx) return SSX_ERR_ARG;

@@ -85,8 +85,8 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 
 // Per-sample state in HBM.  Records r = [tile slot][k-k0][pixel in tile]; a wave's work unit (8x8 tile x
 // group_spp samples, <= 512 records) owns the contiguous records [rec_base, rec_base + 64*n_kq).  48 bytes per sample:
-//   ray[r]   float4  generate: {camera ray dir.xyz, lambda_0}; the fold overwrites it with {X, Y, Z, alpha}
-//                    ({R, G, B, alpha} in RGB mode), which the accumulate pass reads
+//   ray[r]   float4  generate: {camera ray dir.xyz, lambda_0} (ssx_debug_samples: the fold overwrites it with the sample's
+//                    {X, Y, Z, alpha}; a render adds the sample to its pixel's sum in the fold and writes nothing here)
 //   hit[r]   float4  generate: the camera ray's closest hit {dist, hitrec.st.x, .y, 2*quad + which as int bits (-1: none)}
 //   st[r]    uint4   generate: PCG32 {state, inc}; at the end of the path: {lambda_0 bits, tail word, final PCG32
 //                    state} (the final state = draws consumed, for the per-sample tests).  Tail word (D = number
@@ -149,16 +149,17 @@ struct SsxKernelArgs {
 	float4* ray;              // per-sample arrays, see above
 	uint4* st;
 	float4* hit;
-	float4* direct;
-	float4* nee;
-	float4* fs;
-	float2* np;
-	uint32_t* link;
-	uint8_t* vis;
+	uint8_t* logs;            // the waves' level logs: fs | nee | direct | np | link | vis, each for log_cap log records (accessors in ssx_kernels.hip)
+	uint32_t log_cap;
 	uint64_t n_records;       // my_tiles * (k1-k0) * 64
 	uint32_t* unit_counter;   // next work unit of the path kernel's persistent waves (zeroed before the launch)
 	uint32_t rgb_mode;        // 1: RENDER_MODE_RGB (scene uplift == SSX_MODE_RGB): no wavelength draw, no XYZ, plain mean
 	uint32_t fuse_resolve;    // 1: the path kernel folds each unit's samples when the unit is complete; 0: no fold (calibration render: only the tail words are read)
 	uint32_t unit_cohorts;    // cohorts per unit = ceil(group_spp / SSX_COHORT_KS): stride of the waves' log regions
+	double* accum;            // per pixel 4 x binary64: the running sums of _render_pixel (renderer.cpp:292-295), continued across launches
+	uint32_t* tile_done;      // per tile slot: samples per pixel added to accum in this launch (zeroed before the launch): units of a tile take turns in k order
+	uint32_t keep_samples;    // 1: the fold also writes each sample's {X, Y, Z, alpha} to ray[] (ssx_debug_samples)
+	uint32_t pre_hits;        // 1: ssx_generate_kernel* traces the camera rays (hit[] valid, the path loop starts every sample at its first
+	                          // hit); 0: camera rays are traced in the path loop like any other ray (scenes whose rays rarely leave the scene)
 	uint32_t queue_words;     // words per entry of the shadow-ray queues: SSX_QUEUE_WORDS_WIDE or _NARROW (see above)
 };

@@ -805,6 +805,15 @@ struct Path {
 	float hit_st_x, hit_st_y; // hitrec.st (geometry.cpp:91-95), evaluated where the quad's albedo is a texture (its only reader)
 };
 
+// The waves' level logs (ssx_blob.h) are one allocation below 4 GiB: one base pointer (an SGPR pair) and 32-bit byte offsets
+// -- six separate array pointers cost twelve SGPRs in a kernel that has none to spare.  i = index into the array.
+__device__ __forceinline__ float4& log_fs(const SsxKernelArgs& a, uint32_t i) { return *reinterpret_cast<float4*>(a.logs + i * 16u); }
+__device__ __forceinline__ float4& log_nee(const SsxKernelArgs& a, uint32_t i) { return *reinterpret_cast<float4*>(a.logs + (a.log_cap * (16u * SSX_MAX_FRAMES) + i * 16u)); }
+__device__ __forceinline__ float4& log_direct(const SsxKernelArgs& a, uint32_t i) { return *reinterpret_cast<float4*>(a.logs + (a.log_cap * (16u * SSX_MAX_FRAMES + 16u * SSX_MAX_LEVELS) + i * 16u)); }
+__device__ __forceinline__ float2& log_np(const SsxKernelArgs& a, uint32_t i) { return *reinterpret_cast<float2*>(a.logs + (a.log_cap * (16u * SSX_MAX_FRAMES + 32u * SSX_MAX_LEVELS) + i * 8u)); }
+__device__ __forceinline__ uint32_t& log_link(const SsxKernelArgs& a, uint32_t i) { return *reinterpret_cast<uint32_t*>(a.logs + (a.log_cap * (24u * SSX_MAX_FRAMES + 32u * SSX_MAX_LEVELS) + i * 4u)); }
+__device__ __forceinline__ uint8_t& log_vis(const SsxKernelArgs& a, uint32_t i) { return a.logs[a.log_cap * (28u * SSX_MAX_FRAMES + 32u * SSX_MAX_LEVELS) + i]; }
+
 // Where the lane's path appends its level entries: the logs of its COHORT -- the SSX_COHORT_KS consecutive samples
 // per pixel of its work unit that one pass of the fold takes (ssx_blob.h).  A wave has at most two units in flight
 // (the one it hands out items of, and the previous one, whose last paths are still running), each with up to four
@@ -923,7 +932,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 #pragma unroll
 		for (int k = 0; k < 4; ++k) direct[k] += em.v[k];
 		// the level's emission term, read back by the fold (levels without it have none: 0 + x == x)
-		a.direct[lg.log_rec() * SSX_MAX_LEVELS + p.depth * SSX_COHORT_RECORDS + lg.rc(p.rec_index)] = make_float4(direct[0], direct[1], direct[2], direct[3]);
+		log_direct(a, lg.log_rec() * SSX_MAX_LEVELS + p.depth * SSX_COHORT_RECORDS + lg.rc(p.rec_index)) = make_float4(direct[0], direct[1], direct[2], direct[3]);
 		level_word |= 1u << 26;
 	}
 	// :178 `if (depth+1u<MAX_DEPTH)`: with ELS a ray at depth MAX_DEPTH-1 is never started (below);
@@ -964,7 +973,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 				const uint32_t nslot = log_append(lg, 1u);
 				const uint32_t ni = lg.log_rec() * SSX_MAX_LEVELS + nslot;
 				if (NARROW) {
-					a.nee[ni] = make_float4(c[0], c[1], c[2], c[3]);
+					log_nee(a, ni) = make_float4(c[0], c[1], c[2], c[3]);
 					float4* E = q.e + 2u * slot;
 					E[0] = make_float4(hit_pos.x, hit_pos.y, hit_pos.z, sdir.x);
 					E[1] = make_float4(sdir.y, sdir.z, __uint_as_float((light << 8) | hq), __uint_as_float(ni));
@@ -1012,9 +1021,9 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	SSX_STAT(12); // continuing lanes
 	const uint32_t slot = log_append(lg, 0u);
 	const uint32_t entry = lg.log_rec() * SSX_MAX_FRAMES + slot;
-	a.fs[entry] = make_float4(f_s[0], f_s[1], f_s[2], f_s[3]);
-	a.np[entry] = make_float2(n_dot_l, pdf_w_i);
-	a.link[entry] = p.prev_slot | level_word;
+	log_fs(a, entry) = make_float4(f_s[0], f_s[1], f_s[2], f_s[3]);
+	log_np(a, entry) = make_float2(n_dot_l, pdf_w_i);
+	log_link(a, entry) = p.prev_slot | level_word;
 	p.prev_slot = slot;
 	p.orig = hit_pos; p.dir = w_i; p.ignore = (int)hq;
 	++p.depth;
@@ -1039,8 +1048,8 @@ __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& 
 	trace<TOPO>(L, mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y), (int)(tag & 0xFFu), have, sh, 2);
 	if (have) {
 		const bool visible = sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == (tag >> 8);
-		if (narrow) a.vis[__float_as_uint(e2.w)] = visible ? (uint8_t)1 : (uint8_t)0;
-		else a.nee[__float_as_uint(e2.w)] = visible ? make_float4(e1.z, e1.w, e2.x, e2.y) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (narrow) log_vis(a, __float_as_uint(e2.w)) = visible ? (uint8_t)1 : (uint8_t)0;
+		else log_nee(a, __float_as_uint(e2.w)) = visible ? make_float4(e1.z, e1.w, e2.x, e2.y) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	}
 }
 
@@ -1060,7 +1069,7 @@ __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& 
 // Backward fold of the recursion for finished samples (renderer.cpp:247: radiance += L(next) *
 // n_dot_l * f_s / pdf, evaluated innermost first = the reference's post-order) over the levels the
 // path recorded, then flux -> CIE XYZ (util/color.hpp:115-139; FLAT_FIELD_CORRECTION: flux =
-// radiance, renderer.cpp:262-263).  ray[r] becomes {X, Y, Z, alpha} ({R, G, B, alpha} in RGB mode).
+// radiance, renderer.cpp:262-263), and the sample {X, Y, Z, alpha} ({R, G, B, alpha} in RGB mode) is added to the lane's pixel sum `acc`.
 // A record's levels are a chain through its unit's log: the tail word names the entry of the last continued
 // level, every entry's `link` names the entry below and the level's own next-event term, and the chain word of
 // the next level is fetched one round trip ahead, so a level costs one round trip.  SSX_RESOLVE_WAYS records of the
@@ -1069,6 +1078,9 @@ __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& 
 #define SSX_RESOLVE_WAYS SSX_COHORT_KS // measured: 4 ways spill 13 VGPRs in the path loop (-1.3 %), 3: +2.4 %, 2: +2.7 % (one box, r02t)
 #endif
 static_assert(SSX_RESOLVE_WAYS == SSX_COHORT_KS, "a pass of the fold takes one cohort");
+// accesses to the pixel sums, which waves on different XCDs hand to each other (unit_fold): performed at the device's point of coherence
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // a level's next-event term where the level parked a shadow ray, else 0: nee[i] as the flush wrote it (wide queue
 // entries), or vis ? nee : 0 (narrow entries; both loads in flight together)
 template <bool NARROW>
@@ -1076,8 +1088,8 @@ __device__ __forceinline__ float4 nee_term(const SsxKernelArgs& a, uint32_t i, b
 	uint32_t v = 1u;
 	float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	if (has) {
-		if (NARROW) v = a.vis[i];
-		c = a.nee[i];
+		if (NARROW) v = log_vis(a, i);
+		c = log_nee(a, i);
 	}
 	if (!NARROW) return c;
 	return make_float4(v ? c.x : 0.0f, v ? c.y : 0.0f, v ? c.z : 0.0f, v ? c.w : 0.0f);
@@ -1085,7 +1097,7 @@ __device__ __forceinline__ float4 nee_term(const SsxKernelArgs& a, uint32_t i, b
 // fs_base / nee_base: index of slot 0 of the cohort's logs (log_rec * 9, log_rec * 10); rc0: the lane's pixel of the tile
 // (its first sample within the cohort; way s is sample rc0 + 64 s)
 template <uint32_t WAYS, bool NARROW>
-__device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count, uint32_t fs_base, uint32_t nee_base, uint32_t rc0) {
+__device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count, uint32_t fs_base, uint32_t nee_base, uint32_t rc0, double* px) {
 	float rad[WAYS][4];
 	uint32_t depth[WAYS]; // hit_anything << 4 | number of continued levels
 	uint32_t K[WAYS]; // chain word of the level about to be folded: its entry's `link` (parent slot | nee slot << 13 | emission << 26)
@@ -1103,9 +1115,10 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 			at[s] = (y >> 6) & SSX_NO_SLOT;
 			// the last level's radiance: 0 + its emission term (if any) + its next-event term (if it parked a shadow ray)
 			const uint32_t ns = y >> 19;
-			const float4 last = ((y >> 1) & 1u) ? a.direct[nee_base + dep * SSX_COHORT_RECORDS + rc0 + s * 64u] : zero4;
+			float4 last = zero4;
+			if ((y >> 1) & 1u) last = log_direct(a, nee_base + dep * SSX_COHORT_RECORDS + rc0 + s * 64u);
 			const float4 ne = nee_term<NARROW>(a, nee_base + ns, ns != SSX_NO_SLOT);
-			if (dep) K[s] = a.link[fs_base + at[s]];
+			if (dep) K[s] = log_link(a, fs_base + at[s]);
 			rad[s][0] = last.x + ne.x; rad[s][1] = last.y + ne.y; rad[s][2] = last.z + ne.z; rad[s][3] = last.w + ne.w;
 			top = max(top, dep);
 		}
@@ -1116,18 +1129,18 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 		for (uint32_t s = 0; s < WAYS; ++s)
 			if (d < (depth[s] & 0xFu)) {
 				const uint32_t i = fs_base + at[s];
-				F[s] = a.fs[i]; NP[s] = a.np[i];
+				F[s] = log_fs(a, i); NP[s] = log_np(a, i);
 				// emission + next-event term, the order of renderer.cpp:171,216 (0 + x == x where a term is absent)
 				const uint32_t ns = (K[s] >> 13) & SSX_NO_SLOT;
 				const bool has_ne = ns != SSX_NO_SLOT;
 				D[s] = nee_term<NARROW>(a, nee_base + ns, has_ne);
 				if ((K[s] >> 26) & 1u) { // rare: an emission term below the last level (non-ELS build)
-					const float4 em = a.direct[nee_base + d * SSX_COHORT_RECORDS + rc0 + s * 64u];
+					const float4 em = log_direct(a, nee_base + d * SSX_COHORT_RECORDS + rc0 + s * 64u);
 					D[s] = has_ne ? make_float4(em.x + D[s].x, em.y + D[s].y, em.z + D[s].z, em.w + D[s].w) : em;
 				}
 				// the chain word of the level below, one round trip ahead of its use
 				at[s] = K[s] & SSX_NO_SLOT;
-				if (d) K[s] = a.link[fs_base + at[s]];
+				if (d) K[s] = log_link(a, fs_base + at[s]);
 			}
 #pragma unroll
 		for (uint32_t s = 0; s < WAYS; ++s)
@@ -1141,6 +1154,8 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 				rad[s][3] = D[s].w + ssx_exact::div64_by((rad[s][3] * NP[s].x) * F[s].w, pdf_recip);
 			}
 	}
+	// the pixel's running sums (unit_fold): loaded here, behind the chain walk, whose registers they would otherwise take
+	double acc[4] = { ld_agent(px), ld_agent(px + 1), ld_agent(px + 2), ld_agent(px + 3) };
 #pragma unroll
 	for (uint32_t s = 0; s < WAYS; ++s)
 		if (s < count) {
@@ -1149,8 +1164,15 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 			float xyz[3];
 			if (a.rgb_mode) { xyz[0] = rad[s][0]; xyz[1] = rad[s][1]; xyz[2] = rad[s][2]; } // renderer.cpp:274-276: lRGB_A_F32(pixel_flux_est, hit)
 			else flux_to_xyz(L, flux, __uint_as_float(a.st[r0 + s * stride].x), xyz); // lambda_0 (re-read: a register per way less across the chain walk)
-			a.ray[r0 + s * stride] = make_float4(xyz[0], xyz[1], xyz[2], (depth[s] >> 4) ? 1.0f : 0.0f);
+			const float alpha = (depth[s] >> 4) ? 1.0f : 0.0f;
+			// _render_pixel (renderer.cpp:292-295): avg += sample * 0.001f -- a float multiply of all four components, widened, added
+			// in binary64 -- in ascending k: the ways are consecutive k, the passes of a unit ascend, and the units of a tile take
+			// turns in k order (unit_fold).  RENDER_MODE_RGB (:301-303) adds the sample as it is.
+			if (a.rgb_mode) { acc[0] += (double)xyz[0]; acc[1] += (double)xyz[1]; acc[2] += (double)xyz[2]; acc[3] += (double)alpha; }
+			else { acc[0] += (double)(xyz[0] * 0.001f); acc[1] += (double)(xyz[1] * 0.001f); acc[2] += (double)(xyz[2] * 0.001f); acc[3] += (double)(alpha * 0.001f); }
+			if (a.keep_samples) a.ray[r0 + s * stride] = make_float4(xyz[0], xyz[1], xyz[2], alpha); // ssx_debug_samples: what _render_sample returns
 		}
+	st_agent(px, acc[0]); st_agent(px + 1, acc[1]); st_agent(px + 2, acc[2]); st_agent(px + 3, acc[3]);
 }
 
 } // namespace
@@ -1165,6 +1187,9 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 //   hit[r] = {dist, st.x, st.y, 2*quad + which as int bits (-1: the ray left the scene)}
 // A sample whose camera ray hits nothing is complete: st[r] gets its end-of-path form at once ({lambda_0, tail word with
 // no hit and no levels, final PCG32 state}) and the path kernel never runs it; the fold turns it into {0, 0, 0, 0}.
+// That is the rule where rays leave the scene often enough to pay for the extra trace (the Cornell box: 0.87 rays per sample
+// leave through the open front); where they do not (plane-srgb: none), SsxKernelArgs::pre_hits is 0, this kernel writes
+// ray[] and st[] only, and the path loop traces a camera ray like any other ray (ssx_upload_scene decides: calibrate()).
 // Record order [tile slot][k-k0][pixel in tile]: a wave writes 64 consecutive records.  Persistent workgroups (they stage
 // the scene tables into LDS for trace()) striding over the record waves.
 template <int TOPO>
@@ -1182,6 +1207,11 @@ __device__ __forceinline__ void generate_body(const SsxKernelArgs& a) {
 		const bool inside = i < a.width && j < a.height; // lanes outside a ragged image have no record
 		float4 ray = make_float4(0.0f, 0.0f, 1.0f, 0.0f); uint4 st = make_uint4(0u, 0u, 0u, 0u);
 		if (inside) generate_sample(h, a, i, j, kk, ray, st);
+		const uint64_t r = sk * 64u + lane;
+		if (!a.pre_hits) { // camera rays are traced in the path loop (SsxKernelArgs::pre_hits; wave-uniform)
+			if (inside) { a.ray[r] = ray; a.st[r] = st; }
+			continue;
+		}
 		HitInfo hit;
 		trace<TOPO>(L, cam, mk(ray.x, ray.y, ray.z), -1, inside, hit, 16);
 		if (inside) {
@@ -1192,7 +1222,6 @@ __device__ __forceinline__ void generate_body(const SsxKernelArgs& a) {
 			} else {
 				st = make_uint4(__float_as_uint(ray.w), (SSX_NO_SLOT << 6) | (SSX_NO_SLOT << 19), st.x, st.y); // see render_body: the tail word of a path that ends at level 0 without a hit
 			}
-			const uint64_t r = sk * 64u + lane;
 			a.ray[r] = ray;
 			a.st[r] = st;
 			a.hit[r] = make_float4(hit.dist, st_x, st_y, __int_as_float(hit.tri));
@@ -1213,43 +1242,77 @@ SSX_GENERATE_KERNEL(ssx_generate_kernel_plane, 2)
 // Cornell paths end after one interaction, 24 % run all nine).  The recursion L() of the
 // reference is evaluated as a forward pass here (each level's direct light and continuation
 // factors go to the per-level arrays) and a backward fold over them when the wave has finished its unit.
-struct WorkUnit { // wave-uniform description of one work unit: 8x8 tile x a group of consecutive samples
-	uint32_t rec_base, n_kq, tw, th, npx, n_items;
+struct WorkUnit { // wave-uniform description of one work unit: 8x8 tile x a group of consecutive samples (four SGPRs: a wave holds two)
+	uint32_t slot, k_off;   // tile slot (index into the device's tiles) and first sample of the unit relative to the launch's k0
+	uint32_t pixel0;        // framebuffer index of the tile's pixel (0, 0)
+	uint32_t dims;          // tile width | tile height << 4 | samples per pixel << 8
+	__device__ __forceinline__ uint32_t tw() const { return dims & 15u; }
+	__device__ __forceinline__ uint32_t th() const { return (dims >> 4) & 15u; }
+	__device__ __forceinline__ uint32_t n_kq() const { return dims >> 8; }
+	__device__ __forceinline__ uint32_t npx() const { return tw() * th(); }
+	__device__ __forceinline__ uint32_t n_items() const { return npx() * n_kq(); }
+	// first record: records are [tile slot][k - k0][pixel in tile]
+	__device__ __forceinline__ uint32_t rec_base(const SsxKernelArgs& a) const { return (slot * (a.k1 - a.k0) + k_off) * 64u; }
 };
 __device__ __forceinline__ void unit_setup(const SsxKernelArgs& a, uint32_t unit, WorkUnit& u) {
 	const uint32_t slot = unit % a.my_tiles, grp = unit / a.my_tiles;
 	const uint32_t tile = a.tile_first + slot * a.tile_stride;
 	const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-	u.tw = min(8u, a.width - tx * 8u); u.th = min(8u, a.height - ty * 8u);
-	u.npx = u.tw * u.th;
 	const uint32_t ka = a.k0 + grp * a.group_spp;
 	const uint32_t kb = min(ka + a.group_spp, a.k1);
-	u.n_kq = kb - ka;
-	u.n_items = u.npx * u.n_kq;
-	u.rec_base = (slot * (a.k1 - a.k0) + (ka - a.k0)) * 64u;
+	u.dims = min(8u, a.width - tx * 8u) | (min(8u, a.height - ty * 8u) << 4) | ((kb - ka) << 8);
+	u.slot = slot; u.k_off = ka - a.k0;
+	u.pixel0 = ty * 8u * a.width + tx * 8u;
 }
 // Every lane folds the records of its own pixel of a finished unit.  The loads (levels and records
 // this wave wrote during the unit) overlap with the arithmetic of the other waves on the SIMD, which
-// a separate HBM-bound pass after the kernel could not (ssx_resolve_kernel: kept as an option, SSX_FUSE_RESOLVE=0).
+// a separate HBM-bound pass after the kernel could not.
+//
+// The pixel sums (renderer.cpp:292-295: binary64, samples added in ascending k) are kept in a.accum and continued here: a
+// tile's units -- consecutive groups of k, handed out in ascending order by the unit counter -- take turns.  a.tile_done[slot]
+// holds the number of samples per pixel of the tile already added in this launch; a unit waits until that equals its own
+// first sample, adds its samples, and publishes the new count.  The unit waited for was handed out a whole round of
+// tiles earlier, to a wave that is resident and running (persistent grid: every unit handed out is being worked on, and
+// waits only ever point to earlier units), so the wait is short and cannot deadlock.  accum and tile_done are touched only
+// with agent-scope atomic loads and stores (performed at the device's point of coherence, whichever XCD's L2 the two
+// waves sit behind); the sums are complete (s_waitcnt through the release fence) before the count is published.
 template <bool NARROW>
 __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, const WorkUnit& u, uint32_t wave_slot, uint32_t tag) {
 	// see "Memory-ordering contract" above: wait for this wave's stores, drop the CU's L1 lines
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	const uint32_t lane = threadIdx.x & 63u;
-	if ((lane & 7u) < u.tw && (lane >> 3) < u.th)
-		for (uint32_t kq = 0; kq < u.n_kq; kq += SSX_RESOLVE_WAYS) { // one cohort per pass
+	// this unit's turn in the tile's k order?
+	if (u.k_off) {
+#ifdef SSX_ACCUM_FORMAL
+		while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.tile_done + u.slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) != u.k_off) __builtin_amdgcn_s_sleep(8);
+#else
+		while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.tile_done + u.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != u.k_off) __builtin_amdgcn_s_sleep(8);
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#endif
+	}
+	if ((lane & 7u) < u.tw() && (lane >> 3) < u.th()) {
+		double* const px = a.accum + 4u * (size_t)(u.pixel0 + (lane >> 3) * a.width + (lane & 7u));
+		for (uint32_t kq = 0, n_kq = u.n_kq(), rec_base = u.rec_base(a); kq < n_kq; kq += SSX_RESOLVE_WAYS) { // one cohort per pass
 			const uint32_t log_rec = log_region(a, wave_slot, tag, kq / SSX_COHORT_KS);
-			resolve_records<SSX_RESOLVE_WAYS, NARROW>(L, a, u.rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, u.n_kq - kq), log_rec * SSX_MAX_FRAMES, log_rec * SSX_MAX_LEVELS, lane);
+			resolve_records<SSX_RESOLVE_WAYS, NARROW>(L, a, rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, n_kq - kq), log_rec * SSX_MAX_FRAMES, log_rec * SSX_MAX_LEVELS, lane, px);
 		}
+	}
+#ifdef SSX_ACCUM_FORMAL
+	if (lane == 0u) __hip_atomic_store(a.tile_done + u.slot, u.k_off + u.n_kq(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the sums have reached the point of coherence (vmcnt 0)
+	if (lane == 0u) __hip_atomic_store(a.tile_done + u.slot, u.k_off + u.n_kq(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 }
 
-template <int TOPO, bool NARROW>
+// CALIB: the calibration render of ssx_upload_scene (ssx_calibrate_kernel) also counts the rays that leave the scene
+template <int TOPO, bool NARROW, bool CALIB = false>
 __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	uint32_t* const lds_words = stage_lds(a);
 	Lds L; L.w = lds_words;
 
-	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u; // (wave: an SGPR, and with it everything derived from it)
 	const uint32_t wave_slot = blockIdx.x * 4u + wave; // this wave's place in the persistent grid: owner of a region of the level logs
 	const uint32_t total_units = a.my_tiles * a.n_groups;
 	// the camera position from the blob's copy in HBM: wave-uniform scalar loads (SGPRs; LDS reads would hold three VGPRs for the whole kernel)
@@ -1277,40 +1340,57 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	bool cur_valid = false, old_pending = false, more = true;
 	uint32_t cur_tag = 0, old_tag = 0;
 	uint32_t next_item = 0; // wave-uniform
-	// the tail word (ssx_blob.h) of the lane's path ending at level p.depth: hit_anything (always: only samples whose camera
-	// ray hit something run here) | the level has an emission term << 1 | p.depth << 2 | slot of the entry of level
+	// the tail word (ssx_blob.h) of the lane's path ending at level p.depth: hit_anything (0 only for a camera ray that left
+	// the scene) | the level has an emission term << 1 | p.depth << 2 | slot of the entry of level
 	// p.depth-1 << 6 | slot of the level's next-event term << 19; lambda_0 and the final PCG32 state replace the sample's
 	// stream.  The fold happens when the sample's unit is complete.
-	auto end_path = [&](uint32_t level_word) {
-		const uint32_t tail = 1u | ((level_word >> 26) << 1) | (p.depth << 2) | (p.prev_slot << 6) | ((level_word >> 13) << 19);
+	auto end_path = [&](uint32_t level_word, uint32_t hit_anything) {
+		const uint32_t tail = hit_anything | ((level_word >> 26) << 1) | (p.depth << 2) | (p.prev_slot << 6) | ((level_word >> 13) << 19);
 		a.st[p.rec_index] = make_uint4(__float_as_uint(p.lambda_0), tail, (uint32_t)p.rng.state, (uint32_t)(p.rng.state >> 32));
 		active = false;
 	};
-	for (;;) {
-		// One iteration:
-		// (1) every running path shades the hit it holds (one level of L()): it parks a shadow ray and either produces its
-		//     continuation ray or ends;
-		// (2) the parked shadow rays are traced when a wave's worth has gathered, and the previous unit is folded when its
-		//     last path is done -- here, where a lane's state is the path with its next ray and nothing else (the hit of a
-		//     ray lives only from (3)/(5) to (1));
-		// (3) when that made room, the next unit is fetched;
-		// (4) the continuation rays of all lanes are traced in uniform control flow; a ray that leaves the scene ends its
-		//     path there, so that no lane carries a miss into the next shading;
-		// (5) the lanes that fell idle in (1) or (4) take their next samples: camera ray, stream and the camera ray's hit
-		//     come from ssx_generate_kernel.
-		bool pushed = false;
-		if (active) {
-			SSX_STAT(13); // lanes with a path, per iteration
-			LogRef lg;
-			lg.cnt = log_cnt; lg.wave_base = wave_slot * 2u * a.unit_cohorts; lg.tagw = p_tag;
-			uint32_t level_word;
-			if (!path_step<NARROW>(L, sq, a, lg, p, pushed, level_word)) end_path(level_word);
+	// Hands the idle lanes their next samples (items of the current unit, k-major).  with_hit: the sample comes with its camera
+	// ray's hit (pre_hits) -- a sample whose camera ray left the scene was complete when it was generated; otherwise the
+	// lane holds the camera ray itself, to be traced with the continuation rays.
+	auto refill = [&](bool with_hit) {
+		const uint32_t n_items = cur.n_items();
+		if (!(cur_valid && next_item < n_items)) return;
+		const uint64_t idle = __ballot(!active);
+		if (!active) {
+			const uint32_t item = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+			if (item < n_items) {
+				uint32_t in_tile, kq;
+				const uint32_t npx = cur.npx(), tw = cur.tw();
+				if (npx == 64u) { in_tile = item & 63u; kq = item >> 6; }              // full tile (wave-uniform branch)
+				else { const uint32_t r = item % npx; kq = item / npx; in_tile = (r / tw) * 8u + r % tw; }
+				p.rec_index = cur.rec_base(a) + kq * 64u + in_tile;
+				const float4 ray = a.ray[p.rec_index];
+				const uint4 st = a.st[p.rec_index];
+				p.dir = mk(ray.x, ray.y, ray.z);
+				p.lambda_0 = ray.w;
+				p.rng.state = ((uint64_t)st.y << 32) | st.x;
+				p.rng.inc = ((uint64_t)st.w << 32) | st.z;
+				p.orig = cam;
+				p.ignore = -1;
+				p.depth = 0;
+				p.prev_slot = SSX_NO_SLOT;
+				const uint32_t cohort = kq / SSX_COHORT_KS;
+				p_tag = cohort | (cur_tag << 2) | ((cur_tag * a.unit_cohorts + cohort) << 3) | ((kq % SSX_COHORT_KS) << 8);
+				active = true;
+				if (with_hit) {
+					const float4 ht = a.hit[p.rec_index];
+					p.hit_dist = ht.x; p.hit_st_x = ht.y; p.hit_st_y = ht.z; p.hit_tri = __float_as_int(ht.w);
+					active = p.hit_tri >= 0;
+				}
+			}
 		}
-		sq.count += (uint32_t)__popcll(__ballot(pushed));
+		next_item = min(n_items, next_item + (uint32_t)__popcll(idle));
+	};
+	// The parked shadow rays are traced a full wave at a time; all of them when the previous unit's last paths are
+	// done (some may be its: they must be in before its fold) or when nothing is running at all.  One call site:
+	// a flush inlines a whole trace.  Then the fold of the previous unit, if its last path is done.
+	auto flush_fold = [&]() {
 		const bool busy = __any(active);
-		// The parked shadow rays are traced a full wave at a time; all of them when the previous unit's last paths are
-		// done (some may be its: they must be in before its fold) or when nothing is running at all.  One call site:
-		// a flush inlines a whole trace.
 		const bool fold_old = old_pending && !__any(active && ((p_tag >> 2) & 1u) == old_tag);
 		const bool drain = (fold_old && a.fuse_resolve) || !busy;
 		while (sq.count >= SSX_SQ_FLUSH_AT || (drain && sq.count)) {
@@ -1322,8 +1402,10 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			if (a.fuse_resolve) unit_fold<NARROW>(L, a, old, wave_slot, old_tag);
 			old_pending = false;
 		}
-		// rotate: the current unit has no items left and the previous one is folded
-		if (cur_valid && next_item >= cur.n_items && !old_pending) {
+	};
+	// rotate: the current unit has no items left and the previous one is folded; then fetch the next unit
+	auto rotate_fetch = [&]() {
+		if (cur_valid && next_item >= cur.n_items() && !old_pending) {
 			old = cur; old_tag = cur_tag; old_pending = true;
 			cur_valid = false;
 		}
@@ -1337,14 +1419,48 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			}
 			else more = false;
 		}
-		if (busy) {
+	};
+	for (;;) {
+		// One iteration:
+		// (1) every running path shades the hit it holds (one level of L()): it parks a shadow ray and either produces its
+		//     continuation ray or ends;
+		// (2) the parked shadow rays are traced when a wave's worth has gathered, and the previous unit is folded when its
+		//     last path is done -- here, where a lane's state is the path with its next ray and nothing else (the hit of a
+		//     ray lives only from (4)/(5) to (1));
+		// (3) when there is room, the next unit is fetched;
+		// (4) the continuation rays of all lanes are traced in uniform control flow; a ray that leaves the scene ends its
+		//     path there, so that no lane carries a miss into the next shading;
+		// (5) the lanes that fell idle in (1) or (4) take their next samples: camera ray, stream and the camera ray's hit
+		//     come from ssx_generate_kernel.
+		// Without pre-traced camera rays (a.pre_hits == 0) the idle lanes take their samples between (3) and (2) instead, the
+		// camera rays are traced in (4), and a lane whose ray leaves the scene idles through the next shading.
+		// (1)
+		{
+			bool pushed = false;
+			if (active) {
+				SSX_STAT(13); // lanes with a path, per iteration
+				LogRef lg;
+				lg.cnt = log_cnt; lg.wave_base = wave_slot * 2u * a.unit_cohorts; lg.tagw = p_tag;
+				uint32_t level_word;
+				if (!path_step<NARROW>(L, sq, a, lg, p, pushed, level_word)) end_path(level_word, 1u);
+			}
+			sq.count += (uint32_t)__popcll(__ballot(pushed));
+		}
+		rotate_fetch(); // (3)
+		if (!a.pre_hits) refill(false); // the new samples' camera rays ride in the trace (4): their loads are in flight during (2)
+#ifndef SSX_LOOP_FLUSH_LAST
+		flush_fold(); // (2)
+#endif
+		// (4)
+		if (__any(active)) {
 			HitInfo hit;
 			trace<TOPO>(L, p.orig, p.dir, p.ignore, active, hit, 0);
 			// (unconditional assignments: nothing of the previous hit stays live across the trace)
 			p.hit_tri = hit.tri; p.hit_dist = hit.dist;
 			float st_x = 0.0f, st_y = 0.0f;
+			if (CALIB) { const uint32_t left = (uint32_t)__popcll(__ballot(active && hit.tri < 0)); if (lane == 0u && left) atomicAdd(a.unit_counter + 1, left); }
 			if (active) {
-				if (hit.tri < 0) end_path(SSX_NO_SLOT << 13); // the ray left the scene: this level's radiance is 0, no term of either kind
+				if (hit.tri < 0) end_path(SSX_NO_SLOT << 13, p.depth ? 1u : 0u); // the ray left the scene: this level's radiance is 0, no term of either kind (a camera ray: no hit at all)
 				else {
 					const SsxBlobQuad& Q = L.quad((uint32_t)hit.tri >> 1);
 					if (Q.albedo_mode != 0u) hit_st(Q, (uint32_t)hit.tri & 1u, hit, st_x, st_y);
@@ -1352,35 +1468,10 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			}
 			p.hit_st_x = st_x; p.hit_st_y = st_y;
 		}
-		// hand out items to idle lanes
-		if (cur_valid && next_item < cur.n_items) {
-			const uint64_t idle = __ballot(!active);
-			if (!active) {
-				const uint32_t item = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
-				if (item < cur.n_items) {
-					uint32_t in_tile, kq;
-					if (cur.npx == 64u) { in_tile = item & 63u; kq = item >> 6; }              // full tile (wave-uniform branch)
-					else { const uint32_t r = item % cur.npx; kq = item / cur.npx; in_tile = (r / cur.tw) * 8u + r % cur.tw; }
-					p.rec_index = cur.rec_base + kq * 64u + in_tile;
-					const float4 ray = a.ray[p.rec_index];
-					const uint4 st = a.st[p.rec_index];
-					const float4 ht = a.hit[p.rec_index];
-					p.dir = mk(ray.x, ray.y, ray.z);
-					p.lambda_0 = ray.w;
-					p.rng.state = ((uint64_t)st.y << 32) | st.x;
-					p.rng.inc = ((uint64_t)st.w << 32) | st.z;
-					p.orig = cam;
-					p.ignore = -1;
-					p.depth = 0;
-					p.prev_slot = SSX_NO_SLOT;
-					p.hit_dist = ht.x; p.hit_st_x = ht.y; p.hit_st_y = ht.z; p.hit_tri = __float_as_int(ht.w);
-					const uint32_t cohort = kq / SSX_COHORT_KS;
-					p_tag = cohort | (cur_tag << 2) | ((cur_tag * a.unit_cohorts + cohort) << 3) | ((kq % SSX_COHORT_KS) << 8);
-					active = p.hit_tri >= 0; // a camera ray that left the scene: the sample was complete when it was generated
-				}
-			}
-			next_item = min(cur.n_items, next_item + (uint32_t)__popcll(idle));
-		}
+		if (a.pre_hits) refill(true); // (5)
+#ifdef SSX_LOOP_FLUSH_LAST
+		flush_fold(); // (2) moved behind (5): the loads of the new samples are in flight during the flush; four more values live across it
+#endif
 		// nothing runs, nothing is left to hand out, nothing waits for its flush or fold
 		if (!__any(active) && !cur_valid && !more && !old_pending && sq.count == 0u) break;
 	}
@@ -1405,37 +1496,7 @@ SSX_PATH_KERNEL(ssx_render_kernel_plane_nq, 2, true, SSX_WAVES_PER_EU)
 // The generic kernel under another name for the calibration render of ssx_upload_scene (64x64x4 samples), so that
 // kernel traces and statistics of ssx_render_kernel* contain real launches only.  Narrow queue entries: it stages the
 // whole blob, which may only fit with them.
-SSX_PATH_KERNEL(ssx_calibrate_kernel, 0, true, 3)
-
-// Stage 3 of 3: one lane per pixel.  renderer.cpp:292-295: avg += sample*0.001f (float multiply,
-// widened) in ascending k -- the reference's accumulation order, whichever lane of the path
-// kernel produced the sample.  Consecutive lanes read consecutive 16-byte results.
-extern "C" __global__ void __launch_bounds__(256) ssx_accumulate_kernel(SsxKernelArgs a, double* accum) {
-	const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-	const uint32_t slot = gid >> 6, lane = gid & 63u;
-	if (slot >= a.my_tiles) return;
-	const uint32_t tile = a.tile_first + slot * a.tile_stride;
-	const uint32_t i = (tile % a.tiles_x) * 8u + (lane & 7u), j = (tile / a.tiles_x) * 8u + (lane >> 3);
-	if (i >= a.width || j >= a.height) return;
-	const uint32_t n_k = a.k1 - a.k0;
-	double* acc_p = accum + 4u * ((size_t)j * a.width + i);
-	double acc[4] = { acc_p[0], acc_p[1], acc_p[2], acc_p[3] };
-	const float4* s = a.ray + (size_t)slot * n_k * 64u + lane;
-	if (a.rgb_mode) { // renderer.cpp:301-303: avg += _render_sample(...), no pre-scaling
-		for (uint32_t k = 0; k < n_k; ++k) {
-			const float4 v = s[(size_t)k * 64u];
-			acc[0] += (double)v.x; acc[1] += (double)v.y; acc[2] += (double)v.z; acc[3] += (double)v.w;
-		}
-	} else
-	for (uint32_t k = 0; k < n_k; ++k) {
-		const float4 v = s[(size_t)k * 64u];
-		acc[0] += (double)(v.x * 0.001f);
-		acc[1] += (double)(v.y * 0.001f);
-		acc[2] += (double)(v.z * 0.001f);
-		acc[3] += (double)(v.w * 0.001f);
-	}
-	acc_p[0] = acc[0]; acc_p[1] = acc[1]; acc_p[2] = acc[2]; acc_p[3] = acc[3];
-}
+extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) ssx_calibrate_kernel(SsxKernelArgs a) { render_body<0, true, true>(a); }
 
 // renderer.cpp:296,298: avg *= 1000.0/spp, then the float conversion of CIEXYZ_32F(avg) / avg.a.
 // Pixels of tiles this device does not own are written as 0 (x+0 is exact in the framebuffer sum).

@@ -248,13 +248,18 @@ class Renderer:
         self._check(self._lib.ssx_plan_info(self._ctx, C.byref(f), C.byref(k)))
         variant = {0: "generic", 1: "cornell topology", 2: "plane topology"}.get(self._lib.ssx_kernel_variant(self._ctx), "?")
         name = self._lib.ssx_kernel_name(self._ctx)
+        left, pre = C.c_float(), C.c_int()
+        if hasattr(self._lib, "ssx_calibration_info"):  # (an older build loaded through SSX_HIP_LIB_OVERRIDE for an A/B run has neither)
+            self._check(self._lib.ssx_calibration_info(self._ctx, None, C.byref(left), C.byref(pre)))
         return {"frames_per_sample": round(f.value, 3), "fold": "path kernel", "pass1": variant,
+                "rays_left_per_sample": round(left.value, 3), "camera_rays": "pre-traced (generate kernel)" if pre.value else "path loop",
                 "kernel": name.decode() if name else None}
 
     def scratch_info(self):
         """Device scratch held: bytes of per-sample arrays (largest launch so far) and of the persistent waves' level logs."""
         a, b = C.c_uint64(), C.c_uint64()
-        self._check(self._lib.ssx_scratch_info(self._ctx, C.byref(a), C.byref(b)))
+        if hasattr(self._lib, "ssx_scratch_info"):
+            self._check(self._lib.ssx_scratch_info(self._ctx, C.byref(a), C.byref(b)))
         return {"sample_bytes": a.value, "log_bytes": b.value}
 
     def save(self, path):

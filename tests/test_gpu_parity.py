@@ -402,6 +402,35 @@ def test_calibration_and_device_scratch():
     assert float(out[..., 3].mean()) > 0.9
 
 
+def test_camera_rays_pretraced_where_rays_leave_the_scene():
+    """Where rays leave the scene often (Cornell box: 0.87 per sample through the open front) the generate kernel traces
+    the camera rays, coherently, and the path loop starts every sample at its first hit, so that no lane idles through a
+    shading; where they do not (plane-srgb: the light box is closed) the path loop traces camera rays like all others.
+    The calibration render at scene upload decides; SSX_PRE_HITS=0/1 forces a mode.  Same bits either way: subprocesses
+    repeat the oracle comparisons with each scene in the mode it does not take by itself."""
+    import subprocess, sys
+    info = Renderer(Options(scene_name="cornell-srgb", res=(8, 8), spp=1, texture="test-img.png")).plan_info()
+    assert info["camera_rays"].startswith("pre-traced") and 0.6 < info["rays_left_per_sample"] < 1.1
+    info = Renderer(Options(scene_name="plane-srgb", res=(8, 8), spp=1, texture="test-img.png")).plan_info()
+    assert info["camera_rays"] == "path loop" and info["rays_left_per_sample"] < 0.05
+    for mode in ("0", "1"):
+        env = dict(os.environ, SSX_PRE_HITS=mode)
+        out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                              "bit_exact_against_oracle or config1 or launch_chunking or per_sample or without_explicit or mirror"], env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
+        assert out.returncode == 0, out.stdout[-3000:]
+
+
+def test_pixel_sums_chain_through_the_units_of_a_tile():
+    """The binary64 pixel sums (src/renderer.cpp:292-295: ascending k) are continued inside the path kernel: the units of
+    a tile -- groups of consecutive samples, folded by whichever waves took them -- wait for each other in k order.  A tiny
+    image with many samples per pixel makes the chain long and the waves many (every unit waits on its predecessor); also
+    split over several launches (the sums continue) and on a ragged tile."""
+    for (W, H, spp, chunk) in ((16, 8, 2048, 0), (8, 8, 1536, 500), (11, 5, 777, 0)):
+        got, _ = gpu_render(scene_name="cornell-srgb", res=(W, H), spp=spp, seed=33, texture="test-img.png", spp_per_launch=chunk)
+        ref = ol.Oracle("cornell-srgb", texture="test-img.png").render(W, H, spp, seed=33)
+        assert np.array_equal(bits(got), bits(ref)), (W, H, spp, chunk)
+
+
 def test_many_units_per_wave_parity_and_determinism():
     """Rare-event guard for the persistent-wave machinery (unit rotation, the shadow-ray queue's
     read-modify-write of frames and records, the fold's view of this wave's own stores): a render with

@@ -1,11 +1,12 @@
 #!/bin/bash
 # A/B on ONE GPU box (box-to-box spread is +-3 %): alternate bench.py runs of the product library and of the
 # variant libraries given as arguments (paths, loaded through SSX_HIP_LIB_OVERRIDE), three rounds each.
-# usage: tools/ab_bench.sh [variant.so ...]   -> prints value / ms_per_step / kernel_ms per run
+# usage: [BENCH_ARGS="--scene plane-srgb ..."] tools/ab_bench.sh [variant.so ...]   -> prints value / ms_per_step / kernel_ms per run
 R=$(pwd)
+P='import json,sys; d=json.loads(sys.stdin.read()); print(sys.argv[1], d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["stage_ms"], d["roofline"]["scratch_bytes"])'
 for round in 1 2 3; do
-	python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('product', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['scratch_bytes'])"
+	python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline $BENCH_ARGS 2>/dev/null | python -c "$P" product
 	for V in "$@"; do
-		SSX_HIP_LIB_OVERRIDE=$R/$V python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$V', d['value'], d['ms_per_step'], d['roofline']['kernel_ms'], d['roofline']['scratch_bytes'])"
+		SSX_HIP_LIB_OVERRIDE=$R/$V python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline $BENCH_ARGS 2>/dev/null | python -c "$P" $V
 	done
 done
