@@ -39,8 +39,10 @@ enum {
 #define SSX_MAX_DEPTH 10u          /* MAX_DEPTH */
 #define SSX_TILE_SIZE 8u           /* TILE_SIZE */
 #define SSX_SAMPLE_WAVELENGTHS 4u  /* SAMPLE_WAVELENGTHS */
-#define SSX_MAX_TEXTURES 4u
-#define SSX_MAX_QUADS 32u          /* one candidate bit pair per quad in a 64-bit lane mask */
+#define SSX_MAX_TEXTURES 4u        /* texture descriptors staged per workgroup */
+#define SSX_MAX_QUADS 128u         /* Scene::primitives: the per-quad records are staged in LDS (160 bytes each; with more than
+                                      32 primitives the intersection works through them in groups of 32 and, where the
+                                      48 KB of scene tables would overflow, keeps its permuted vertex table in HBM) */
 
 /* _Spectrum (reference src/spectrum.hpp:12-31): n uniform samples over [low,high]. */
 typedef struct ssx_spectrum {
@@ -53,13 +55,19 @@ typedef struct ssx_spectrum {
 /* Vertex (src/geometry.hpp:13-22) */
 typedef struct ssx_vertex { float pos[3]; float st[2]; } ssx_vertex;
 
-/* PrimQuad = tri0(v00,v10,v11) + tri1(v00,v11,v01) (src/geometry.hpp:76-103); normals are the
- * host-computed PrimTri normals (src/geometry.hpp:68). */
+/* One primitive of Scene::primitives (src/scene.hpp:39).  PrimQuad = tri0(v00,v10,v11) + tri1(v00,v11,v01)
+ * (src/geometry.hpp:76-103); normals are the host-computed PrimTri normals (src/geometry.hpp:68).
+ * With SSX_PRIM_TRI in `flags` the primitive is a PrimTri (src/geometry.hpp:55-74) of v00, v10, v11: v01 and
+ * normal1 are ignored, intersection tests the one triangle (src/geometry.cpp:12-101), and as a light it is
+ * sampled by PrimTri::get_rand_toward (src/geometry.cpp:103-116: no triangle pick, so one random number fewer
+ * than a quad, and no halving of the pdf, :141-145). */
+enum { SSX_PRIM_LIGHT = 1u,      /* material->is_emissive() at construction, src/geometry.cpp:7-9 */
+       SSX_PRIM_TRI = 0x100u };  /* PrimBase::TYPE::TRI (src/geometry.hpp:28-32); otherwise QUAD */
 typedef struct ssx_quad {
 	ssx_vertex v00, v10, v11, v01;
 	float normal0[3], normal1[3];
 	uint32_t material;
-	uint32_t is_light; /* material->is_emissive() at construction, src/geometry.cpp:7-9 */
+	uint32_t flags;    /* SSX_PRIM_LIGHT | SSX_PRIM_TRI (the field was `is_light` = 0 / 1 before the triangle kind existed) */
 } ssx_quad;
 
 enum { SSX_MTL_LAMBERTIAN = 0, SSX_MTL_MIRROR = 1 };   /* src/material.hpp:144-176 */
@@ -128,6 +136,10 @@ typedef struct ssx_scene_desc {
 	/* SSX_UPLIFT_MENG: the grid (copied at upload); NULL otherwise.  Callers built against the
 	 * struct without this field (smaller struct_size) keep working. */
 	const ssx_meng_grid* meng;
+	/* camera.dir (src/scene.hpp:21), read only by renders with ssx_render_params.no_flat_field_correction.
+	 * Callers built against the struct without this field keep working (such renders are then refused). */
+	float cam_dir[3];
+	uint32_t reserved2;
 } ssx_scene_desc;
 
 /* One render = Renderer::render_start..render_wait (src/renderer.cpp:396-430) for this device's
@@ -142,7 +154,9 @@ typedef struct ssx_render_params {
 	uint32_t spp_per_launch;  /* progress/cancel granularity; 0 = library default */
 	uint32_t no_explicit_light_sampling; /* 0 = EXPLICIT_LIGHT_SAMPLING defined (src/stdafx.hpp:44, the
 	                             reference's default); 1 = the integrator it compiles without it */
-	uint32_t reserved;
+	uint32_t no_flat_field_correction;   /* 0 = FLAT_FIELD_CORRECTION defined (src/stdafx.hpp:55, the reference's default:
+	                             flux = radiance); 1 = the build without it: flux = radiance * dot(camera_ray_dir,
+	                             camera.dir) (src/renderer.cpp:262-266).  (Was `reserved`, 0.) */
 	uint64_t seed;            /* seeding contract below */
 } ssx_render_params;
 

@@ -97,6 +97,7 @@ typedef struct {
 	orc_tri tri0, tri1;
 	int material; /* index into scene materials */
 	int is_light;
+	int is_tri;   /* PrimBase::TYPE::TRI (geometry.hpp:28-32): the primitive is tri0 alone (a PrimTri), tri1 is unused */
 } orc_quad;
 
 typedef struct {
@@ -185,7 +186,7 @@ orc_scene* orc_scene_create(const orc_color*, const char* name, const char* data
  * (Scene::primitives as quads v00,v10,v11,v01 + materials + spectra + textures + camera.matr_PV_inv / pos).
  * Triangle normals (geometry.hpp:62-69), is_light (geometry.cpp:7-9) and the light list (scene.cpp:26-30)
  * are derived as the reference derives them.  Spectral mode only. */
-typedef struct { float pos[4][3]; float st[4][2]; int material; } orc_quad_in;
+typedef struct { float pos[4][3]; float st[4][2]; int material; int kind; /* 0: PrimQuad; 1: PrimTri of pos[0..2] */ } orc_quad_in;
 typedef struct { int kind, albedo_mode, albedo_spectrum, texture, emission_spectrum; } orc_material_in;
 typedef struct { int n; float low, high; const float* data; } orc_spectrum_in;
 typedef struct { int w, h; const uint8_t* rgb; } orc_texture_in;
@@ -207,6 +208,10 @@ void orc_seed_sample(uint64_t seed, uint64_t pixel, uint64_t k, orc_rng* out);
 
 /* Renderer::_render_sample (renderer.cpp:104-277): out = X,Y,Z,alpha.  `indirect_only` is a flag
  * word: bit 0 = Options::indirect_only, bit 1 = integrator compiled WITHOUT EXPLICIT_LIGHT_SAMPLING. */
+/* camera.dir of a custom scene (read only by renders without FLAT_FIELD_CORRECTION) */
+void orc_scene_set_camera_dir(orc_scene*, const float dir[3]);
+/* `indirect_only` of orc_render_sample / orc_render carries the build switches as bits: 1 = Options::indirect_only,
+ * 2 = built without EXPLICIT_LIGHT_SAMPLING (stdafx.hpp:44), 4 = built without FLAT_FIELD_CORRECTION (stdafx.hpp:55) */
 void orc_render_sample(const orc_color*, const orc_scene*, orc_rng*, size_t i, size_t j,
                        size_t W, size_t H, int indirect_only, float out_xyza[4], orc_stats*);
 

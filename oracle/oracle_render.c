@@ -140,7 +140,13 @@ void orc_render_sample(const orc_color* cd, const orc_scene* sc, orc_rng* rng, s
 	orc_ray ray_camera = { sc->camera.pos, camera_ray_dir };
 	orc_hero rad = radiance_L(&c, &ray_camera, 1, 0u, -1);
 
-	/* FLAT_FIELD_CORRECTION: flux = radiance (:262-263) */
+	/* FLAT_FIELD_CORRECTION: flux = radiance (:262-263); without it (:264-265) flux = radiance * glm::dot(camera_ray_dir, camera.dir) */
+	if (indirect_only & 4) {
+		const orc_v3 cd_ = sc->camera.dir;
+		const float tx = camera_ray_dir.x * cd_.x, ty = camera_ray_dir.y * cd_.y, tz = camera_ray_dir.z * cd_.z;
+		const float d = tx + ty + tz; /* glm::dot(vec3): t.x + t.y + t.z */
+		for (int k = 0; k < ORC_NWAVE; ++k) rad.v[k] = rad.v[k] * d;
+	}
 	float xyz[3];
 	if (cd->rgb_mode) { xyz[0] = rad.v[0]; xyz[1] = rad.v[1]; xyz[2] = rad.v[2]; } /* :274-276 lRGB_A_F32(pixel_flux_est, hit) */
 	else

@@ -81,8 +81,9 @@ int orc_tri_intersect(const orc_tri* tri, const orc_ray* ray, orc_hit* hitrec, i
 	return 0;
 }
 
-/* geometry.cpp:128-139 */
+/* geometry.cpp:128-139; a PrimTri primitive (geometry.cpp:12-101) is its one triangle */
 static int quad_intersect(const orc_quad* q, int prim_id, const orc_ray* ray, orc_hit* hitrec, orc_stats* st) {
+	if (q->is_tri) return orc_tri_intersect(&q->tri0, ray, hitrec, prim_id, st);
 	if (orc_tri_intersect(&q->tri0, ray, hitrec, prim_id, st)) goto HIT;
 	if (orc_tri_intersect(&q->tri1, ray, hitrec, prim_id, st)) goto HIT;
 	return 0;
@@ -122,6 +123,8 @@ static void quad_get_rand_toward(const orc_quad* q, orc_rng* rng, orc_v3 from, o
 /* scene.cpp:417-431 */
 void orc_scene_get_rand_toward_light(const orc_scene* sc, orc_rng* rng, orc_v3 from, orc_v3* dir, int* light, float* pdf) {
 	*light = sc->lights[orc_rand_choice(rng, (size_t)sc->n_lights)];
+	if (sc->prims[*light].is_tri) tri_get_rand_toward(&sc->prims[*light].tri0, rng, from, dir, pdf); /* virtual dispatch: PrimTri::get_rand_toward */
+	else
 	quad_get_rand_toward(&sc->prims[*light], rng, from, dir, pdf);
 	*pdf /= (float)sc->n_lights;
 }
@@ -258,6 +261,7 @@ static void scene_add_quad(orc_scene* sc, int material, orc_vertex v00, orc_vert
 	tri_make(&q->tri0, v00, v10, v11);
 	tri_make(&q->tri1, v00, v11, v01);
 	q->material = material;
+	q->is_tri = 0;
 	q->is_light = material_is_emissive(sc->rgb_mode, &sc->materials[material]); /* geometry.cpp:7-9 */
 }
 static int scene_add_material(orc_scene* sc) {
@@ -496,6 +500,7 @@ orc_scene* orc_scene_create_custom(const orc_color* cd, const double pv_inv[16],
 		orc_vertex v[4];
 		for (int k = 0; k < 4; ++k) v[k] = vtx(in->pos[k][0], in->pos[k][1], in->pos[k][2], in->st[k][0], in->st[k][1]);
 		scene_add_quad(sc, in->material, v[0], v[1], v[2], v[3]);
+		sc->prims[sc->n_prims - 1].is_tri = in->kind == 1; /* PrimTri(material, v0, v1, v2): geometry.hpp:62-69 = tri0 */
 	}
 	memcpy(sc->camera.matr_PV_inv, pv_inv, sizeof sc->camera.matr_PV_inv);
 	sc->camera.pos = v3_make(cam_pos[0], cam_pos[1], cam_pos[2]);
@@ -506,6 +511,7 @@ orc_scene* orc_scene_create_custom(const orc_color* cd, const double pv_inv[16],
 	if (sc->n_lights == 0) { orc_set_error("%s", "custom scene: no lights (scene.cpp:30 asserts !lights.empty())"); orc_scene_destroy(sc); return NULL; }
 	return sc;
 }
+void orc_scene_set_camera_dir(orc_scene* sc, const float dir[3]) { sc->camera.dir = v3_make(dir[0], dir[1], dir[2]); }
 void orc_scene_quad_normals(const orc_scene* sc, int quad, float out[6]) {
 	const orc_quad* q = &sc->prims[quad];
 	out[0] = q->tri0.normal.x; out[1] = q->tri0.normal.y; out[2] = q->tri0.normal.z;

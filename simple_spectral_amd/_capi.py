@@ -17,7 +17,7 @@ class SsxVertex(C.Structure):
 class SsxQuad(C.Structure):
     _fields_ = [("v00", SsxVertex), ("v10", SsxVertex), ("v11", SsxVertex), ("v01", SsxVertex),
                 ("normal0", C.c_float * 3), ("normal1", C.c_float * 3),
-                ("material", C.c_uint32), ("is_light", C.c_uint32)]
+                ("material", C.c_uint32), ("flags", C.c_uint32)]   # SSX_PRIM_LIGHT | SSX_PRIM_TRI
 
 
 class SsxMaterial(C.Structure):
@@ -52,17 +52,19 @@ class SsxSceneDesc(C.Structure):
         ("uplift", C.c_uint32), ("jh_res", C.c_uint32),
         ("jh_scale", C.POINTER(C.c_float)), ("jh_data", C.POINTER(C.c_float)),
         ("meng", C.POINTER(SsxMengGrid)),
+        ("cam_dir", C.c_float * 3), ("reserved2", C.c_uint32),
     ]
 
 
 class SsxRenderParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32),
                 ("indirect_only", C.c_uint32), ("tile_first", C.c_uint32), ("tile_stride", C.c_uint32),
-                ("spp_per_launch", C.c_uint32), ("no_explicit_light_sampling", C.c_uint32), ("reserved", C.c_uint32),
+                ("spp_per_launch", C.c_uint32), ("no_explicit_light_sampling", C.c_uint32), ("no_flat_field_correction", C.c_uint32),
                 ("seed", C.c_uint64)]
 
 
 SSX_MODE_RGB, SSX_UPLIFT_OURS, SSX_UPLIFT_MENG, SSX_UPLIFT_JH = 0, 1, 2, 3
+SSX_PRIM_LIGHT, SSX_PRIM_TRI = 1, 0x100
 SSX_OK, SSX_ERR_DATA, SSX_ERR_ARG, SSX_ERR_SCENE, SSX_ERR_DEVICE, SSX_ERR_STATE = 0, -1, -2, -3, -10, -11
 
 # every symbol include/ssx.h and include/ssx_host.h declare (tests check the libraries export them)

@@ -61,6 +61,7 @@ struct ssx_ctx {
 	float* d_out = nullptr;     size_t out_pixels = 0;
 	float* d_peer = nullptr;    size_t peer_pixels = 0; // staging buffer of ssx_accumulate_peer
 	bool have_scene = false;
+	bool have_cam_dir = false;  // the caller's ssx_scene_desc carried camera.dir
 
 	std::thread worker;
 	std::atomic<int> rendering{0};
@@ -133,6 +134,14 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 		if (m.albedo_mode == SSX_ALBEDO_TEXTURE && m.albedo_texture >= s->n_textures) return fail(ctx, SSX_ERR_ARG, "material texture out of range");
 	}
 	for (uint32_t i = 0; i < s->n_quads; ++i) if (s->quads[i].material >= s->n_materials) return fail(ctx, SSX_ERR_ARG, "quad material out of range");
+	for (uint32_t i = 0; i < s->n_quads; ++i) if (s->quads[i].flags & ~(uint32_t)(SSX_PRIM_LIGHT | SSX_PRIM_TRI)) return fail(ctx, SSX_ERR_ARG, "unknown primitive flags");
+	// ssx_exact::rcp is exact for |x| <= 2^126 (determinants of the watertight test are products of two coordinate differences):
+	// refuse coordinates that could leave the range instead of losing bit parity silently
+	for (uint32_t i = 0; i < s->n_quads; ++i) {
+		const ssx_vertex* vs[4] = { &s->quads[i].v00, &s->quads[i].v10, &s->quads[i].v11, &s->quads[i].v01 };
+		for (const ssx_vertex* v : vs) for (float c : v->pos) if (!(std::fabs(c) <= 0x1p30f)) return fail(ctx, SSX_ERR_SCENE, "vertex coordinate beyond 2^30 (or not a number)");
+	}
+	for (float c : s->cam_pos) if (!(std::fabs(c) <= 0x1p30f)) return fail(ctx, SSX_ERR_SCENE, "camera position beyond 2^30 (or not a number)");
 	for (uint32_t i = 0; i < s->n_lights; ++i) if (s->lights[i] >= s->n_quads) return fail(ctx, SSX_ERR_ARG, "light index out of range");
 
 	SsxBlobHeader h{};
@@ -156,7 +165,10 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	// that of one of the reference's built-in meshes (csrc/ssx_pass1_gen.h) the kernel with that topology's pass 1 runs.
 	std::vector<std::array<uint8_t, 4>> vid(s->n_quads);
 	std::vector<const float*> distinct;
-	for (uint32_t q = 0; q < s->n_quads; ++q) {
+	bool any_tri = false;
+	for (uint32_t q = 0; q < s->n_quads; ++q) any_tri = any_tri || (s->quads[q].flags & SSX_PRIM_TRI);
+	const bool topo_candidate = s->n_quads <= 32u && !any_tri; // the built-in topologies: at most 32 primitives, all quads
+	for (uint32_t q = 0; topo_candidate && q < s->n_quads; ++q) {
 		const ssx_vertex* vs[4] = { &s->quads[q].v00, &s->quads[q].v10, &s->quads[q].v11, &s->quads[q].v01 };
 		for (int v = 0; v < 4; ++v) {
 			size_t k = 0;
@@ -167,7 +179,7 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	}
 	h.topology = 0; h.n_verts = (uint32_t)distinct.size();
 	for (const SsxTopology& t : ssx_topologies) {
-		if (t.n_quads != s->n_quads || t.n_verts != distinct.size()) continue;
+		if (!topo_candidate || t.n_quads != s->n_quads || t.n_verts != distinct.size()) continue;
 		bool same = true;
 		for (uint32_t q = 0; q < s->n_quads && same; ++q) for (int v = 0; v < 4; ++v) same = same && t.vid[q][v] == vid[q][v];
 		if (same) h.topology = t.id;
@@ -222,8 +234,15 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	h.off_perm = off;      off = align4(off + s->n_quads * SSX_PERM_WORDS_PER_QUAD); // last: not staged by the specialised kernels
 	h.total_words = off;
 	// prefix + blob + the four waves' shadow-ray queues is what a path-kernel workgroup allocates (<= 64 KiB); the
-	// calibration render stages the whole blob also where the scene's own kernel stops before the per-quad table
-	if ((size_t)off * 4 > SSX_BLOB_MAX_BYTES) return fail(ctx, SSX_ERR_SCENE, fmt("scene tables need %u bytes of LDS (max %u)", off * 4, SSX_BLOB_MAX_BYTES));
+	// calibration render stages the whole blob also where the scene's own kernel stops before the per-quad table.
+	// A scene whose tables exceed that with the permuted vertex table (288 bytes per primitive) keeps that table in HBM
+	// (generic kernels read it from there: SsxBlobHeader::perm_hbm; ssx_upload_scene fills in the address).
+	h.perm_hbm = ((size_t)off * 4 > SSX_BLOB_MAX_BYTES) ? 1u : 0u;
+	if ((size_t)(h.perm_hbm ? h.words_without_perm : off) * 4 > SSX_BLOB_MAX_BYTES)
+		return fail(ctx, SSX_ERR_SCENE, fmt("scene tables need %u bytes of LDS (max %u)", (h.perm_hbm ? h.words_without_perm : off) * 4, SSX_BLOB_MAX_BYTES));
+	std::memcpy(h.cam_dir, s->cam_dir, sizeof h.cam_dir);
+	for (uint32_t g = 0; g < 4u; ++g) h.tri_valid[g] = 0ull;
+	for (uint32_t q = 0; q < s->n_quads; ++q) h.tri_valid[q >> 5] |= ((s->quads[q].flags & SSX_PRIM_TRI) ? 1ull : 3ull) << (2u * (q & 31u));
 
 	blob.assign(off, 0u);
 	memcpy(blob.data(), &h, sizeof h);
@@ -257,6 +276,7 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 		bq[q].emission = desc(m.emission_spectrum);
 		// any nonzero emission sample?  (all-zero tables evaluate to exactly +0 at every wavelength)
 		const ssx_spectrum& es = s->spectra[m.emission_spectrum];
+		bq[q].is_tri = (Q.flags & SSX_PRIM_TRI) ? 1u : 0u;
 		bq[q].is_emissive = 0;
 		for (uint32_t k = 0; k < es.n; ++k) if (s->samples[es.offset + k] != 0.0f) bq[q].is_emissive = 1;
 	}
@@ -309,6 +329,7 @@ int check_params(ssx_ctx* ctx, const ssx_render_params* p) {
 	if (p->width == 0 || p->height == 0 || p->spp == 0) return fail(ctx, SSX_ERR_ARG, "width, height and spp must be positive");
 	if ((uint64_t)p->width * p->height > (1ull << 28)) return fail(ctx, SSX_ERR_ARG, "image too large");
 	if (p->tile_stride == 0 || p->tile_first >= p->tile_stride) return fail(ctx, SSX_ERR_ARG, "need tile_first < tile_stride");
+	if (p->no_flat_field_correction && !ctx->have_cam_dir) return fail(ctx, SSX_ERR_ARG, "no_flat_field_correction needs ssx_scene_desc.cam_dir (caller built against an older ssx.h)");
 	return SSX_OK;
 }
 
@@ -347,6 +368,7 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	a.tile_first = p->tile_first; a.tile_stride = p->tile_stride;
 	a.indirect_only = p->indirect_only ? 1u : 0u;
 	a.no_els = p->no_explicit_light_sampling ? 1u : 0u;
+	a.no_flat_field = p->no_flat_field_correction ? 1u : 0u;
 	a.seed = p->seed;
 	a.rgb_mode = ctx->rgb_mode ? 1u : 0u;
 	a.fuse_resolve = ctx->fuse_resolve ? 1u : 0u;
@@ -729,10 +751,12 @@ void ssx_destroy(ssx_ctx* ctx) {
 int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 	if (!ctx) return SSX_ERR_ARG;
 	ssx_scene_desc local;
-	if (s && s->struct_size == offsetof(ssx_scene_desc, meng)) { // caller built before the Meng field existed
-		memcpy(&local, s, offsetof(ssx_scene_desc, meng));
-		local.meng = nullptr;
+	bool have_cam_dir = true;
+	if (s && (s->struct_size == offsetof(ssx_scene_desc, meng) || s->struct_size == offsetof(ssx_scene_desc, cam_dir))) { // caller built before the Meng / cam_dir fields existed
+		memset(&local, 0, sizeof local);
+		memcpy(&local, s, s->struct_size);
 		local.struct_size = sizeof(ssx_scene_desc);
+		have_cam_dir = false;
 		s = &local;
 	}
 	if (!s || s->struct_size != sizeof(ssx_scene_desc)) return fail(ctx, SSX_ERR_ARG, "ssx_scene_desc.struct_size mismatch");
@@ -796,10 +820,17 @@ int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 	SSX_HIP(ctx, hipMemcpy(ctx->d_blob, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
 	ctx->blob_words = (uint32_t)blob.size();
 	{
-		const SsxBlobHeader* bh = reinterpret_cast<const SsxBlobHeader*>(blob.data());
+		SsxBlobHeader* bh = reinterpret_cast<SsxBlobHeader*>(blob.data());
 		ctx->topology = bh->topology;
-		ctx->path_blob_words = bh->topology ? bh->words_without_perm : ctx->blob_words;
+		ctx->path_blob_words = (bh->topology || bh->perm_hbm) ? bh->words_without_perm : ctx->blob_words;
+		if (bh->perm_hbm) { // the permuted vertex table is read from this copy: tell the kernels where it is, and stage only what precedes it
+			const uint64_t at = (uint64_t)(uintptr_t)(ctx->d_blob + bh->off_perm);
+			bh->perm_ptr_lo = (uint32_t)at; bh->perm_ptr_hi = (uint32_t)(at >> 32);
+			SSX_HIP(ctx, hipMemcpy(ctx->d_blob, blob.data(), sizeof(SsxBlobHeader), hipMemcpyHostToDevice));
+			ctx->blob_words = bh->words_without_perm;
+		}
 	}
+	ctx->have_cam_dir = have_cam_dir;
 	ctx->resident_blocks = 0; ctx->gen_blocks = 0; // depend on the blob's LDS footprint
 	ctx->have_scene = true;
 	return calibrate(ctx);

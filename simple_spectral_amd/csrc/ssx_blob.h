@@ -48,7 +48,8 @@ struct SsxBlobQuad {   // 40 words (160 B): 16-byte aligned, stride 40 mod 32 = 
 	uint32_t is_emissive; // emission table has a nonzero sample
 	SsxBlobSpectrum albedo;
 	SsxBlobSpectrum emission;
-	uint32_t pad[2];
+	uint32_t is_tri;      // the primitive is a PrimTri of v00, v10, v11 (SSX_PRIM_TRI): no second triangle, sampled as a triangle
+	uint32_t pad;
 };
 static_assert(sizeof(SsxBlobQuad) == 160, "layout");
 
@@ -73,6 +74,15 @@ struct SsxBlobHeader {
 	// n_verts distinct vertices, then their v[kz]; off_vid: per quad 4 x u8 distinct-vertex ids of v00, v10, v11, v01.
 	// The per-quad permuted table (off_perm) is the LAST section of the blob: the specialised kernels do not stage it.
 	uint32_t topology, n_verts, off_vtab, vtab_stride, off_vid, words_without_perm, pad3_[2];
+	// Intersection candidates are kept as 64-bit masks of 32 primitives (two triangle bits each); scenes with more primitives are
+	// worked through in groups of 32 in list order (ssx_kernels.hip: trace).  tri_valid[g]: the triangle bits of group g that
+	// exist (a PrimTri primitive has no second triangle).
+	uint64_t tri_valid[4];
+	// generic kernels only: where the permuted vertex table does not fit into LDS next to the other tables (large scenes) it is
+	// read from the blob's copy in HBM: perm_hbm = 1 and the table's device address
+	uint32_t perm_hbm, perm_ptr_lo, perm_ptr_hi;
+	float cam_dir[3];           // camera.dir (no_flat_field_correction renders)
+	uint32_t pad4_[2];
 	float lambda_steps[4];      // float(i) * lambda_step, i = 0..3 (spectrum.cpp:63: lambda_0 + i*LAMBDA_STEP)
 	double n_lights_recip;      // RN64(1 / (double)(float)n_lights): `pdf /= float(lights.size())` (scene.cpp:430) as one multiply (ssx_exact.h)
 	double pad2_;
@@ -158,6 +168,7 @@ struct SsxKernelArgs {
 	uint32_t unit_cohorts;    // cohorts per unit = ceil(group_spp / SSX_COHORT_KS): stride of the waves' log regions
 	double* accum;            // per pixel 4 x binary64: the running sums of _render_pixel (renderer.cpp:292-295), continued across launches
 	uint32_t* tile_done;      // per tile slot: samples per pixel added to accum in this launch (zeroed before the launch): units of a tile take turns in k order
+	uint32_t no_flat_field;   // 1: flux = radiance * dot(camera_ray_dir, camera.dir) (renderer.cpp:264-265: built without FLAT_FIELD_CORRECTION)
 	uint32_t keep_samples;    // 1: the fold also writes each sample's {X, Y, Z, alpha} to ray[] (ssx_debug_samples)
 	uint32_t pre_hits;        // 1: ssx_generate_kernel* traces the camera rays (hit[] valid, the path loop starts every sample at its first
 	                          // hit); 0: camera rays are traced in the path loop like any other ray (scenes whose rays rarely leave the scene)

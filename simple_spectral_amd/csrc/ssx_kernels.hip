@@ -509,15 +509,23 @@ namespace {
 template <int TOPO>
 __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_quad, bool has_ray, HitInfo& hit, int stat_base = 0) {
 	const RaySetup rs = ray_setup(orig, dir);
-	const uint32_t nq = L.hdr().n_quads;
+	const SsxBlobHeader& hd = L.hdr();
+	const uint32_t nq = hd.n_quads;
+	hit.tri = -1;
+	hit.dist = __builtin_inff();
+	hit.U = hit.V = hit.W = hit.det_recip = 0.0f;
+	SSX_STAT(stat_base); // lanes holding a ray (of the lanes that called)
+	// Large scenes (generic kernel): the permuted vertex table stays in HBM when it does not fit into LDS (wave-uniform)
+	const bool perm_hbm = TOPO == 0 && hd.perm_hbm != 0u;
+	const float* const gperm = reinterpret_cast<const float*>(((uint64_t)hd.perm_ptr_hi << 32) | (uint64_t)hd.perm_ptr_lo);
 	// "Mixed" flag of a triangle = sign bit of fma(min3, max3, +0): negative iff min < 0 < max strictly (a zero
 	// edge value gives -0 + +0 = +0, an underflowing product keeps its sign) -- one v_fma instead of two
 	// compares and a select.  The flags are shifted into two 32-bit accumulators (16 quads each) with one
 	// v_alignbit per triangle; the filter's own arithmetic is not part of the reference's, only its verdicts are.
-	uint32_t acc0 = 0u, acc1 = 0u;
 	auto quad_flags = [&](uint32_t q, uint32_t& acc) {
 		float pv[12];
-		load_perm(L.perm(q, rs.perm), pv);
+		if (perm_hbm) load_perm(gperm + q * SSX_PERM_WORDS_PER_QUAD + rs.perm * 12u, pv);
+		else load_perm(L.perm(q, rs.perm), pv);
 		SV a = shear_vertex(pv, 0, rs), b = shear_vertex(pv, 1, rs), c = shear_vertex(pv, 2, rs), d = shear_vertex(pv, 3, rs);
 		// tri0 = (A=a,B=b,C=c): UVW = cross(ABCy, ABCx)
 		float U0 = b.y * c.x - b.x * c.y;
@@ -532,73 +540,83 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(__builtin_fmaf(mn0, mx0, 0.0f)), 31u); // acc = acc << 1 | sign
 		acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(__builtin_fmaf(mn1, mx1, 0.0f)), 31u);
 	};
-	const uint32_t n0 = min(nq, 16u), n1 = nq - n0;
-	if constexpr (TOPO == 1) pass1_cornell(L.vtab(rs.perm), rs, acc0, acc1);
-	else if constexpr (TOPO == 2) pass1_plane(L.vtab(rs.perm), rs, acc0, acc1);
-	else {
-		for (uint32_t q = 0; q < n0; ++q) quad_flags(q, acc0);
-		for (uint32_t q = 16u; q < nq; ++q) quad_flags(q, acc1);
-	}
-	// triangle k of an accumulator (k-th shifted in) sits at bit (count - 1 - k): reverse and align
-	const uint32_t mixed0 = __builtin_bitreverse32(acc0) >> (32u - 2u * n0);
-	const uint32_t mixed1 = n1 ? __builtin_bitreverse32(acc1) >> (32u - 2u * n1) : 0u;
-	const uint64_t valid = nq >= 32u ? ~0ull : ((1ull << (2u * nq)) - 1ull);
-	uint64_t cand = ~(((uint64_t)mixed1 << 32) | (uint64_t)mixed0) & valid;
-	if (ignore_quad >= 0) cand &= ~(3ull << (2u * (uint32_t)ignore_quad));
-	if (!has_ray) cand = 0ull;
-
-	hit.tri = -1;
-	hit.dist = __builtin_inff();
-	hit.U = hit.V = hit.W = hit.det_recip = 0.0f;
-	SSX_STAT(stat_base); // lanes holding a ray (of the lanes that called)
-	while (cand) {
-		SSX_STAT(stat_base + 1); // pass-2 trips x lanes with a candidate
-		uint32_t bit = (uint32_t)__builtin_ctzll(cand);
-		cand &= cand - 1ull;
-		uint32_t q = bit >> 1, which = bit & 1u;
-		// the candidate's three vertices only: A = vertex 0, B = vertex 1 + which, C = vertex 2 + which of
-		// { x0 y0 x1 y1 x2 y2 x3 y3 | z0 z1 z2 z3 }
-		float pv3[9];
-		if constexpr (TOPO != 0) {
-			const uint32_t ids = L.vid(q);
-			const uint32_t ia = ids & 0xFFu, ib = (ids >> (8u + 8u * which)) & 0xFFu, ic = (ids >> (16u + 8u * which)) & 0xFFu;
-			const float* vt = L.vtab(rs.perm);
-			const float* vz = vt + 2u * L.hdr().n_verts;
-			const float2 Axy = *reinterpret_cast<const float2*>(vt + 2u * ia), Bxy = *reinterpret_cast<const float2*>(vt + 2u * ib), Cxy = *reinterpret_cast<const float2*>(vt + 2u * ic);
-			pv3[0] = Axy.x; pv3[1] = Axy.y; pv3[2] = vz[ia]; pv3[3] = Bxy.x; pv3[4] = Bxy.y; pv3[5] = vz[ib]; pv3[6] = Cxy.x; pv3[7] = Cxy.y; pv3[8] = vz[ic];
-		} else {
-			const float* pq = L.perm(q, rs.perm);
-			const float2 Axy = *reinterpret_cast<const float2*>(pq);
-			const float2 Bxy = *reinterpret_cast<const float2*>(pq + 2u + 2u * which);
-			const float2 Cxy = *reinterpret_cast<const float2*>(pq + 4u + 2u * which);
-			pv3[0] = Axy.x; pv3[1] = Axy.y; pv3[2] = pq[8]; pv3[3] = Bxy.x; pv3[4] = Bxy.y; pv3[5] = pq[9u + which]; pv3[6] = Cxy.x; pv3[7] = Cxy.y; pv3[8] = pq[10u + which];
+	// The primitives are worked through in groups of 32 in list order -- one group for the reference's scenes, the
+	// topology-specialised kernels know no other case -- each with pass 1 over the group and pass 2 over its candidates,
+	// the closest hit so far carried along: the reference's visiting order (scene.cpp:433-445).
+	for (uint32_t base = 0; base < (TOPO == 0 ? nq : 1u); base += 32u) {
+		const uint32_t ng = TOPO == 0 ? min(nq - base, 32u) : nq;
+		uint32_t acc0 = 0u, acc1 = 0u;
+		const uint32_t n0 = min(ng, 16u), n1 = ng - n0;
+		if constexpr (TOPO == 1) pass1_cornell(L.vtab(rs.perm), rs, acc0, acc1);
+		else if constexpr (TOPO == 2) pass1_plane(L.vtab(rs.perm), rs, acc0, acc1);
+		else {
+			for (uint32_t q = 0; q < n0; ++q) quad_flags(base + q, acc0);
+			for (uint32_t q = 16u; q < ng; ++q) quad_flags(base + q, acc1);
 		}
-		SV A = shear_xyz(pv3[0], pv3[1], pv3[2], rs), B = shear_xyz(pv3[3], pv3[4], pv3[5], rs), C = shear_xyz(pv3[6], pv3[7], pv3[8], rs);
-		float U = B.y * C.x - B.x * C.y;
-		float V = C.y * A.x - C.x * A.y;
-		float W = A.y * B.x - A.x * B.y;
-		// geometry.cpp:55-67.  With U, V, W all nonzero the reference rejects a triangle of mixed signs (:55-56): pass 1
-		// has tested exactly that on these same floats (same operands, same operations; a shared edge evaluated the other
-		// way round is the exact negative) and a candidate is a triangle that passed, so nothing is left to test here.
-		// With a zero among them the reference decides on the binary64 values (:57-67), which pass 1 does not look at:
-		if (U == 0.0f || V == 0.0f || W == 0.0f) {
-			double Ud = (double)B.y * (double)C.x - (double)B.x * (double)C.y;
-			double Vd = (double)C.y * (double)A.x - (double)C.x * (double)A.y;
-			double Wd = (double)A.y * (double)B.x - (double)A.x * (double)B.y;
-			if ((Ud < 0.0 || Vd < 0.0 || Wd < 0.0) && (Ud > 0.0 || Vd > 0.0 || Wd > 0.0)) continue;
-			U = (float)Ud; V = (float)Vd; W = (float)Wd;
-		}
-		float det = U + V + W;
-		if (!(__builtin_fabsf(det) > SSX_EPS)) continue;
-		float Az = rs.Sz * A.z, Bz = rs.Sz * B.z, Cz = rs.Sz * C.z;
-		float T = U * Az + V * Bz + W * Cz;
-		if ((__float_as_uint(det) ^ __float_as_uint(T)) & 0x80000000u) continue;
-		float det_recip = ssx_exact::rcp(det);
-		float dist = T * det_recip;
-		if (dist >= SSX_EPS && dist < hit.dist) {
-			hit.tri = (int)bit; hit.dist = dist;
-			hit.U = U; hit.V = V; hit.W = W; hit.det_recip = det_recip;
-			if (which == 0u) cand &= ~(1ull << (bit + 1u)); // PrimQuad::intersect: tri0 hit -> tri1 not tested
+		// triangle k of an accumulator (k-th shifted in) sits at bit (count - 1 - k): reverse and align
+		const uint32_t mixed0 = __builtin_bitreverse32(acc0) >> (32u - 2u * n0);
+		const uint32_t mixed1 = n1 ? __builtin_bitreverse32(acc1) >> (32u - 2u * n1) : 0u;
+		// the triangles that exist: two per quad, one per PrimTri primitive (header; the built-in topologies are all quads)
+		const uint64_t valid = TOPO == 0 ? hd.tri_valid[base >> 5] : (nq >= 32u ? ~0ull : ((1ull << (2u * nq)) - 1ull));
+		uint64_t cand = ~(((uint64_t)mixed1 << 32) | (uint64_t)mixed0) & valid;
+		const uint32_t ign = (uint32_t)ignore_quad - base; // (a negative ignore_quad, or one of another group, falls outside 0..31)
+		if (ign < 32u) cand &= ~(3ull << (2u * ign));
+		if (!has_ray) cand = 0ull;
+		while (cand) {
+			SSX_STAT(stat_base + 1); // pass-2 trips x lanes with a candidate
+			uint32_t bit = (uint32_t)__builtin_ctzll(cand);
+			cand &= cand - 1ull;
+			uint32_t q = base + (bit >> 1), which = bit & 1u;
+			// the candidate's three vertices only: A = vertex 0, B = vertex 1 + which, C = vertex 2 + which of
+			// { x0 y0 x1 y1 x2 y2 x3 y3 | z0 z1 z2 z3 }
+			float pv3[9];
+			if constexpr (TOPO != 0) {
+				const uint32_t ids = L.vid(q);
+				const uint32_t ia = ids & 0xFFu, ib = (ids >> (8u + 8u * which)) & 0xFFu, ic = (ids >> (16u + 8u * which)) & 0xFFu;
+				const float* vt = L.vtab(rs.perm);
+				const float* vz = vt + 2u * L.hdr().n_verts;
+				const float2 Axy = *reinterpret_cast<const float2*>(vt + 2u * ia), Bxy = *reinterpret_cast<const float2*>(vt + 2u * ib), Cxy = *reinterpret_cast<const float2*>(vt + 2u * ic);
+				pv3[0] = Axy.x; pv3[1] = Axy.y; pv3[2] = vz[ia]; pv3[3] = Bxy.x; pv3[4] = Bxy.y; pv3[5] = vz[ib]; pv3[6] = Cxy.x; pv3[7] = Cxy.y; pv3[8] = vz[ic];
+			} else {
+				float2 Axy, Bxy, Cxy; float Az_, Bz_, Cz_;
+				if (perm_hbm) { // (loads from HBM; the two address spaces do not share a pointer)
+					const float* pq = gperm + q * SSX_PERM_WORDS_PER_QUAD + rs.perm * 12u;
+					Axy = *reinterpret_cast<const float2*>(pq); Bxy = *reinterpret_cast<const float2*>(pq + 2u + 2u * which); Cxy = *reinterpret_cast<const float2*>(pq + 4u + 2u * which);
+					Az_ = pq[8]; Bz_ = pq[9u + which]; Cz_ = pq[10u + which];
+				} else {
+					const float* lq = L.perm(q, rs.perm);
+					Axy = *reinterpret_cast<const float2*>(lq); Bxy = *reinterpret_cast<const float2*>(lq + 2u + 2u * which); Cxy = *reinterpret_cast<const float2*>(lq + 4u + 2u * which);
+					Az_ = lq[8]; Bz_ = lq[9u + which]; Cz_ = lq[10u + which];
+				}
+				pv3[0] = Axy.x; pv3[1] = Axy.y; pv3[2] = Az_; pv3[3] = Bxy.x; pv3[4] = Bxy.y; pv3[5] = Bz_; pv3[6] = Cxy.x; pv3[7] = Cxy.y; pv3[8] = Cz_;
+			}
+			SV A = shear_xyz(pv3[0], pv3[1], pv3[2], rs), B = shear_xyz(pv3[3], pv3[4], pv3[5], rs), C = shear_xyz(pv3[6], pv3[7], pv3[8], rs);
+			float U = B.y * C.x - B.x * C.y;
+			float V = C.y * A.x - C.x * A.y;
+			float W = A.y * B.x - A.x * B.y;
+			// geometry.cpp:55-67.  With U, V, W all nonzero the reference rejects a triangle of mixed signs (:55-56): pass 1
+			// has tested exactly that on these same floats (same operands, same operations; a shared edge evaluated the other
+			// way round is the exact negative) and a candidate is a triangle that passed, so nothing is left to test here.
+			// With a zero among them the reference decides on the binary64 values (:57-67), which pass 1 does not look at:
+			if (U == 0.0f || V == 0.0f || W == 0.0f) {
+				double Ud = (double)B.y * (double)C.x - (double)B.x * (double)C.y;
+				double Vd = (double)C.y * (double)A.x - (double)C.x * (double)A.y;
+				double Wd = (double)A.y * (double)B.x - (double)A.x * (double)B.y;
+				if ((Ud < 0.0 || Vd < 0.0 || Wd < 0.0) && (Ud > 0.0 || Vd > 0.0 || Wd > 0.0)) continue;
+				U = (float)Ud; V = (float)Vd; W = (float)Wd;
+			}
+			float det = U + V + W;
+			if (!(__builtin_fabsf(det) > SSX_EPS)) continue;
+			float Az = rs.Sz * A.z, Bz = rs.Sz * B.z, Cz = rs.Sz * C.z;
+			float T = U * Az + V * Bz + W * Cz;
+			if ((__float_as_uint(det) ^ __float_as_uint(T)) & 0x80000000u) continue;
+			float det_recip = ssx_exact::rcp(det);
+			float dist = T * det_recip;
+			if (dist >= SSX_EPS && dist < hit.dist) {
+				hit.tri = (int)(2u * base + bit); hit.dist = dist;
+				hit.U = U; hit.V = V; hit.W = W; hit.det_recip = det_recip;
+				if (which == 0u) cand &= ~(1ull << (bit + 1u)); // PrimQuad::intersect: tri0 hit -> tri1 not tested
+			}
 		}
 	}
 }
@@ -743,7 +761,11 @@ __device__ __forceinline__ void sample_light(const Lds& L, Rng& rng, V3 from, V3
 	if (nl == 1u) (void)rng_next(rng); else pick = rand_choice(rng, nl);
 	light_quad = L.light(pick);
 	const SsxBlobQuad& Q = L.quad(light_quad);
-	bool first = rand_1f(rng) <= 0.5f;
+	// PrimQuad::get_rand_toward (geometry.cpp:141-145) picks one of its triangles with a random number and halves the
+	// pdf; a PrimTri light (:103-116) does neither
+	const bool is_tri = Q.is_tri != 0u;
+	bool first = true;
+	if (!is_tri) first = rand_1f(rng) <= 0.5f;
 	const float* p0 = Q.pos[0];
 	const float* p1 = first ? Q.pos[1] : Q.pos[2];
 	const float* p2 = first ? Q.pos[2] : Q.pos[3];
@@ -753,7 +775,7 @@ __device__ __forceinline__ void sample_light(const Lds& L, Rng& rng, V3 from, V3
 	            normalize3_any(sub(mk(p2[0], p2[1], p2[2]), from)), st);
 	dir = rand_toward_sphericaltri(rng, st);
 	pdf = ssx_exact::rcp(st.area);
-	pdf *= 0.5f;
+	if (!is_tri) pdf *= 0.5f;
 	pdf = ssx_exact::div64_by(pdf, L.hdr().n_lights_recip); // pdf /= float(n_lights): the divisor's binary64 reciprocal comes with the scene
 }
 
@@ -1160,6 +1182,12 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 	for (uint32_t s = 0; s < WAYS; ++s)
 		if (s < count) {
 			SSX_STAT(15); // flux -> XYZ
+			if (a.no_flat_field) { // renderer.cpp:264-265 (built without FLAT_FIELD_CORRECTION): pixel_rad_est * glm::dot(camera_ray_dir, camera.dir)
+				const float4 cr = a.ray[r0 + s * stride]; // {camera ray dir, lambda_0}: still what the generate kernel wrote
+				const SsxBlobHeader& hh = L.hdr();
+				const float d = dot3(mk(cr.x, cr.y, cr.z), mk(hh.cam_dir[0], hh.cam_dir[1], hh.cam_dir[2]));
+				rad[s][0] *= d; rad[s][1] *= d; rad[s][2] *= d; rad[s][3] *= d;
+			}
 			Hero flux; flux.v[0] = rad[s][0]; flux.v[1] = rad[s][1]; flux.v[2] = rad[s][2]; flux.v[3] = rad[s][3];
 			float xyz[3];
 			if (a.rgb_mode) { xyz[0] = rad[s][0]; xyz[1] = rad[s][1]; xyz[2] = rad[s][2]; } // renderer.cpp:274-276: lRGB_A_F32(pixel_flux_est, hit)

@@ -144,6 +144,7 @@ void Renderer::render_start() {
 		p.spp = static_cast<uint32_t>(options.spp);
 		p.indirect_only = options.indirect_only ? 1u : 0u;
 		p.no_explicit_light_sampling = options.explicit_light_sampling ? 0u : 1u;
+		p.no_flat_field_correction = options.flat_field_correction ? 0u : 1u;
 		p.tile_first = static_cast<uint32_t>(d); p.tile_stride = static_cast<uint32_t>(ctxs_.size());
 		p.spp_per_launch = 0;
 		p.seed = options.seed;

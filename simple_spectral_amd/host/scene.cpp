@@ -118,7 +118,7 @@ void Scene::add_quad(uint32_t material, const float p[4][3], const float st[4][2
 	set3(q.normal0, n0.x, n0.y, n0.z);
 	set3(q.normal1, n1.x, n1.y, n1.z);
 	q.material = material;
-	q.is_light = spectra_src_[materials_[material].emission_spectrum].integral() > 0.0f ? 1u : 0u;
+	q.flags = spectra_src_[materials_[material].emission_spectrum].integral() > 0.0f ? (uint32_t)SSX_PRIM_LIGHT : 0u;
 	quads_.push_back(q);
 }
 
@@ -242,12 +242,13 @@ void Scene::build_plane_srgb(const Texture* tex) {
 
 void Scene::finish() {
 	init_camera(camera);
-	for (uint32_t q = 0; q < quads_.size(); ++q) if (quads_[q].is_light) lights_.push_back(q); // src/scene.cpp:26-30
+	for (uint32_t q = 0; q < quads_.size(); ++q) if (quads_[q].flags & SSX_PRIM_LIGHT) lights_.push_back(q); // src/scene.cpp:26-30
 	for (const Texture& t : textures_) texture_descs_.push_back(ssx_texture{ t.width, t.height, t.rgb.data() });
 
 	desc_.struct_size = sizeof(ssx_scene_desc);
 	std::memcpy(desc_.pv_inv, camera.matr_PV_inv, sizeof desc_.pv_inv);
 	std::memcpy(desc_.cam_pos, camera.pos, sizeof desc_.cam_pos);
+	std::memcpy(desc_.cam_dir, camera.dir, sizeof desc_.cam_dir);
 	if (rgb_) { // no observer, no basis: the "wavelengths" are the component indices 0,1,2,(3)
 		desc_.lambda_min = 0.0f;
 		desc_.lambda_step = 1.0f;

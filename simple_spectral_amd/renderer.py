@@ -43,6 +43,7 @@ class Options:
     light_scale: float = 30.0            # lightsc (src/scene.cpp:291-293)
     explicit_light_sampling: bool = True  # EXPLICIT_LIGHT_SAMPLING (src/stdafx.hpp:44); False also makes
     #                                       plane-srgb's textured quad a mirror (src/scene.cpp:346-355)
+    flat_field_correction: bool = True   # FLAT_FIELD_CORRECTION (src/stdafx.hpp:55); False: flux = radiance * dot(ray dir, camera.dir)
     render_mode: str = "spectral"        # "spectral" (RENDER_MODE_SPECTRAL) | "rgb" (RENDER_MODE_RGB, src/stdafx.hpp:91-93:
     #                                       no spectra; `xyza` then holds linear RGB + alpha, `uplift`/`observer` are unused)
     uplift: str = "ours"                 # RENDER_MODE_SPECTRAL_ALGNUM: "ours" (1) | "meng" (2, Meng et al. 2015) | "jh" (3, Jakob-Hanika 2019)
@@ -169,6 +170,7 @@ class Renderer:
         p.spp = o.spp
         p.indirect_only = int(o.indirect_only)
         p.no_explicit_light_sampling = int(not o.explicit_light_sampling)
+        p.no_flat_field_correction = int(not o.flat_field_correction)
         p.tile_first, p.tile_stride = o.tile_first, o.tile_stride
         p.spp_per_launch = o.spp_per_launch
         p.seed = o.seed

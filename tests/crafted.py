@@ -67,3 +67,45 @@ def shared_edge_scene():
     c.add_quad((0, -1, z), (1, -1, z), (1, 0, z), (0, 0, z), WHITE)
     c.set_camera((0.0, 0.0, -2.0), (0.0, 0.0, 1.0), up=(0, 1, 0), vfov_deg=2e-5)
     return c
+
+
+def triangle_scene():
+    """Top-level PrimTri primitives (src/geometry.hpp:55-74, src/scene.hpp:39-41): one as a LIGHT -- sampled by
+    PrimTri::get_rand_toward (src/geometry.cpp:103-116): no triangle pick, so one random number fewer than a quad
+    light, and no halving of the pdf (:141-145) -- next to a quad light (the light pick, src/scene.cpp:417-431,
+    then mixes both kinds), two as occluders (one triangle each: where a quad's second triangle would be, rays pass)."""
+    c = cs.CustomScene("cornell", keep_quads=False)
+    _room(c)
+    c.add_tri((-3, 3.9, -3), (-1, 3.9, -3), (-3, 3.9, -1), LIGHT)                    # 6: triangle light under the ceiling
+    c.add_quad((1, 3.9, 1), (2.5, 3.9, 1), (2.5, 3.9, 2.5), (1, 3.9, 2.5), LIGHT)    # 7: quad light
+    c.add_tri((-2.5, 0.5, 0.5), (0.5, 0.5, 0.0), (-1.0, 0.5, 2.5), GREEN)             # 8: a triangle hovering over the floor
+    c.add_tri((0.0, -1.0, -1.0), (2.0, -1.5, 0.0), (1.0, 1.5, 0.5), RED)              # 9: a tilted one
+    c.add_quad((-3.5, -4 + 1e-3, -3.5), (-1.5, -4 + 1e-3, -3.5), (-1.5, -4 + 1e-3, -1.5), (-3.5, -4 + 1e-3, -1.5), WHITE)  # 10: a quad after the triangles
+    c.set_camera((3.4, -2.5, -3.4), (-0.5, 0.3, 0.5), up=(0, 1, 0), vfov_deg=65.0)
+    return c
+
+
+def many_prims_scene(n_prims, observer=1931, seed=9):
+    """More than 32 primitives (the reference's Scene::intersect loops over any number, src/scene.cpp:433-445): the room, then
+    a cloud of small quads and triangles in all orientations, lights among them at list positions in different groups of
+    32, the last primitive a light too.  n_prims = 70 with the CIE 1931 tables keeps every table in LDS; 128 with the
+    CIE 2006 tables overflows it: the permuted vertex table is then read from HBM."""
+    g = np.random.default_rng(seed)
+    c = cs.CustomScene("cornell", observer=observer, keep_quads=False)
+    _room(c)
+    mats = (WHITE, GREEN, RED)
+    light_at = {6, 20, 33, 64, 97, n_prims - 1}
+    while len(c.quads) < n_prims:
+        i = len(c.quads)
+        ctr = g.uniform(-3.2, 3.2, size=3)
+        u = g.normal(size=3); u /= np.linalg.norm(u)
+        v = np.cross(u, g.normal(size=3)); v /= np.linalg.norm(v)
+        su, sv = g.uniform(0.25, 0.9, size=2)
+        m = LIGHT if i in light_at else mats[i % 3]
+        p00, p10, p11, p01 = ctr - su * u - sv * v, ctr + su * u - sv * v, ctr + su * u + sv * v, ctr - su * u + sv * v
+        if i % 5 == 3:
+            c.add_tri(p00, p10, p11, m)
+        else:
+            c.add_quad(p00, p10, p11, p01, m)
+    c.set_camera((3.6, 0.2, -3.6), (0.0, 0.0, 0.0), up=(0, 1, 0), vfov_deg=70.0)
+    return c

@@ -54,6 +54,8 @@ class CustomScene:
         for i in range(d.n_textures):
             t = d.textures[i]
             self.textures.append(np.ctypeslib.as_array(t.rgb, shape=(t.height, t.width, 3)).copy())
+        self.cam_dir = np.array(d.cam_dir[:], dtype=np.float32)
+        self.kinds = {}     # quad index -> "tri": the primitive is a PrimTri of its first three vertices (src/geometry.hpp:55-74)
         self.quads = []     # (pos[4][3], st[4][2], material)
         if keep_quads:
             for i in range(d.n_quads):
@@ -80,9 +82,17 @@ class CustomScene:
         self.quads.append((np.array([v00, v10, v11, v01], dtype=np.float32), np.array(st, dtype=np.float32), int(material)))
         return len(self.quads) - 1
 
+    def add_tri(self, v0, v1, v2, material, st=((0, 0), (1, 0), (1, 1))):
+        """PrimTri(material, v0, v1, v2): carried as a quad record whose fourth vertex is unused (= v0)."""
+        i = self.add_quad(v0, v1, v2, v0, material, st=tuple(st) + (st[0],))
+        self.kinds[i] = "tri"
+        return i
+
     def set_camera(self, eye, target, up=(0, 1, 0), vfov_deg=40.0, aspect=1.0):
         self.pv_inv = look_at_pv_inv(eye, target, up, vfov_deg, aspect)
         self.cam_pos = np.asarray(eye, dtype=np.float32)
+        f = np.asarray(target, dtype=np.float64) - np.asarray(eye, dtype=np.float64)
+        self.cam_dir = (f / np.linalg.norm(f)).astype(np.float32)   # camera.dir (both sides receive these three floats)
 
     # ---- the two sides -------------------------------------------------------------------------
     def oracle(self):
@@ -110,9 +120,13 @@ class CustomScene:
                     for k in range(2):
                         qs[i].st[v][k] = float(st[v][k])
                 qs[i].material = m
+                qs[i].kind = 1 if self.kinds.get(i) == "tri" else 0
             pv = (C.c_double * 16)(*[float(x) for x in self.pv_inv])
             cp = (C.c_float * 3)(*[float(x) for x in self.cam_pos])
-            return lib.orc_scene_create_custom(color, pv, cp, sp, len(self.spectra), mt, len(self.materials), tx, len(self.textures), qs, len(self.quads))
+            sc = lib.orc_scene_create_custom(color, pv, cp, sp, len(self.spectra), mt, len(self.materials), tx, len(self.textures), qs, len(self.quads))
+            if sc:
+                lib.orc_scene_set_camera_dir(sc, (C.c_float * 3)(*[float(x) for x in self.cam_dir]))
+            return sc
         return ol.Oracle(observer=self.observer, custom=make)
 
     def desc(self, orc):
@@ -124,6 +138,7 @@ class CustomScene:
             d.pv_inv[k] = float(self.pv_inv[k])
         for k in range(3):
             d.cam_pos[k] = float(self.cam_pos[k])
+            d.cam_dir[k] = float(self.cam_dir[k])
         n_samples = sum(len(s[0]) for s in self.spectra)
         samples = (C.c_float * n_samples)()
         spectra = (_capi.SsxSpectrum * len(self.spectra))()
@@ -158,7 +173,7 @@ class CustomScene:
             for k in range(3):
                 quads[i].normal0[k] = n6[k]; quads[i].normal1[k] = n6[3 + k]
             quads[i].material = m
-            quads[i].is_light = 1 if i in list(lights) else 0
+            quads[i].flags = (_capi.SSX_PRIM_LIGHT if i in list(lights) else 0) | (_capi.SSX_PRIM_TRI if self.kinds.get(i) == "tri" else 0)
         d.spectra = C.cast(spectra, C.POINTER(_capi.SsxSpectrum)); d.n_spectra = len(self.spectra)
         d.samples = C.cast(samples, C.POINTER(C.c_float)); d.n_samples = n_samples
         d.materials = C.cast(mats, C.POINTER(_capi.SsxMaterial)); d.n_materials = len(self.materials)

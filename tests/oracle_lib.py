@@ -67,7 +67,7 @@ class Stats(C.Structure):
 
 
 class QuadIn(C.Structure):
-    _fields_ = [("pos", (C.c_float * 3) * 4), ("st", (C.c_float * 2) * 4), ("material", C.c_int)]
+    _fields_ = [("pos", (C.c_float * 3) * 4), ("st", (C.c_float * 2) * 4), ("material", C.c_int), ("kind", C.c_int)]
 
 
 class MaterialIn(C.Structure):
@@ -128,6 +128,8 @@ def load(variant=""):
     lib.orc_scene_create_custom.argtypes = [vp, C.POINTER(C.c_double), f32p, C.POINTER(SpectrumIn), C.c_int, C.POINTER(MaterialIn), C.c_int,
                                             C.POINTER(TextureIn), C.c_int, C.POINTER(QuadIn), C.c_int]
     lib.orc_scene_quad_normals.argtypes = [vp, C.c_int, f32p]
+    lib.orc_scene_set_camera_dir.argtypes = [vp, f32p]
+    lib.orc_scene_set_camera_dir.restype = None
     lib.orc_scene_light.argtypes = [vp, C.c_int]
     lib.orc_scene_set_material_kind.argtypes = [vp, C.c_int, C.c_int]
     lib.orc_scene_quad_material.argtypes = [vp, C.c_int]
@@ -258,11 +260,11 @@ class Oracle:
         except Exception:
             pass
 
-    def render(self, W, H, spp, seed=0, rect=None, indirect_only=False, nthreads=0, stats=False, els=True):
+    def render(self, W, H, spp, seed=0, rect=None, indirect_only=False, nthreads=0, stats=False, els=True, flat_field=True):
         out = np.zeros((H, W, 4), dtype=np.float32)
         i0, j0, i1, j1 = rect if rect else (0, 0, W, H)
         st = Stats() if stats else None
-        rc = self.lib.orc_render(self.color, self.scene, seed, W, H, i0, j0, i1, j1, spp, int(indirect_only) | (0 if els else 2),
+        rc = self.lib.orc_render(self.color, self.scene, seed, W, H, i0, j0, i1, j1, spp, int(indirect_only) | (0 if els else 2) | (0 if flat_field else 4),
                                  nthreads, out.ctypes.data, C.byref(st) if stats else None)
         assert rc == 0
         return (out, st) if stats else out
@@ -274,7 +276,7 @@ class Oracle:
         self.lib.orc_render_sample(self.color, self.scene, C.byref(rng), i, j, W, H, int(indirect_only), out, None)
         return np.array(out[:], dtype=np.float32)
 
-    def samples(self, W, H, spp, seed=0, rect=None, indirect_only=False, els=True):
+    def samples(self, W, H, spp, seed=0, rect=None, indirect_only=False, els=True, flat_field=True):
         """Per-sample results for the pixel rectangle: (xyza [h, w, spp, 4] float32, final PCG32 state
         [h, w, spp] uint64 -- i.e. the draws consumed -- and the summed stats)."""
         i0, j0, i1, j1 = rect if rect else (0, 0, W, H)
@@ -283,7 +285,7 @@ class Oracle:
         st = Stats()
         rng = Rng()
         out = (C.c_float * 4)()
-        flags = int(indirect_only) | (0 if els else 2)
+        flags = int(indirect_only) | (0 if els else 2) | (0 if flat_field else 4)
         for j in range(j0, j1):
             for i in range(i0, i1):
                 for k in range(spp):

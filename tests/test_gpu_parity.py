@@ -377,6 +377,19 @@ def test_rgb_render_mode_bit_exact(scene, texture, W, H, spp, io, els):
         assert not np.array_equal(bits(spectral), bits(ref))
 
 
+@pytest.mark.parametrize("scene,io", [("cornell-srgb", False), ("plane-srgb", False), ("cornell", True)])
+def test_without_flat_field_correction_bit_exact(scene, io):
+    """The reference's other compile-time switch of the estimator, FLAT_FIELD_CORRECTION (src/stdafx.hpp:55): without it
+    flux = radiance * dot(camera_ray_dir, camera.dir) (src/renderer.cpp:262-266).  A render parameter here."""
+    W, H, spp = 40, 32, 8
+    tex = None if scene == "cornell" else "test-img.png"
+    got, _ = gpu_render(scene_name=scene, res=(W, H), spp=spp, seed=8, texture=tex, indirect_only=io, flat_field_correction=False)
+    orc = ol.Oracle(scene, texture=tex)
+    ref = orc.render(W, H, spp, seed=8, indirect_only=io, flat_field=False)
+    assert np.array_equal(bits(got), bits(ref))
+    assert not np.array_equal(bits(ref), bits(orc.render(W, H, spp, seed=8, indirect_only=io)))   # (and it is another image)
+
+
 def test_calibration_and_device_scratch():
     """ssx_upload_scene renders 64x64x4 samples of the scene to count the continued levels per sample (unit size, byte
     accounting of the benchmark).  The levels of the recursion live in logs owned by the persistent waves and recycled

@@ -191,7 +191,7 @@ def test_rgb_mode_host_scene_equals_the_oracle(scene):
         if mode == 0:
             a = d.spectra[m.albedo_spectrum]
             assert np.array_equal(samples[a.offset:a.offset + 3], want[3:]), q
-        assert bool(d.quads[q].is_light) == bool((want[:3] > 0).any())
+        assert bool(d.quads[q].flags & 1) == bool((want[:3] > 0).any())
     x = np.random.RandomState(1).uniform(0, 2, (64, 4)).astype(np.float32)
     assert np.array_equal(s.xyza_to_srgba(x).view(np.uint32), o.to_srgba(x).view(np.uint32))
     with pytest.raises(SsxError):

@@ -69,3 +69,38 @@ def test_unit_inputs_cover_the_branches():
         assert st.lemire_redraws - before >= int(uc.lemire_redraws(w).sum()) > 300
     finally:
         lib.orc_debug_set_stats(None)
+
+
+def test_triangle_light_draws_one_number_fewer_and_has_one_triangle():
+    """PrimTri::get_rand_toward (src/geometry.cpp:103-116) against PrimQuad::get_rand_toward (:141-145), PrimTri::intersect
+    against PrimQuad::intersect (:128-139): what the oracle does with the triangle kind of tests/crafted.py."""
+    c = crafted.triangle_scene()
+    o = c.oracle()
+    w = uc.sample_light_inputs(np.random.default_rng(1).uniform(-3, 3, size=(400, 3)).astype(np.float32))
+    out = uc.oracle_sample_light(o, w)
+    # number of PCG32 steps from the input state to the output state
+    def steps(i):
+        st = int(w[i, 3]) | (int(w[i, 4]) << 32); inc = int(w[i, 5]) | (int(w[i, 6]) << 32)
+        end = int(out[i, 5]) | (int(out[i, 6]) << 32)
+        for n in range(12):
+            if st == end:
+                return n
+            st = (st * 6364136223846793005 + inc) & 0xFFFFFFFFFFFFFFFF
+        return -1
+    n_tri = {steps(i) for i in range(len(w)) if out[i, 3] == 6}
+    n_quad = {steps(i) for i in range(len(w)) if out[i, 3] == 7}
+    assert n_tri == {3} and n_quad == {4}            # light pick + [triangle pick] + two for the spherical triangle
+    # a ray through the point that a QUAD of the triangle's vertices would cover with its second triangle passes primitive 8
+    ray = ol.Ray(ol.V3(-2.0, 3.0, 1.8), ol.V3(0.0, -1.0, 0.0)); hit = ol.Hit()
+    assert o.lib.orc_scene_intersect(o.scene, C.byref(ray), C.byref(hit), -1, None) and hit.prim != 8
+    ray = ol.Ray(ol.V3(-1.0, 3.0, 1.0), ol.V3(0.0, -1.0, 0.0))
+    assert o.lib.orc_scene_intersect(o.scene, C.byref(ray), C.byref(hit), -1, None) and hit.prim == 8
+
+
+def test_many_prims_scene_shapes():
+    for n, obs in ((33, 1931), (70, 1931), (128, 2006)):
+        c = crafted.many_prims_scene(n, obs)
+        assert len(c.quads) == n and sum(1 for k in c.kinds.values() if k == "tri") > n // 8
+        o = c.oracle()
+        img, st = o.render(16, 12, 2, seed=6, stats=True)
+        assert np.isfinite(img).all() and img[..., :3].max() > 0 and st.nee_visible > 50
