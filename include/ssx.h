@@ -234,9 +234,17 @@ int ssx_calibration_info(ssx_ctx* ctx, float* frames_per_sample, float* rays_lef
 int ssx_scratch_info(ssx_ctx* ctx, uint64_t* sample_bytes, uint64_t* log_bytes);
 /* Which path kernel the uploaded scene runs: 0 = the generic one (pass 1 of the intersection loops over the
  * quads), 1 / 2 = the kernel whose pass 1 is specialised to the mesh topology of the reference's Cornell box /
- * plane scene (the scene's quad corners coincide in exactly that pattern; positions are free).  A performance
+ * plane scene (the scene's quad corners coincide in exactly that pattern; positions are free), 3 = specialised to
+ * the scene's own topology at upload (ssx_set_jit).  A performance
  * choice only: same bits.  The environment variable SSX_GENERIC_KERNEL forces 0 at upload.  -1: no scene. */
 int ssx_kernel_variant(ssx_ctx* ctx);
+/* Pass 1 of the intersection is straight-line code for the two mesh topologies of the reference's built-in scenes; other
+ * scenes run a generic loop (~12 % slower).  After ssx_set_jit(ctx, 1), ssx_upload_scene generates that straight-line code
+ * for the uploaded scene's own sharing pattern (scenes of at most 32 primitives, all quads, that match no built-in one) and
+ * compiles the path kernels around it with hipRTC -- about 5 s once per pattern and process; ssx_kernel_variant then returns 3.
+ * Needs libhiprtc and /opt/rocm/include at run time; an upload fails with SSX_ERR_DEVICE if the compilation does.  Same
+ * bits as the generic loop.  (The environment variable SSX_JIT_PASS1=1 at upload does the same.) */
+int ssx_set_jit(ssx_ctx* ctx, int enable);
 /* The name of the path kernel the context launches for the uploaded scene, as a profiler lists it
  * ("ssx_render_kernel", "..._cornell", "..._plane", each also with "_nq": the variants with narrow shadow-ray
  * queue entries, taken where they let one more workgroup live on a CU).  NULL: no scene. */
@@ -276,6 +284,11 @@ enum {
 	SSX_SWEEP_ACOS_SIN = 10    /* |x| <= 1: fused {min(acos x, under_pi), its sine} vs ssx_acosf / ssx_sinf; result[1] = inputs sent to the fallback */
 };
 int ssx_debug_sweep(ssx_ctx* ctx, uint32_t op, uint32_t lo, uint64_t count, uint64_t result[11]);
+/* The text of the pass-1 function ssx_set_jit would compile for the sharing pattern vid[n_quads][4] (distinct-vertex ids of
+ * v00, v10, v11, v01, numbered by first occurrence), under the name pass1_<name>: returns its length (and copies up to
+ * out_size - 1 characters).  Needs no device: the CPU tests compare it with what tools/gen_pass1.py wrote into
+ * csrc/ssx_pass1_gen.h for the built-in topologies. */
+int ssx_debug_pass1_source(const uint8_t* vid, uint32_t n_quads, const char* name, char* out, size_t out_size);
 int ssx_debug_eval(ssx_ctx* ctx, uint32_t op, const void* in, uint32_t in_words, void* out, uint32_t out_words, uint32_t n);
 /* One launch of the whole image (tile_first 0, tile_stride 1), per-sample results in [j][i][k] order:
  * xyza = what Renderer::_render_sample returns (float4), rng_state = the sample's PCG32 state after its

@@ -19,6 +19,8 @@
 #include <thread>
 #include <vector>
 
+#include "ssx_jit.h"
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -42,7 +44,9 @@ struct ssx_ctx {
 	uint32_t* d_blob = nullptr;
 	uint32_t blob_words = 0;      // whole blob (generic / calibration / debug kernels stage all of it)
 	uint32_t path_blob_words = 0; // what the path kernel stages: without the per-quad vertex table when a specialised kernel runs
-	uint32_t topology = 0;        // 0, or the built-in mesh topology the scene matched (csrc/ssx_pass1_gen.h)
+	uint32_t topology = 0;        // 0, the built-in mesh topology the scene matched (csrc/ssx_pass1_gen.h), or 3: its own, compiled at upload
+	bool jit = false;             // ssx_set_jit: specialise pass 1 for scenes that match no built-in topology
+	const ssx_jit::Kernels* jit_kernels = nullptr; // the run-time compiled kernels of the uploaded scene (topology 3)
 	std::vector<uint8_t*> d_textures;
 	float* d_jh_data = nullptr;
 	bool rgb_mode = false;     // scene uploaded with uplift == SSX_MODE_RGB
@@ -185,6 +189,13 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 		if (same) h.topology = t.id;
 	}
 	if (env_on("SSX_GENERIC_KERNEL")) h.topology = 0; // A/B measurements and tests of the generic loop on the built-in scenes
+	else if (h.topology == 0 && topo_candidate && (ctx->jit || env_on("SSX_JIT_PASS1"))) {
+		// no built-in topology: generate and compile pass 1 for this scene's own sharing pattern (csrc/ssx_jit.h)
+		std::string err;
+		ctx->jit_kernels = ssx_jit::get(ctx->device, vid, &err);
+		if (!ctx->jit_kernels) return fail(ctx, SSX_ERR_DEVICE, err);
+		h.topology = 3;
+	}
 
 	uint32_t off = (uint32_t)(sizeof(SsxBlobHeader) / 4);
 	h.off_quads = off;     off = align4(off + s->n_quads * (uint32_t)(sizeof(SsxBlobQuad) / 4));
@@ -511,12 +522,36 @@ path_kernel_t path_kernel_of(uint32_t topology, bool narrow) {
 	if (topology == 2u) return narrow ? ssx_render_kernel_plane_nq : ssx_render_kernel_plane;
 	return narrow ? ssx_render_kernel_nq : ssx_render_kernel;
 }
+// A kernel of this library (host function) or of a run-time compiled module (topology 3)
+struct KernelRef { const void* host = nullptr; hipFunction_t mod = nullptr; };
+KernelRef path_kernel_ref(const ssx_ctx* ctx, bool narrow) {
+	KernelRef k;
+	if (ctx->topology == 3u && ctx->jit_kernels) k.mod = narrow ? ctx->jit_kernels->path_nq : ctx->jit_kernels->path;
+	else k.host = (const void*)path_kernel_of(ctx->topology, narrow);
+	return k;
+}
+int occupancy_of(ssx_ctx* ctx, const KernelRef& k, size_t lds, int* per_cu) {
+	if (k.mod) SSX_HIP(ctx, hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k.mod, 256, lds));
+	else SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k.host, 256, lds));
+	return SSX_OK;
+}
+int launch_kernel(ssx_ctx* ctx, const KernelRef& k, uint32_t blocks, size_t lds, hipStream_t stream, SsxKernelArgs& a) {
+	if (k.mod) {
+		size_t size = sizeof a;
+		void* config[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END };
+		SSX_HIP(ctx, hipModuleLaunchKernel(k.mod, blocks, 1, 1, 256, 1, 1, (unsigned)lds, stream, nullptr, config));
+	} else {
+		void* args[] = { &a };
+		SSX_HIP(ctx, hipLaunchKernel(k.host, dim3(blocks), dim3(256), args, lds, stream));
+	}
+	return SSX_OK;
+}
 // Wide queue entries (ssx_blob.h) unless the narrow ones let one more workgroup live on a CU (or only they fit at all).
-int pick_queue(ssx_ctx* ctx, uint32_t topology, uint32_t blob_words, uint32_t* queue_words, int* blocks_per_cu) {
-	int wide = 0, narrow = 0;
+int pick_queue(ssx_ctx* ctx, uint32_t blob_words, uint32_t* queue_words, int* blocks_per_cu) {
+	int wide = 0, narrow = 0, rc;
 	if (path_lds_bytes(blob_words, SSX_QUEUE_WORDS_WIDE) <= 65536u)
-		SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&wide, (const void*)path_kernel_of(topology, false), 256, path_lds_bytes(blob_words, SSX_QUEUE_WORDS_WIDE)));
-	SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&narrow, (const void*)path_kernel_of(topology, true), 256, path_lds_bytes(blob_words, SSX_QUEUE_WORDS_NARROW)));
+		if ((rc = occupancy_of(ctx, path_kernel_ref(ctx, false), path_lds_bytes(blob_words, SSX_QUEUE_WORDS_WIDE), &wide))) return rc;
+	if ((rc = occupancy_of(ctx, path_kernel_ref(ctx, true), path_lds_bytes(blob_words, SSX_QUEUE_WORDS_NARROW), &narrow))) return rc;
 	const bool use_narrow = narrow > wide || env_on("SSX_NARROW_QUEUE"); // the variable: tests and A/B runs
 	*queue_words = use_narrow ? SSX_QUEUE_WORDS_NARROW : SSX_QUEUE_WORDS_WIDE;
 	if (blocks_per_cu) *blocks_per_cu = use_narrow ? narrow : wide;
@@ -531,18 +566,19 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	{
 		// camera rays + their closest hits: persistent workgroups striding over the record waves (they stage the blob)
 		const uint32_t topo = calibration ? 0u : ctx->topology;
-		auto gen_kernel = topo == 1u ? ssx_generate_kernel_cornell : (topo == 2u ? ssx_generate_kernel_plane : ssx_generate_kernel);
+		KernelRef gen_kernel;
+		if (topo == 3u && ctx->jit_kernels) gen_kernel.mod = ctx->jit_kernels->generate;
+		else gen_kernel.host = topo == 1u ? (const void*)ssx_generate_kernel_cornell : (topo == 2u ? (const void*)ssx_generate_kernel_plane : (const void*)ssx_generate_kernel);
 		const size_t gen_lds = ((size_t)b.a.blob_words + SSX_LDS_PREFIX_WORDS) * 4;
 		if (ctx->gen_blocks == 0 || calibration) {
 			int per_cu = 0;
 			hipDeviceProp_t prop;
-			SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gen_kernel, 256, gen_lds));
+			{ int r = occupancy_of(ctx, gen_kernel, gen_lds, &per_cu); if (r) return r; }
 			SSX_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
 			ctx->gen_blocks = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
 		}
 		const uint64_t want = (b.n_rec + 255u) / 256u;
-		hipLaunchKernelGGL(gen_kernel, dim3((uint32_t)(want < (uint64_t)ctx->gen_blocks ? want : (uint64_t)ctx->gen_blocks)), dim3(256), gen_lds, stream, b.a);
-		SSX_HIP(ctx, hipGetLastError());
+		{ int r = launch_kernel(ctx, gen_kernel, (uint32_t)(want < (uint64_t)ctx->gen_blocks ? want : (uint64_t)ctx->gen_blocks), gen_lds, stream, b.a); if (r) return r; }
 		if (calibration) ctx->gen_blocks = 0;
 	}
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[1], stream));
@@ -556,7 +592,7 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 			ctx->queue_words = SSX_QUEUE_WORDS_NARROW;
 			SSX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)ssx_calibrate_kernel, 256, path_lds_bytes(b.a.blob_words, SSX_QUEUE_WORDS_NARROW)));
 		} else {
-			int r = pick_queue(ctx, ctx->topology, b.a.blob_words, &ctx->queue_words, &per_cu);
+			int r = pick_queue(ctx, b.a.blob_words, &ctx->queue_words, &per_cu);
 			if (r) return r;
 		}
 		SSX_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
@@ -564,7 +600,8 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	}
 	b.a.queue_words = ctx->queue_words;
 	const size_t path_lds = path_lds_bytes(b.a.blob_words, b.a.queue_words);
-	auto path_kernel = path_kernel_of(ctx->topology, b.a.queue_words == SSX_QUEUE_WORDS_NARROW);
+	KernelRef path_kernel = path_kernel_ref(ctx, b.a.queue_words == SSX_QUEUE_WORDS_NARROW);
+	if (calibration) { path_kernel = KernelRef(); path_kernel.host = (const void*)ssx_calibrate_kernel; }
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_unit_counter, 0, 2 * sizeof(uint32_t), stream));
 	if (ctx->tile_done_slots < b.a.my_tiles) { // (grown here, synchronously: the first launch of a larger image)
 		if (ctx->d_tile_done) { SSX_HIP(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->d_tile_done); }
@@ -578,8 +615,7 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	const uint32_t want_blocks = (b.units + 3u) / 4u;
 	uint32_t blocks = want_blocks < (uint32_t)ctx->resident_blocks ? want_blocks : (uint32_t)ctx->resident_blocks;
 	if (blocks * 4u > ctx->max_wave_slots) blocks = ctx->max_wave_slots / 4u; // every wave of the grid owns a log region
-	hipLaunchKernelGGL(calibration ? ssx_calibrate_kernel : path_kernel, dim3(blocks), dim3(256), path_lds, stream, b.a);
-	SSX_HIP(ctx, hipGetLastError());
+	{ int r = launch_kernel(ctx, path_kernel, blocks, path_lds, stream, b.a); if (r) return r; }
 	if (calibration) ctx->resident_blocks = 0; // computed for the calibration kernel: recompute for the path kernel
 	if (ctx->timing) for (int k = 2; k < 6; ++k) SSX_HIP(ctx, hipEventRecord(b.tev[k], stream)); // (fold and pixel sums ran inside the path kernel: their slots stay ~0)
 	return SSX_OK;
@@ -813,6 +849,7 @@ int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 		SSX_HIP(ctx, hipMemcpy(ctx->d_jh_data, s->jh_data, bytes, hipMemcpyHostToDevice));
 	}
 	std::vector<uint32_t> blob;
+	ctx->jit_kernels = nullptr;
 	int rc = pack_blob(ctx, s, ctx->d_textures, ctx->d_jh_data, blob);
 	if (rc) return rc;
 	if (ctx->d_blob) { (void)hipFree(ctx->d_blob); ctx->d_blob = nullptr; }
@@ -1064,6 +1101,21 @@ int ssx_lanestat(unsigned long long* out, int reset) {
 }
 #endif
 
+int ssx_set_jit(ssx_ctx* ctx, int enable) {
+	if (!ctx) return SSX_ERR_ARG;
+	ctx->jit = enable != 0;
+	return SSX_OK;
+}
+
+int ssx_debug_pass1_source(const uint8_t* vid, uint32_t n_quads, const char* name, char* out, size_t out_size) {
+	if (!vid || !name || n_quads == 0 || n_quads > 32u) return SSX_ERR_ARG;
+	ssx_jit::VidTable t(n_quads);
+	for (uint32_t q = 0; q < n_quads; ++q) for (int v = 0; v < 4; ++v) t[q][v] = vid[4 * q + v];
+	const std::string text = ssx_jit::pass1_source(name, t);
+	if (out && out_size) { const size_t n = text.size() < out_size - 1 ? text.size() : out_size - 1; memcpy(out, text.data(), n); out[n] = '\0'; }
+	return (int)text.size();
+}
+
 int ssx_calibration_info(ssx_ctx* ctx, float* frames_per_sample, float* rays_left_per_sample, int* camera_rays_pretraced) {
 	if (!ctx) return SSX_ERR_ARG;
 	if (!ctx->have_scene) return fail(ctx, SSX_ERR_STATE, "no scene uploaded");
@@ -1086,10 +1138,10 @@ const char* ssx_kernel_name(ssx_ctx* ctx) {
 	if (!ctx || !ctx->have_scene) return nullptr;
 	if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
 	uint32_t qw = 0;
-	if (pick_queue(ctx, ctx->topology, ctx->path_blob_words, &qw, nullptr) != SSX_OK) return nullptr;
-	static const char* const names[3][2] = { { "ssx_render_kernel", "ssx_render_kernel_nq" }, { "ssx_render_kernel_cornell", "ssx_render_kernel_cornell_nq" },
-	                                         { "ssx_render_kernel_plane", "ssx_render_kernel_plane_nq" } };
-	return names[ctx->topology < 3u ? ctx->topology : 0u][qw == SSX_QUEUE_WORDS_NARROW ? 1 : 0];
+	if (pick_queue(ctx, ctx->path_blob_words, &qw, nullptr) != SSX_OK) return nullptr;
+	static const char* const names[4][2] = { { "ssx_render_kernel", "ssx_render_kernel_nq" }, { "ssx_render_kernel_cornell", "ssx_render_kernel_cornell_nq" },
+	                                         { "ssx_render_kernel_plane", "ssx_render_kernel_plane_nq" }, { "ssx_render_kernel_jit", "ssx_render_kernel_jit_nq" } };
+	return names[ctx->topology < 4u ? ctx->topology : 0u][qw == SSX_QUEUE_WORDS_NARROW ? 1 : 0];
 }
 
 int ssx_plan_info(ssx_ctx* ctx, float* frames_per_sample, int* fold_in_path_kernel) {
@@ -1105,9 +1157,15 @@ int ssx_kernel_info(ssx_ctx* ctx, int* vgprs, int* sgprs, int* lds_bytes, int* s
 	SSX_HIP(ctx, hipSetDevice(ctx->device));
 	hipFuncAttributes at;
 	uint32_t qw = 0; int nb = 0;
-	int r = pick_queue(ctx, ctx->topology, ctx->path_blob_words, &qw, &nb);
+	int r = pick_queue(ctx, ctx->path_blob_words, &qw, &nb);
 	if (r) return r;
-	SSX_HIP(ctx, hipFuncGetAttributes(&at, (const void*)path_kernel_of(ctx->topology, qw == SSX_QUEUE_WORDS_NARROW)));
+	const KernelRef k = path_kernel_ref(ctx, qw == SSX_QUEUE_WORDS_NARROW);
+	if (k.mod) {
+		int v = 0;
+		SSX_HIP(ctx, hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_NUM_REGS, k.mod)); at.numRegs = v;
+		SSX_HIP(ctx, hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, k.mod)); at.sharedSizeBytes = (size_t)v;
+		SSX_HIP(ctx, hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, k.mod)); at.localSizeBytes = (size_t)v;
+	} else SSX_HIP(ctx, hipFuncGetAttributes(&at, k.host));
 	if (vgprs) *vgprs = at.numRegs;
 	if (sgprs) *sgprs = 0;
 	if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes + (int)path_lds_bytes(ctx->path_blob_words, qw);

@@ -22,7 +22,9 @@
 // candidate triangles finished in a second pass) each individual operation still sees the same
 // operands, so every intermediate is the same float.
 #include <hip/hip_runtime.h>
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 #include "ssx_blob.h"
 #include "ssx_exact.h"
@@ -33,7 +35,11 @@
 // scene blob (same object as the buffers the kernels store to, so the loads stay where they are used).
 extern __shared__ __attribute__((aligned(16))) uint32_t ssx_lds[];
 #define SSX_FM_TABLE (reinterpret_cast<const double*>(ssx_lds))
+#ifdef SSX_JIT_BUILD // run-time compilation (csrc/ssx_jit.h): the sources come as named strings, not from the tree
+#include "ssx_fmath.h"
+#else
 #include "../../include/ssx_fmath.h"
+#endif
 __device__ const double ssx_fm_coeff_values[SSX_FM_N_COEFF] = SSX_FM_COEFF_INIT;
 static_assert(2 * SSX_FM_N_COEFF <= SSX_LDS_PREFIX_WORDS, "coefficient table");
 // stages the coefficient table and the scene blob; returns the blob's LDS address
@@ -491,6 +497,9 @@ __device__ __forceinline__ SV shear_xyz(float x, float y, float z, const RaySetu
 
 } // namespace
 #include "ssx_pass1_gen.h" // pass1_cornell / pass1_plane: pass 1 straight-line for the built-in scenes' mesh topologies
+#ifdef SSX_JIT_BUILD
+#include "ssx_pass1_jit.h" // pass1_jit: the same for the uploaded scene's topology, generated at upload (csrc/ssx_jit.h)
+#endif
 namespace {
 
 // scene.cpp:433-445 + geometry.cpp:128-139 + geometry.cpp:12-101.
@@ -502,7 +511,8 @@ namespace {
 // dist, closest-so-far with strict '<' -- and skip tri1 when tri0 of the same quad was accepted
 // (the `goto HIT` of PrimQuad::intersect).
 // has_ray = false: the lane takes part in the wave-uniform pass 1 but traces nothing.
-// TOPO: 0 = any scene (loop over quads, per-quad vertex table); 1, 2 = the scene's corners coincide in the pattern of
+// TOPO: 0 = any scene (loop over quads, per-quad vertex table); 3 = pass 1 generated for the scene's own pattern at upload
+// and compiled at run time (csrc/ssx_jit.h), otherwise as 1 and 2; 1, 2 = the scene's corners coincide in the pattern of
 // the reference's Cornell box / plane scene (ssx_upload_scene checks): pass 1 is the generated straight-line code that
 // shears every distinct vertex once and evaluates every distinct edge once (tools/gen_pass1.py), pass 2 looks its three
 // vertices up in the distinct-vertex table.  Same floats, same candidates, same hits either way.
@@ -549,6 +559,9 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		const uint32_t n0 = min(ng, 16u), n1 = ng - n0;
 		if constexpr (TOPO == 1) pass1_cornell(L.vtab(rs.perm), rs, acc0, acc1);
 		else if constexpr (TOPO == 2) pass1_plane(L.vtab(rs.perm), rs, acc0, acc1);
+#ifdef SSX_JIT_BUILD
+		else if constexpr (TOPO == 3) pass1_jit(L.vtab(rs.perm), rs, acc0, acc1);
+#endif
 		else {
 			for (uint32_t q = 0; q < n0; ++q) quad_flags(base + q, acc0);
 			for (uint32_t q = 16u; q < ng; ++q) quad_flags(base + q, acc1);
@@ -1258,9 +1271,13 @@ __device__ __forceinline__ void generate_body(const SsxKernelArgs& a) {
 }
 #define SSX_GENERATE_KERNEL(name, topo) \
 	extern "C" __global__ void __launch_bounds__(256) name(SsxKernelArgs a) { generate_body<topo>(a); }
+#ifdef SSX_JIT_BUILD
+SSX_GENERATE_KERNEL(ssx_generate_kernel_jit, 3)
+#else
 SSX_GENERATE_KERNEL(ssx_generate_kernel, 0)
 SSX_GENERATE_KERNEL(ssx_generate_kernel_cornell, 1)
 SSX_GENERATE_KERNEL(ssx_generate_kernel_plane, 2)
+#endif
 
 // Stage 2 of 3: the path megakernel.  Work unit of one wave64 = one 8x8 tile (Framebuffer::Tile,
 // renderer.cpp:396-409) x a group of consecutive samples; its items (pixel of the tile, k) are
@@ -1513,6 +1530,10 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 // size (wide / narrow, ssx_blob.h); the host picks.
 #define SSX_PATH_KERNEL(name, topo, narrow, waves) \
 	extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(waves))) name(SsxKernelArgs a) { render_body<topo, narrow>(a); }
+#ifdef SSX_JIT_BUILD // the run-time compilation holds the two path kernels of the uploaded scene's topology, nothing else
+SSX_PATH_KERNEL(ssx_render_kernel_jit, 3, false, SSX_WAVES_PER_EU)
+SSX_PATH_KERNEL(ssx_render_kernel_jit_nq, 3, true, SSX_WAVES_PER_EU)
+#else
 SSX_PATH_KERNEL(ssx_render_kernel, 0, false, SSX_WAVES_PER_EU)
 SSX_PATH_KERNEL(ssx_render_kernel_cornell, 1, false, SSX_WAVES_PER_EU)
 #ifndef SSX_PROBE_BUILD // tools/kernel_resources.py --probe: the two kernels above only (register pressure experiments)
@@ -1525,7 +1546,9 @@ SSX_PATH_KERNEL(ssx_render_kernel_plane_nq, 2, true, SSX_WAVES_PER_EU)
 // kernel traces and statistics of ssx_render_kernel* contain real launches only.  Narrow queue entries: it stages the
 // whole blob, which may only fit with them.
 extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) ssx_calibrate_kernel(SsxKernelArgs a) { render_body<0, true, true>(a); }
+#endif
 
+#ifndef SSX_JIT_BUILD
 // renderer.cpp:296,298: avg *= 1000.0/spp, then the float conversion of CIEXYZ_32F(avg) / avg.a.
 // Pixels of tiles this device does not own are written as 0 (x+0 is exact in the framebuffer sum).
 extern "C" __global__ void __launch_bounds__(256) ssx_finalize_kernel(const double* accum, float4* out, uint32_t width, uint32_t height,
@@ -1559,3 +1582,4 @@ extern "C" __global__ void __launch_bounds__(256) ssx_sum_kernel(float4* dst, co
 	const float4 a = dst[p], b = src[p];
 	dst[p] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
+#endif // !SSX_JIT_BUILD

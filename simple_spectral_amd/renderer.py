@@ -50,6 +50,7 @@ class Options:
     meng_grid_path: Optional[str] = None  # "SSXMENG1" file converted from the authors' header (simple_spectral_amd/meng.py)
     jh_res: int = 64                     # resolution of the fitted JH model when no coefficient file exists
     jh_coeff_path: Optional[str] = None  # data/jakob-and-hanika-2019-srgb.coeff in the reference (missing blob)
+    jit_pass1: bool = False              # ssx_set_jit: compile pass 1 for the mesh topology of scenes that match no built-in one (hipRTC, ~5 s)
     device: int = 0
     tile_first: int = 0
     tile_stride: int = 1
@@ -153,6 +154,8 @@ class Renderer:
         rc = self._lib.ssx_create(options.device, C.byref(self._ctx))
         if rc != 0:
             raise SsxError(rc, self._lib.ssx_last_error(None).decode())
+        if options.jit_pass1:
+            self._check(self._lib.ssx_set_jit(self._ctx, 1))
         self._check(self._lib.ssx_upload_scene(self._ctx, self.scene.desc))
         W, H = options.res
         self.xyza = np.zeros((H, W, 4), dtype=np.float32)
@@ -202,6 +205,9 @@ class Renderer:
         p = self.params(**over)
         self._check(self._lib.ssx_render_device(self._ctx, C.byref(p), C.c_void_p(d_ptr), C.c_void_p(stream)))
 
+    def set_jit(self, enable=True):
+        self._check(self._lib.ssx_set_jit(self._ctx, int(enable)))
+
     def upload_scene_desc(self, desc):
         """Replace the scene by an arbitrary ssx_scene_desc (the flat description the C ABI takes)."""
         self._check(self._lib.ssx_upload_scene(self._ctx, C.byref(desc) if not hasattr(desc, "contents") else desc))
@@ -248,7 +254,7 @@ class Renderer:
         """What the calibration render at scene upload found: frames per sample, and where the fold runs."""
         f, k = C.c_float(), C.c_int()
         self._check(self._lib.ssx_plan_info(self._ctx, C.byref(f), C.byref(k)))
-        variant = {0: "generic", 1: "cornell topology", 2: "plane topology"}.get(self._lib.ssx_kernel_variant(self._ctx), "?")
+        variant = {0: "generic", 1: "cornell topology", 2: "plane topology", 3: "scene topology (compiled at upload)"}.get(self._lib.ssx_kernel_variant(self._ctx), "?")
         name = self._lib.ssx_kernel_name(self._ctx)
         left, pre = C.c_float(), C.c_int()
         if hasattr(self._lib, "ssx_calibration_info"):  # (an older build loaded through SSX_HIP_LIB_OVERRIDE for an A/B run has neither)

@@ -492,6 +492,50 @@ def test_pass1_variants_specialised_for_builtin_topologies_generic_otherwise():
     assert out.returncode == 0, out.stdout[-3000:]
 
 
+def test_pass1_compiled_at_upload_for_any_topology():
+    """with ssx_set_jit the scene that matches no built-in topology -- the Cornell box with one corner
+    moved apart from its twin -- gets ITS straight-line pass 1: generated at upload (csrc/ssx_jit.h, the generator of
+    tools/gen_pass1.py in C++), compiled with hipRTC, launched from the module.  Same bits as the generic loop and the
+    oracle; a second upload of the same pattern reuses the code; a scene with triangles or more than 32 primitives stays
+    generic.  (tools/jit_rate.py measures the three rates side by side.)"""
+    import time
+    import crafted
+    import custom_scene as cs
+    c = cs.CustomScene("cornell-srgb")
+    pos, st, m = c.quads[0]
+    pos = pos.copy(); pos[0, 0] += 1.0
+    c.quads[0] = (pos, st, m)
+    orc = c.oracle()
+    r = Renderer(Options(scene_name="cornell-srgb", res=(40, 32), spp=4, seed=3, texture="test-img.png", jit_pass1=True))
+    assert r.plan_info()["pass1"] == "cornell topology"                       # a built-in pattern keeps its built-in kernel
+    t = time.time(); r.upload_scene_desc(c.desc(orc)); first = time.time() - t
+    info = r.plan_info()
+    assert info["pass1"].startswith("scene topology") and info["kernel"] == "ssx_render_kernel_jit"
+    assert r.kernel_info()["vgprs"] <= 128 and r.kernel_info()["scratch_bytes"] == 0
+    r.render_start(); r.render_wait()
+    ref = orc.render(40, 32, 4, seed=3)
+    assert np.array_equal(bits(r.xyza), bits(ref))
+    xyza, state, _ = r.debug_samples()
+    ref_xyza, ref_state, _st = orc.samples(40, 32, 4, seed=3)
+    assert np.array_equal(state, ref_state) and np.array_equal(bits(xyza), bits(ref_xyza))
+    t = time.time(); r.upload_scene_desc(c.desc(orc)); again = time.time() - t   # same pattern: no second compilation
+    assert again < 0.5 * first or again < 1.0, (first, again)
+    # CIE 2006 tables + this pattern: the narrow-queue kernel of the same module
+    c6 = cs.CustomScene("cornell-srgb", observer=2006)
+    c6.quads[0] = (pos, st, m)
+    orc6 = c6.oracle()
+    r6 = Renderer(Options(scene_name="cornell-srgb", res=(24, 24), spp=3, seed=5, texture="test-img.png", observer=2006, jit_pass1=True))
+    r6.upload_scene_desc(c6.desc(orc6))
+    assert r6.plan_info()["kernel"] == "ssx_render_kernel_jit_nq"
+    r6.render_start(); r6.render_wait()
+    assert np.array_equal(bits(r6.xyza), bits(orc6.render(24, 24, 3, seed=5)))
+    # not candidates: triangles, more than 32 primitives
+    ct = crafted.triangle_scene()
+    rt = Renderer(Options(scene_name="cornell", res=(8, 8), spp=1, jit_pass1=True))
+    rt.upload_scene_desc(ct.desc(ct.oracle()))
+    assert rt.plan_info()["pass1"] == "generic"
+
+
 def test_shadow_queue_layouts_wide_by_default_narrow_when_it_buys_a_workgroup():
     """The shadow-ray queues have 48-byte entries (the contribution rides along, the flush writes the finished
     next-event term) unless 32-byte entries (contribution to HBM at park time, visibility byte at flush time)

@@ -204,3 +204,35 @@ def test_generated_pass1_header_is_up_to_date():
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     assert subprocess.run([sys.executable, os.path.join(root, "tools", "gen_pass1.py"), "--check"]).returncode == 0
+
+
+def test_runtime_pass1_generator_equals_the_committed_one():
+    """ssx_set_jit compiles pass 1 for an uploaded scene's own mesh topology; its C++ generator (csrc/ssx_jit.h) must write what
+    tools/gen_pass1.py wrote into csrc/ssx_pass1_gen.h for the two built-in topologies, character for character (no device
+    needed: ssx_debug_pass1_source only generates text)."""
+    import ctypes as C
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gen_pass1
+    from simple_spectral_amd import build as b
+    lib = C.CDLL(b.HIP_LIB)
+    lib.ssx_debug_pass1_source.argtypes = [C.POINTER(C.c_uint8), C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t]
+    header = open(os.path.join(root, "simple_spectral_amd", "csrc", "ssx_pass1_gen.h")).read()
+    for name, _tid, scene in gen_pass1.TOPOLOGIES:
+        vids = gen_pass1.scene_vids(scene)
+        flat = (C.c_uint8 * (4 * len(vids)))(*[v for row in vids for v in row])
+        buf = C.create_string_buffer(1 << 20)
+        n = lib.ssx_debug_pass1_source(flat, len(vids), name.encode(), buf, len(buf))
+        assert 0 < n < len(buf)
+        text = buf.value.decode()
+        assert text == "\n".join(gen_pass1.emit_topology(name, vids)) + "\n"
+        assert text in header
+    # and a pattern of its own: two quads sharing an edge, one apart
+    vids = [[0, 1, 2, 3], [1, 4, 5, 2], [6, 7, 8, 9]]
+    flat = (C.c_uint8 * 12)(*[v for row in vids for v in row])
+    buf = C.create_string_buffer(1 << 16)
+    lib.ssx_debug_pass1_source(flat, 3, b"jit", buf, len(buf))
+    text = buf.value.decode()
+    assert text == "\n".join(gen_pass1.emit_topology("jit", vids)) + "\n"
+    assert "10 distinct vertices of 12 corners, 14 distinct edges of 15" in text and text.count("// quads") == 2

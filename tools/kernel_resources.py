@@ -4,6 +4,9 @@
     Cornell path kernels only: a third of the compile time, for register-pressure experiments)"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from simple_spectral_amd import build as _b
+_b.embed_sources()
 probe = "--probe" in sys.argv
 if probe:
     sys.argv.remove("--probe")
