@@ -139,7 +139,7 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 #define SSX_MAX_UNIT_KS 8u        // most samples per pixel in a work unit: four cohorts (the host picks 4 or 8 per scene, make_batch)
 #endif
 #define SSX_UNIT_COHORTS (SSX_MAX_UNIT_KS / SSX_COHORT_KS)  // a power of two
-#define SSX_WAVE_COUNTER_WORDS (4u * SSX_UNIT_COHORTS) // per wave, behind the shadow-ray queues: fill counts [unit tag 2][cohort][fs, nee]
+#define SSX_WAVE_COUNTER_WORDS (4u * SSX_UNIT_COHORTS + 4u) // per wave, behind the shadow-ray queues: fill counts [unit tag 2][cohort][fs, nee], then the wave's hand-over word (wave_release / wave_acquire; 3 words of padding)
 #define SSX_BYTES_PER_SAMPLE (16u + 16u + 16u)         // ray, st, hit
 #define SSX_LOG_BYTES_PER_RECORD ((16u + 8u + 4u) * SSX_MAX_FRAMES + (16u + 16u + 1u) * SSX_MAX_LEVELS) // fs, np, link; nee, direct, vis
 
