@@ -184,6 +184,11 @@ int ssx_render_stop(ssx_ctx* ctx);
 int ssx_is_rendering(ssx_ctx* ctx);
 /* the `part` of Renderer::_print_progress (src/renderer.cpp:75): fraction in [0,1] */
 float ssx_progress(ssx_ctx* ctx);
+/* Samples per pixel accumulated so far by the render started last (== ssx_render_params.spp once it has completed).  After
+ * ssx_render_stop the image is the mean over THESE samples for every pixel -- the reference instead keeps finished tiles at
+ * full spp next to untouched checkerboard tiles (src/renderer.cpp:388-394, src/framebuffer.cpp:9-33); with several devices
+ * each context may have stopped at another count, which the caller can read here. */
+uint32_t ssx_done_spp(ssx_ctx* ctx);
 /* Renderer::render_wait (src/renderer.cpp:423-430) + read-back of what `framebuffer(i,j)=...`
  * (src/renderer.cpp:298) would receive BEFORE ciexyz_to_srgb: float4 {X,Y,Z,alpha} per pixel,
  * index j*W+i, row 0 = bottom (src/framebuffer.hpp:26-34).  xyza_out may be NULL. */

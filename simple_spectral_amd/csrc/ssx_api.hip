@@ -942,6 +942,8 @@ float ssx_progress(ssx_ctx* ctx) {
 	return (float)ctx->done_spp.load() / (float)ctx->total_spp;
 }
 
+uint32_t ssx_done_spp(ssx_ctx* ctx) { return ctx ? ctx->done_spp.load() : 0u; }
+
 int ssx_render_wait(ssx_ctx* ctx, float* xyza_out) {
 	if (!ctx) return SSX_ERR_ARG;
 	if (!ctx->worker.joinable()) return fail(ctx, SSX_ERR_STATE, "no render was started");

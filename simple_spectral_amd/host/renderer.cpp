@@ -38,6 +38,7 @@ struct Renderer::Api {
 	int (*device_index)(ssx_ctx*) = nullptr;
 	int (*read_framebuffer)(ssx_ctx*, float*) = nullptr;
 	int (*accumulate_peer)(ssx_ctx*, void*, int, const void*, uint32_t, uint32_t, void*) = nullptr;
+	uint32_t (*done_spp)(ssx_ctx*) = nullptr;
 
 	explicit Api(const std::string& path) {
 		handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
@@ -60,6 +61,7 @@ struct Renderer::Api {
 		device_index = reinterpret_cast<decltype(device_index)>(sym("ssx_device_index"));
 		read_framebuffer = reinterpret_cast<decltype(read_framebuffer)>(sym("ssx_read_framebuffer"));
 		accumulate_peer = reinterpret_cast<decltype(accumulate_peer)>(sym("ssx_accumulate_peer"));
+		done_spp = reinterpret_cast<decltype(done_spp)>(sym("ssx_done_spp"));
 	}
 	~Api() { if (handle) dlclose(handle); }
 };
@@ -203,6 +205,14 @@ void Renderer::render_wait() {
 	for (ssx_ctx* c : ctxs_) {
 		int rc = api_->render_wait(c, nullptr);
 		if (rc) throw HostError{ rc, std::string("ssx_render_wait: ") + api_->last_error(c) };
+	}
+	// a stopped render: every device's share is the mean over the samples IT accumulated (ssx.h: ssx_done_spp); say so when the
+	// counts differ from the request, as the image then is not what the reference would have left (finished tiles next to
+	// untouched ones, src/renderer.cpp:388-394)
+	for (size_t d = 0; d < ctxs_.size(); ++d) {
+		const uint32_t done = api_->done_spp(ctxs_[d]);
+		if (done != static_cast<uint32_t>(options.spp))
+			std::fprintf(stderr, "Render stopped: device %d accumulated %u of %zu samples per pixel; its tiles hold the mean over those.\n", api_->device_index(ctxs_[d]), done, static_cast<size_t>(options.spp));
 	}
 	ssx_ctx* root = ctxs_[0];
 	for (size_t d = 1; d < ctxs_.size(); ++d) {

@@ -193,6 +193,10 @@ class Renderer:
     def progress(self):
         return float(self._lib.ssx_progress(self._ctx))
 
+    def done_spp(self):
+        """Samples per pixel accumulated so far (after render_stop: what the partial image is the mean of)."""
+        return int(self._lib.ssx_done_spp(self._ctx))
+
     def render_wait(self):
         self._check(self._lib.ssx_render_wait(self._ctx, self.xyza.ctypes.data))
         self.framebuffer = self.scene.xyza_to_srgba(self.xyza)  # src/renderer.cpp:298
