@@ -344,12 +344,17 @@ int check_params(ssx_ctx* ctx, const ssx_render_params* p) {
 	return SSX_OK;
 }
 
-int ensure_buffers(ssx_ctx* ctx, size_t pixels, bool need_out) {
-	if (ctx->accum_pixels < pixels) {
+// The pixel sums are laid out per 8x8 tile as [tile][X, Y, Z, alpha][pixel of the tile] (binary64), so that the 64 lanes of a
+// folding wave read and write 512 consecutive bytes per component: one slot per pixel of every (whole) tile of the image.
+size_t accum_slots(uint32_t width, uint32_t height) { return (size_t)((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u; }
+
+int ensure_buffers(ssx_ctx* ctx, uint32_t width, uint32_t height, bool need_out) {
+	const size_t pixels = (size_t)width * height, slots = accum_slots(width, height);
+	if (ctx->accum_pixels < slots) {
 		if (ctx->d_accum) (void)hipFree(ctx->d_accum);
 		ctx->d_accum = nullptr; ctx->accum_pixels = 0;
-		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_accum, pixels * 4 * sizeof(double)));
-		ctx->accum_pixels = pixels;
+		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_accum, slots * 4 * sizeof(double)));
+		ctx->accum_pixels = slots;
 	}
 	if (need_out && ctx->out_pixels < pixels) {
 		if (ctx->d_out) (void)hipFree(ctx->d_out);
@@ -689,7 +694,7 @@ void worker_main(ssx_ctx* ctx) {
 	auto run = [&]() -> int {
 		SSX_HIP(ctx, hipSetDevice(ctx->device));
 		size_t pixels = (size_t)p.width * p.height;
-		SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, pixels * 4 * sizeof(double), ctx->stream));
+		SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, accum_slots(p.width, p.height) * 4 * sizeof(double), ctx->stream));
 		LaunchPlan pl = make_plan(ctx, &p);
 		// progress / cancel granularity: 1/32 of the render, but at least ~32 M samples (~20 ms) per launch so
 		// that the synchronisation between launches stays a few percent
@@ -890,13 +895,13 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	{
 		LaunchPlan probe = make_plan(ctx, p);
 		const size_t need = (size_t)probe.args.my_tiles * 64u * (p->spp < probe.max_spp_per_launch ? p->spp : probe.max_spp_per_launch);
-		if (ctx->device_pending && (ctx->accum_pixels < pixels || ctx->sample_slots < need)) {
+		if (ctx->device_pending && (ctx->accum_pixels < accum_slots(p->width, p->height) || ctx->sample_slots < need)) {
 			SSX_HIP(ctx, hipEventSynchronize(ctx->ev_device_done));
 			ctx->device_pending = false;
 		}
 	}
-	if ((rc = ensure_buffers(ctx, pixels, false))) return rc;
-	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, pixels * 4 * sizeof(double), stream));
+	if ((rc = ensure_buffers(ctx, p->width, p->height, false))) return rc;
+	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, accum_slots(p->width, p->height) * 4 * sizeof(double), stream));
 	LaunchPlan pl = make_plan(ctx, p);
 	// one batch when the whole render fits the buffer budget, else batches back to back
 	uint32_t batch = p->spp_per_launch ? p->spp_per_launch : p->spp;
@@ -918,7 +923,7 @@ int ssx_render_start(ssx_ctx* ctx, const ssx_render_params* p) {
 	if (ctx->worker.joinable()) ctx->worker.join();
 	SSX_HIP(ctx, hipSetDevice(ctx->device));
 	if (ctx->device_pending) { SSX_HIP(ctx, hipEventSynchronize(ctx->ev_device_done)); ctx->device_pending = false; } // a queued ssx_render_device uses the same buffers
-	if ((rc = ensure_buffers(ctx, (size_t)p->width * p->height, true))) return rc;
+	if ((rc = ensure_buffers(ctx, p->width, p->height, true))) return rc;
 	ctx->cur = *p;
 	ctx->total_spp = p->spp;
 	ctx->done_spp.store(0);
@@ -1069,11 +1074,11 @@ int ssx_debug_samples(ssx_ctx* ctx, const ssx_render_params* p, float* xyza, uin
 	SSX_HIP(ctx, hipSetDevice(ctx->device));
 	if (ctx->device_pending) { SSX_HIP(ctx, hipEventSynchronize(ctx->ev_device_done)); ctx->device_pending = false; }
 	const size_t pixels = (size_t)p->width * p->height;
-	if ((rc = ensure_buffers(ctx, pixels, false))) return rc;
+	if ((rc = ensure_buffers(ctx, p->width, p->height, false))) return rc;
 	LaunchPlan pl = make_plan(ctx, p);
 	if (p->spp > pl.max_spp_per_launch) return fail(ctx, SSX_ERR_ARG, "ssx_debug_samples: too many samples for one launch");
 	if ((rc = ensure_samples(ctx, pl, p->spp))) return rc;
-	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, pixels * 4 * sizeof(double), ctx->stream));
+	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, accum_slots(p->width, p->height) * 4 * sizeof(double), ctx->stream));
 	Batch b = make_batch(ctx, pl, 0, p->spp);
 	b.a.keep_samples = 1u; // the fold leaves every sample's {X, Y, Z, alpha} in ray[]
 	if ((rc = enqueue_front(ctx, pl, b, ctx->stream))) return rc;

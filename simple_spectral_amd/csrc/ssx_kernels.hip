@@ -3,7 +3,7 @@
 // Path covered (reference file:line, paths relative to the reference's src/):
 //   renderer.cpp:309-395  tile loop            -> persistent waves fetching work units (8x8 tile x 8
 //                                                 samples per pixel); lanes take (pixel, k) items
-//   renderer.cpp:278-299  _render_pixel        -> ssx_accumulate_kernel: f64 XYZA sum in ascending k
+//   renderer.cpp:278-299  _render_pixel        -> the f64 XYZA pixel sums, continued in ascending k by the fold of every work unit (unit_fold)
 //   renderer.cpp:104-277  _render_sample / L   -> ssx_generate_kernel (camera ray, lambda_0), then the
 //                                                 iterative path loop of ssx_render_kernel with the
 //                                                 shadow rays parked and traced 64 at a time, and the
@@ -1148,7 +1148,7 @@ __device__ __forceinline__ float4 nee_term(const SsxKernelArgs& a, uint32_t i, b
 // fs_base / nee_base: index of slot 0 of the cohort's logs (log_rec * 9, log_rec * 10); rc0: the lane's pixel of the tile
 // (its first sample within the cohort; way s is sample rc0 + 64 s)
 template <uint32_t WAYS, bool NARROW>
-__device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count, uint32_t fs_base, uint32_t nee_base, uint32_t rc0, double* px) {
+__device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count, uint32_t fs_base, uint32_t nee_base, uint32_t rc0, double* px, double* acc_regs = nullptr) {
 	float rad[WAYS][4];
 	uint32_t depth[WAYS]; // hit_anything << 4 | number of continued levels
 	uint32_t K[WAYS]; // chain word of the level about to be folded: its entry's `link` (parent slot | nee slot << 13 | emission << 26)
@@ -1206,7 +1206,11 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 			}
 	}
 	// the pixel's running sums (unit_fold): loaded here, behind the chain walk, whose registers they would otherwise take
-	double acc[4] = { ld_agent(px), ld_agent(px + 1), ld_agent(px + 2), ld_agent(px + 3) };
+#ifdef SSX_ACC_REGS
+	double* const acc = acc_regs; (void)px;
+#else
+	double acc[4] = { ld_agent(px), ld_agent(px + 64), ld_agent(px + 128), ld_agent(px + 192) };
+#endif
 #pragma unroll
 	for (uint32_t s = 0; s < WAYS; ++s)
 		if (s < count) {
@@ -1229,7 +1233,9 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 			else { acc[0] += (double)(xyz[0] * 0.001f); acc[1] += (double)(xyz[1] * 0.001f); acc[2] += (double)(xyz[2] * 0.001f); acc[3] += (double)(alpha * 0.001f); }
 			if (a.keep_samples) a.ray[r0 + s * stride] = make_float4(xyz[0], xyz[1], xyz[2], alpha); // ssx_debug_samples: what _render_sample returns
 		}
-	st_agent(px, acc[0]); st_agent(px + 1, acc[1]); st_agent(px + 2, acc[2]); st_agent(px + 3, acc[3]);
+#ifndef SSX_ACC_REGS
+	st_agent(px, acc[0]); st_agent(px + 64, acc[1]); st_agent(px + 128, acc[2]); st_agent(px + 192, acc[3]);
+#endif
 }
 
 } // namespace
@@ -1305,7 +1311,7 @@ SSX_GENERATE_KERNEL(ssx_generate_kernel_plane, 2)
 // factors go to the per-level arrays) and a backward fold over them when the wave has finished its unit.
 struct WorkUnit { // wave-uniform description of one work unit: 8x8 tile x a group of consecutive samples (four SGPRs: a wave holds two)
 	uint32_t slot, k_off;   // tile slot (index into the device's tiles) and first sample of the unit relative to the launch's k0
-	uint32_t pixel0;        // framebuffer index of the tile's pixel (0, 0)
+	uint32_t tile;          // the tile's index in the image's row-major tile list (its block of the pixel sums)
 	uint32_t dims;          // tile width | tile height << 4 | samples per pixel << 8
 	__device__ __forceinline__ uint32_t tw() const { return dims & 15u; }
 	__device__ __forceinline__ uint32_t th() const { return (dims >> 4) & 15u; }
@@ -1323,7 +1329,7 @@ __device__ __forceinline__ void unit_setup(const SsxKernelArgs& a, uint32_t unit
 	const uint32_t kb = min(ka + a.group_spp, a.k1);
 	u.dims = min(8u, a.width - tx * 8u) | (min(8u, a.height - ty * 8u) << 4) | ((kb - ka) << 8);
 	u.slot = slot; u.k_off = ka - a.k0;
-	u.pixel0 = ty * 8u * a.width + tx * 8u;
+	u.tile = tile;
 }
 // Every lane folds the records of its own pixel of a finished unit.  The loads (levels and records
 // this wave wrote during the unit) overlap with the arithmetic of the other waves on the SIMD, which
@@ -1336,7 +1342,7 @@ __device__ __forceinline__ void unit_setup(const SsxKernelArgs& a, uint32_t unit
 // tiles earlier, to a wave that is resident and running (persistent grid: every unit handed out is being worked on, and
 // waits only ever point to earlier units), so the wait is short and cannot deadlock.  accum and tile_done are touched only
 // with agent-scope atomic loads and stores (performed at the device's point of coherence, whichever XCD's L2 the two
-// waves sit behind); the sums are complete (s_waitcnt through the release fence) before the count is published.
+// waves sit behind); the sums are complete (s_waitcnt vmcnt(0)) before the count is published.
 template <bool NARROW>
 __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, const WorkUnit& u, uint32_t wave_slot, uint32_t tag, uint32_t* cnt) {
 	// see "Memory-ordering contract" above: the acquire side of the wave's hand-over; then wait for this wave's stores and
@@ -1355,16 +1361,30 @@ __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, 
 #endif
 	}
 	if ((lane & 7u) < u.tw() && (lane >> 3) < u.th()) {
-		double* const px = a.accum + 4u * (size_t)(u.pixel0 + (lane >> 3) * a.width + (lane & 7u));
+		double* const px = a.accum + (size_t)u.tile * 256u + lane; // [tile][component][pixel of the tile]: components 64 doubles apart
+#ifdef SSX_ACC_REGS
+		double acc[4] = { ld_agent(px), ld_agent(px + 64), ld_agent(px + 128), ld_agent(px + 192) };
+#else
+		double* const acc = nullptr;
+#endif
 		for (uint32_t kq = 0, n_kq = u.n_kq(), rec_base = u.rec_base(a); kq < n_kq; kq += SSX_RESOLVE_WAYS) { // one cohort per pass
 			const uint32_t log_rec = log_region(a, wave_slot, tag, kq / SSX_COHORT_KS);
-			resolve_records<SSX_RESOLVE_WAYS, NARROW>(L, a, rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, n_kq - kq), log_rec * SSX_MAX_FRAMES, log_rec * SSX_MAX_LEVELS, lane, px);
+			resolve_records<SSX_RESOLVE_WAYS, NARROW>(L, a, rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, n_kq - kq), log_rec * SSX_MAX_FRAMES, log_rec * SSX_MAX_LEVELS, lane, px, acc);
 		}
+#ifdef SSX_ACC_REGS
+		st_agent(px, acc[0]); st_agent(px + 64, acc[1]); st_agent(px + 128, acc[2]); st_agent(px + 192, acc[3]);
+#endif
 	}
 #ifdef SSX_ACCUM_FORMAL
 	if (lane == 0u) __hip_atomic_store(a.tile_done + u.slot, u.k_off + u.n_kq(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #else
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the sums have reached the point of coherence (vmcnt 0)
+	// The sums must have reached the device's point of coherence before the count is published: device-scope (sc1) stores are
+	// acknowledged from there, so waiting for this wave's outstanding vector-memory operations is the release.  (A workgroup-scope
+	// fence compiles to nothing here -- the first version relied on it and lost samples when a tile's units ran neck and neck:
+	// tests/test_gpu_parity.py::test_config1 / test_pixel_sums_chain; an agent-scope release fence adds an L2 write-back of
+	// everything the wave has ever written: -25 %.)
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	if (lane == 0u) __hip_atomic_store(a.tile_done + u.slot, u.k_off + u.n_kq(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
 }
@@ -1577,18 +1597,19 @@ extern "C" __global__ void __launch_bounds__(256) ssx_finalize_kernel(const doub
 	uint32_t i = p % width, j = p / width;
 	uint32_t tile = (j >> 3) * tiles_x + (i >> 3);
 	float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	const double* const px = accum + (size_t)tile * 256u + ((j & 7u) * 8u + (i & 7u)); // [tile][component][pixel of the tile] (unit_fold)
 	if (tile % tile_stride == tile_first && rgb_mode) { // renderer.cpp:304: avg /= double(spp)
 		const double n = (double)spp;
-		o.x = (float)(accum[4u * p + 0] / n);
-		o.y = (float)(accum[4u * p + 1] / n);
-		o.z = (float)(accum[4u * p + 2] / n);
-		o.w = (float)(accum[4u * p + 3] / n);
+		o.x = (float)(px[0] / n);
+		o.y = (float)(px[64] / n);
+		o.z = (float)(px[128] / n);
+		o.w = (float)(px[192] / n);
 	} else if (tile % tile_stride == tile_first) {
 		double sc = 1000.0 / (double)spp;
-		o.x = (float)(accum[4u * p + 0] * sc);
-		o.y = (float)(accum[4u * p + 1] * sc);
-		o.z = (float)(accum[4u * p + 2] * sc);
-		o.w = (float)(accum[4u * p + 3] * sc);
+		o.x = (float)(px[0] * sc);
+		o.y = (float)(px[64] * sc);
+		o.z = (float)(px[128] * sc);
+		o.w = (float)(px[192] * sc);
 	}
 	out[p] = o;
 }

@@ -442,6 +442,17 @@ def test_pixel_sums_chain_through_the_units_of_a_tile():
         got, _ = gpu_render(scene_name="cornell-srgb", res=(W, H), spp=spp, seed=33, texture="test-img.png", spp_per_launch=chunk)
         ref = ol.Oracle("cornell-srgb", texture="test-img.png").render(W, H, spp, seed=33)
         assert np.array_equal(bits(got), bits(ref)), (W, H, spp, chunk)
+    # Units that run neck and neck: 128 x 128 at 16 spp is 4096 units of ONE sample per pixel, all handed out at once, the 16 of a
+    # tile finishing within microseconds of each other -- every hand-over of the sums happens while the predecessor's stores are
+    # still on their way (this case lost samples before the hand-over waited for them).  40 renders, one oracle.
+    import torch
+    r = Renderer(Options(scene_name="cornell-srgb", res=(128, 128), spp=16, seed=2, texture="test-img.png"))
+    ref = ol.Oracle("cornell-srgb", texture="test-img.png").render(128, 128, 16, seed=2)
+    out = torch.zeros((128, 128, 4), device="cuda")
+    for _ in range(40):
+        r.render_device(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
 
 
 def test_many_units_per_wave_parity_and_determinism():
