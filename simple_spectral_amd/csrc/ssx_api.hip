@@ -76,6 +76,7 @@ struct ssx_ctx {
 	ssx_render_params cur{};
 
 	uint32_t* d_tile_done = nullptr; size_t tile_done_slots = 0; // per tile slot: samples per pixel accumulated in the running launch (ssx_blob.h)
+	uint32_t* d_tile_mask = nullptr; // per tile slot 4 words (same capacity): primitives the tile's camera rays can hit
 
 	// optional per-kernel timing (ssx_set_timing): events around each stage of each batch
 	bool timing = false;
@@ -143,7 +144,8 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	// refuse coordinates that could leave the range instead of losing bit parity silently
 	for (uint32_t i = 0; i < s->n_quads; ++i) {
 		const ssx_vertex* vs[4] = { &s->quads[i].v00, &s->quads[i].v10, &s->quads[i].v11, &s->quads[i].v01 };
-		for (const ssx_vertex* v : vs) for (float c : v->pos) if (!(std::fabs(c) <= 0x1p30f)) return fail(ctx, SSX_ERR_SCENE, "vertex coordinate beyond 2^30 (or not a number)");
+		const int nv = (s->quads[i].flags & SSX_PRIM_TRI) ? 3 : 4; // (a triangle's v01 is not part of the scene)
+		for (int v = 0; v < nv; ++v) for (float c : vs[v]->pos) if (!(std::fabs(c) <= 0x1p30f)) return fail(ctx, SSX_ERR_SCENE, "vertex coordinate beyond 2^30 (or not a number)");
 	}
 	for (float c : s->cam_pos) if (!(std::fabs(c) <= 0x1p30f)) return fail(ctx, SSX_ERR_SCENE, "camera position beyond 2^30 (or not a number)");
 	for (uint32_t i = 0; i < s->n_lights; ++i) if (s->lights[i] >= s->n_quads) return fail(ctx, SSX_ERR_ARG, "light index out of range");
@@ -261,7 +263,7 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	SsxBlobQuad* bq = reinterpret_cast<SsxBlobQuad*>(blob.data() + h.off_quads);
 	for (uint32_t q = 0; q < s->n_quads; ++q) {
 		const ssx_quad& Q = s->quads[q];
-		const ssx_vertex* vs[4] = { &Q.v00, &Q.v10, &Q.v11, &Q.v01 };
+		const ssx_vertex* vs[4] = { &Q.v00, &Q.v10, &Q.v11, (Q.flags & SSX_PRIM_TRI) ? &Q.v00 : &Q.v01 }; // a triangle's v01 is not part of the scene
 		for (uint32_t p = 0; p < 6; ++p) {
 			// (kx,ky,kz) of geometry.cpp:19-32: kz=0 -> (1,2,0); kz=1 -> (2,0,1); kz=2 -> (0,1,2); odd p swaps kx,ky
 			uint32_t kz = p >> 1, kx = (kz + 1) % 3, ky = (kz + 2) % 3;
@@ -568,14 +570,28 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	if (ctx->timing) { int r = timing_events(ctx, &b.tev); if (r) return r; SSX_HIP(ctx, hipEventRecord(b.tev[0], stream)); }
 	// the calibration render runs the generic kernels, which read the per-quad vertex table: they stage the whole blob
 	if (calibration) b.a.blob_words = ctx->blob_words;
+	// per-tile buffers of the launch: the progress words of the pixel sums, and the camera-ray primitive masks
+	if (ctx->tile_done_slots < b.a.my_tiles) { // (grown here, synchronously: the first launch of a larger image)
+		if (ctx->d_tile_done) { SSX_HIP(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->d_tile_done); (void)hipFree(ctx->d_tile_mask); }
+		ctx->d_tile_done = nullptr; ctx->d_tile_mask = nullptr; ctx->tile_done_slots = 0;
+		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_tile_done, (size_t)b.a.my_tiles * sizeof(uint32_t)));
+		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_tile_mask, (size_t)b.a.my_tiles * 4u * sizeof(uint32_t)));
+		ctx->tile_done_slots = b.a.my_tiles;
+	}
+	b.a.tile_done = ctx->d_tile_done; b.a.tile_mask = ctx->d_tile_mask;
 	{
-		// camera rays + their closest hits: persistent workgroups striding over the record waves (they stage the blob)
-		const uint32_t topo = calibration ? 0u : ctx->topology;
-		KernelRef gen_kernel;
-		if (topo == 3u && ctx->jit_kernels) gen_kernel.mod = ctx->jit_kernels->generate;
-		else gen_kernel.host = topo == 1u ? (const void*)ssx_generate_kernel_cornell : (topo == 2u ? (const void*)ssx_generate_kernel_plane : (const void*)ssx_generate_kernel);
-		const size_t gen_lds = ((size_t)b.a.blob_words + SSX_LDS_PREFIX_WORDS) * 4;
-		if (ctx->gen_blocks == 0 || calibration) {
+		// camera rays + (where the scene pre-traces them) their closest hits: persistent workgroups striding over the record
+		// waves; they stage the whole blob -- the trace is the generic one, restricted per tile to the primitives its frustum
+		// can contain (ssx_tile_mask_kernel, a few microseconds)
+		SsxKernelArgs ga = b.a;
+		ga.blob_words = ctx->blob_words;
+		if (ga.pre_hits) {
+			hipLaunchKernelGGL(ssx_tile_mask_kernel, dim3((ga.my_tiles + 3u) / 4u), dim3(256), 0, stream, ga);
+			SSX_HIP(ctx, hipGetLastError());
+		}
+		KernelRef gen_kernel; gen_kernel.host = (const void*)ssx_generate_kernel;
+		const size_t gen_lds = ((size_t)ga.blob_words + SSX_LDS_PREFIX_WORDS) * 4;
+		if (ctx->gen_blocks == 0) {
 			int per_cu = 0;
 			hipDeviceProp_t prop;
 			{ int r = occupancy_of(ctx, gen_kernel, gen_lds, &per_cu); if (r) return r; }
@@ -583,8 +599,7 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 			ctx->gen_blocks = (per_cu > 0 ? per_cu : 1) * prop.multiProcessorCount;
 		}
 		const uint64_t want = (b.n_rec + 255u) / 256u;
-		{ int r = launch_kernel(ctx, gen_kernel, (uint32_t)(want < (uint64_t)ctx->gen_blocks ? want : (uint64_t)ctx->gen_blocks), gen_lds, stream, b.a); if (r) return r; }
-		if (calibration) ctx->gen_blocks = 0;
+		{ int r = launch_kernel(ctx, gen_kernel, (uint32_t)(want < (uint64_t)ctx->gen_blocks ? want : (uint64_t)ctx->gen_blocks), gen_lds, stream, ga); if (r) return r; }
 	}
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[1], stream));
 	// persistent waves: as many workgroups as the GPU holds at once (or fewer, for a small launch); they
@@ -608,13 +623,6 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	KernelRef path_kernel = path_kernel_ref(ctx, b.a.queue_words == SSX_QUEUE_WORDS_NARROW);
 	if (calibration) { path_kernel = KernelRef(); path_kernel.host = (const void*)ssx_calibrate_kernel; }
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_unit_counter, 0, 2 * sizeof(uint32_t), stream));
-	if (ctx->tile_done_slots < b.a.my_tiles) { // (grown here, synchronously: the first launch of a larger image)
-		if (ctx->d_tile_done) { SSX_HIP(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->d_tile_done); }
-		ctx->d_tile_done = nullptr; ctx->tile_done_slots = 0;
-		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_tile_done, (size_t)b.a.my_tiles * sizeof(uint32_t)));
-		ctx->tile_done_slots = b.a.my_tiles;
-	}
-	b.a.tile_done = ctx->d_tile_done;
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_tile_done, 0, (size_t)b.a.my_tiles * sizeof(uint32_t), stream));
 	b.a.unit_counter = ctx->d_unit_counter;
 	const uint32_t want_blocks = (b.units + 3u) / 4u;
@@ -785,6 +793,7 @@ void ssx_destroy(ssx_ctx* ctx) {
 	if (ctx->d_peer) (void)hipFree(ctx->d_peer);
 	for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
 	if (ctx->d_tile_done) (void)hipFree(ctx->d_tile_done);
+	if (ctx->d_tile_mask) (void)hipFree(ctx->d_tile_mask);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }

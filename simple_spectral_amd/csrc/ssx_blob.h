@@ -167,6 +167,7 @@ struct SsxKernelArgs {
 	uint32_t fuse_resolve;    // 1: the path kernel folds each unit's samples when the unit is complete; 0: no fold (calibration render: only the tail words are read)
 	uint32_t unit_cohorts;    // cohorts per unit = ceil(group_spp / SSX_COHORT_KS): stride of the waves' log regions
 	double* accum;            // per pixel 4 x binary64: the running sums of _render_pixel (renderer.cpp:292-295), continued across launches
+	uint32_t* tile_mask;      // per tile slot 4 words: the primitives a camera ray through the tile can hit (ssx_tile_mask_kernel), for ssx_generate_kernel
 	uint32_t* tile_done;      // per tile slot: samples per pixel added to accum in this launch (zeroed before the launch): units of a tile take turns in k order
 	uint32_t no_flat_field;   // 1: flux = radiance * dot(camera_ray_dir, camera.dir) (renderer.cpp:264-265: built without FLAT_FIELD_CORRECTION)
 	uint32_t keep_samples;    // 1: the fold also writes each sample's {X, Y, Z, alpha} to ray[] (ssx_debug_samples)

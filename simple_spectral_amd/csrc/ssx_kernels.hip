@@ -516,8 +516,10 @@ namespace {
 // the reference's Cornell box / plane scene (ssx_upload_scene checks): pass 1 is the generated straight-line code that
 // shears every distinct vertex once and evaluates every distinct edge once (tools/gen_pass1.py), pass 2 looks its three
 // vertices up in the distinct-vertex table.  Same floats, same candidates, same hits either way.
+// quad_mask (TOPO 0 only): wave-uniform bit per primitive, or nullptr; primitives whose bit is clear are known not to be
+// hit by any ray of the wave (ssx_tile_mask_kernel: the camera rays of a pixel tile) and are left out of pass 1.
 template <int TOPO>
-__device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_quad, bool has_ray, HitInfo& hit, int stat_base = 0) {
+__device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_quad, bool has_ray, HitInfo& hit, int stat_base = 0, const uint32_t* quad_mask = nullptr) {
 	const RaySetup rs = ray_setup(orig, dir);
 	const SsxBlobHeader& hd = L.hdr();
 	const uint32_t nq = hd.n_quads;
@@ -561,7 +563,23 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 #ifdef SSX_JIT_BUILD
 		else if constexpr (TOPO == 3) pass1_jit(L.vtab(rs.perm), rs, acc0, acc1);
 #endif
-		else if (!perm_hbm) {
+		else if (quad_mask) {
+			// only the primitives of the mask: their flags go to their places in the accumulators (acc bit of triangle k of an
+			// accumulator = count - 1 - k, see below); every other triangle counts as "mixed" (no candidate)
+			acc0 = ~0u; acc1 = ~0u;
+			uint32_t qm = (uint32_t)__builtin_amdgcn_readfirstlane((int)quad_mask[base >> 5]);
+			if (ng < 32u) qm &= (1u << ng) - 1u;
+			while (qm) {
+				const uint32_t q = (uint32_t)__builtin_ctz(qm);
+				qm &= qm - 1u;
+				uint32_t two = 0u;
+				quad_flags(perm_hbm ? gperm + (base + q) * SSX_PERM_WORDS_PER_QUAD + rs.perm * 12u : L.perm(base + q, rs.perm), two); // two = tri0 flag << 1 | tri1 flag
+				const uint32_t k = q < 16u ? q : q - 16u, cnt = q < 16u ? n0 : n1;
+				const uint32_t sh = 2u * (cnt - 1u - k); // tri0 of quad k sits at bit 2*(cnt-1-k)+1, tri1 at 2*(cnt-1-k)
+				uint32_t& acc = q < 16u ? acc0 : acc1;
+				acc = (acc & ~(3u << sh)) | ((two & 3u) << sh);
+			}
+		} else if (!perm_hbm) {
 			for (uint32_t q = 0; q < n0; ++q) quad_flags(L.perm(base + q, rs.perm), acc0);
 			for (uint32_t q = 16u; q < ng; ++q) quad_flags(L.perm(base + q, rs.perm), acc1);
 		} else { // (large scenes: the table is read from HBM)
@@ -888,6 +906,20 @@ __device__ __forceinline__ uint32_t log_append(const LogRef& lg, uint32_t which)
 // renderer.cpp:113-138: camera ray (f64, as the reference) and hero wavelength of sample k of
 // pixel (i,j), from its own PCG32 stream (the seeding contract of include/ssx.h).  Runs in
 // ssx_generate_kernel with every lane busy; the record carries the stream on to the path kernel.
+// renderer.cpp:114-131 up to the normalisation: the (unnormalised, binary64) direction from the camera through the image point
+// (x, y) in pixel units
+__device__ __forceinline__ void camera_dir(const SsxBlobHeader& h, const SsxKernelArgs& a, double x, double y, double& dx, double& dy, double& dz) {
+	double st_x = x / (double)a.width;
+	double st_y = y / (double)a.height;
+	double ndc_x = st_x * 2.0 - 1.0, ndc_y = st_y * 2.0 - 1.0;
+	double q[4];
+#pragma unroll
+	for (int r = 0; r < 4; ++r)
+		q[r] = (h.pv_inv[0 * 4 + r] * ndc_x + h.pv_inv[1 * 4 + r] * ndc_y) + (h.pv_inv[2 * 4 + r] * 0.0 + h.pv_inv[3 * 4 + r] * 1.0);
+	double w = q[3];
+	double px = q[0] / w, py = q[1] / w, pz = q[2] / w;
+	dx = px - (double)h.cam_pos[0]; dy = py - (double)h.cam_pos[1]; dz = pz - (double)h.cam_pos[2];
+}
 __device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const SsxKernelArgs& a, uint32_t i, uint32_t j, uint32_t k, float4& ray, uint4& st) {
 	const uint64_t pixel = (uint64_t)j * (uint64_t)a.width + (uint64_t)i;
 	const uint64_t pa = mix64(a.seed + 0x9E3779B97F4A7C15ull * (pixel + 1ull));
@@ -898,16 +930,8 @@ __device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const Ss
 	// :113 -- g++ evaluates dvec2(rand_1d(rng),rand_1d(rng)) right to left: y first
 	double sub_y = rand_1d(rng);
 	double sub_x = rand_1d(rng);
-	double st_x = ((double)i + sub_x) / (double)a.width;
-	double st_y = ((double)j + sub_y) / (double)a.height;
-	double ndc_x = st_x * 2.0 - 1.0, ndc_y = st_y * 2.0 - 1.0;
-	double q[4];
-#pragma unroll
-	for (int r = 0; r < 4; ++r)
-		q[r] = (h.pv_inv[0 * 4 + r] * ndc_x + h.pv_inv[1 * 4 + r] * ndc_y) + (h.pv_inv[2 * 4 + r] * 0.0 + h.pv_inv[3 * 4 + r] * 1.0);
-	double w = q[3];
-	double px = q[0] / w, py = q[1] / w, pz = q[2] / w;
-	double dx = px - (double)h.cam_pos[0], dy = py - (double)h.cam_pos[1], dz = pz - (double)h.cam_pos[2];
+	double dx, dy, dz;
+	camera_dir(h, a, (double)i + sub_x, (double)j + sub_y, dx, dy, dz);
 	double inv = 1.0 / __builtin_sqrt((dx * dx + dy * dy) + dz * dz);
 	// :138 exists #ifdef RENDER_MODE_SPECTRAL only: the RGB build draws no wavelength (its "spectra" are
 	// 4-sample tables {r,g,b,0} on the grid 0,1,2,3 and lambda_0 = 0, lambda_step = 1 pick them out exactly)
@@ -1255,7 +1279,6 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 // ray[] and st[] only, and the path loop traces a camera ray like any other ray (ssx_upload_scene decides: calibrate()).
 // Record order [tile slot][k-k0][pixel in tile]: a wave writes 64 consecutive records.  Persistent workgroups (they stage
 // the scene tables into LDS for trace()) striding over the record waves.
-template <int TOPO>
 __device__ __forceinline__ void generate_body(const SsxKernelArgs& a) {
 	Lds L; L.w = stage_lds(a);
 	const SsxBlobHeader& h = L.hdr();
@@ -1275,8 +1298,9 @@ __device__ __forceinline__ void generate_body(const SsxKernelArgs& a) {
 			if (inside) { a.ray[r] = ray; a.st[r] = st; }
 			continue;
 		}
+		// the closest hit, by the generic trace restricted to the primitives the tile's frustum can contain (ssx_tile_mask_kernel)
 		HitInfo hit;
-		trace<TOPO>(L, cam, mk(ray.x, ray.y, ray.z), -1, inside, hit, 16);
+		trace<0>(L, cam, mk(ray.x, ray.y, ray.z), -1, inside, hit, 16, a.tile_mask + 4u * slot);
 		if (inside) {
 			float st_x = 0.0f, st_y = 0.0f;
 			if (hit.tri >= 0) {
@@ -1291,14 +1315,61 @@ __device__ __forceinline__ void generate_body(const SsxKernelArgs& a) {
 		}
 	}
 }
-#define SSX_GENERATE_KERNEL(name, topo) \
-	extern "C" __global__ void __launch_bounds__(256) name(SsxKernelArgs a) { generate_body<topo>(a); }
-#ifdef SSX_JIT_BUILD
-SSX_GENERATE_KERNEL(ssx_generate_kernel_jit, 3)
-#else
-SSX_GENERATE_KERNEL(ssx_generate_kernel, 0)
-SSX_GENERATE_KERNEL(ssx_generate_kernel_cornell, 1)
-SSX_GENERATE_KERNEL(ssx_generate_kernel_plane, 2)
+#ifndef SSX_JIT_BUILD
+extern "C" __global__ void __launch_bounds__(256) ssx_generate_kernel(SsxKernelArgs a) { generate_body(a); }
+
+// Which primitives can a camera ray through a pixel tile hit at all?  One wave per tile slot of the device, one lane per
+// primitive: the tile's frustum is the cone of the four planes through the camera position and two neighbouring corner rays of
+// the tile's pixel rectangle (every sample's sub-pixel offset lies in [0, 1)^2: all of the tile's rays run inside); a primitive
+// whose vertices ALL lie outside ONE of the planes, by more than 1e-4 of their distance from the camera, cannot be met by a
+// ray inside the cone (the hit point is a convex combination of the vertices and would lie outside by the same angle; the
+// float rounding of a ray's direction moves it by ~1e-7) -- in front of the camera or behind it.  Everything else stays in the
+// mask, so the masked trace of ssx_generate_kernel finds the hit the full one finds; tile_mask[4 slot + g] = primitives 32 g ...
+extern "C" __global__ void __launch_bounds__(256) ssx_tile_mask_kernel(SsxKernelArgs a) {
+	const SsxBlobHeader& h = *reinterpret_cast<const SsxBlobHeader*>(a.blob);
+	const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (slot >= a.my_tiles) return;
+	const uint32_t tile = a.tile_first + slot * a.tile_stride;
+	const double x0 = (double)((tile % a.tiles_x) * 8u), y0 = (double)((tile / a.tiles_x) * 8u);
+	// corner rays counter-clockwise (as seen along the viewing direction it does not matter: the planes are oriented by the centre ray)
+	double d[4][3], c[3];
+	camera_dir(h, a, x0, y0, d[0][0], d[0][1], d[0][2]);
+	camera_dir(h, a, x0 + 8.0, y0, d[1][0], d[1][1], d[1][2]);
+	camera_dir(h, a, x0 + 8.0, y0 + 8.0, d[2][0], d[2][1], d[2][2]);
+	camera_dir(h, a, x0, y0 + 8.0, d[3][0], d[3][1], d[3][2]);
+	camera_dir(h, a, x0 + 4.0, y0 + 4.0, c[0], c[1], c[2]);
+	double n[4][3];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) {
+		const double* p = d[k]; const double* q = d[(k + 1) & 3];
+		double nx = p[1] * q[2] - p[2] * q[1], ny = p[2] * q[0] - p[0] * q[2], nz = p[0] * q[1] - p[1] * q[0];
+		const double inv = 1.0 / __builtin_sqrt(nx * nx + ny * ny + nz * nz);
+		const double sgn = (nx * c[0] + ny * c[1] + nz * c[2]) < 0.0 ? -inv : inv; // inward: the centre ray is inside
+		n[k][0] = nx * sgn; n[k][1] = ny * sgn; n[k][2] = nz * sgn;
+	}
+	const SsxBlobQuad* quads = reinterpret_cast<const SsxBlobQuad*>(a.blob + h.off_quads);
+	for (uint32_t g = 0; g < 2u; ++g) { // primitives g*64 + lane
+		const uint32_t q = g * 64u + lane;
+		bool keep = false;
+		if (q < h.n_quads) {
+			keep = true;
+#pragma unroll
+			for (int k = 0; k < 4; ++k) {
+				bool all_out = true;
+#pragma unroll
+				for (int v = 0; v < 4; ++v) {
+					const double vx = (double)quads[q].pos[v][0] - (double)h.cam_pos[0], vy = (double)quads[q].pos[v][1] - (double)h.cam_pos[1], vz = (double)quads[q].pos[v][2] - (double)h.cam_pos[2];
+					const double dist = __builtin_sqrt(vx * vx + vy * vy + vz * vz);
+					const double sd = n[k][0] * vx + n[k][1] * vy + n[k][2] * vz;
+					all_out = all_out && (sd < -1.0e-4 * dist); // (NaN compares false: the primitive stays)
+				}
+				if (all_out) keep = false;
+			}
+		}
+		const uint64_t m = __ballot(keep);
+		if (lane == 0u) { a.tile_mask[4u * slot + 2u * g] = (uint32_t)m; a.tile_mask[4u * slot + 2u * g + 1u] = (uint32_t)(m >> 32); }
+	}
+}
 #endif
 
 // Stage 2 of 3: the path megakernel.  Work unit of one wave64 = one 8x8 tile (Framebuffer::Tile,
