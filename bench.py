@@ -39,8 +39,8 @@ FLOP_PER_SAMPLE = {"cornell-srgb": 1.28e4, "cornell": 1.28e4, "plane-srgb": 2.8e
 #   path      : read the three 48; per continued level append fs 16 + np 8 + chain word 4; emission term 16 E;
 #               at the end write {lambda, tail word, final stream state} 16
 #   shadow    : R x write nee 16 (write-only: contribution or zeros)
-#   fold      : read tail 16 + (fs 16 + np 8 + chain word 4) L + nee 16 R + emission 16 E; write XYZA 16
-#   accumulate: read XYZA 16
+#   fold      : read tail 16 + (fs 16 + np 8 + chain word 4) L + nee 16 R + emission 16 E; the pixel sums (4 x binary64 per pixel)
+#               are read and written once per work unit of U samples per pixel: 64 / U
 LEVELS = {"cornell-srgb": 4.07, "cornell": 4.07, "plane-srgb": 1.0}
 SHADOW = {"cornell-srgb": 3.08, "cornell": 3.08, "plane-srgb": 1.36}
 # gfx950 FP32 vector peak is 157.3 TFLOP/s counting FMA as 2; the parity contract forbids
@@ -53,8 +53,9 @@ def algorithmic_bytes_per_sample(scene, path_kernel_only=False, levels=None):
     L = levels if levels else LEVELS.get(scene, 4.07)
     R = SHADOW.get(scene, 3.08)
     E = 0.01
-    path = (48 + 28 * L + 16 * E + 16) + 16 * R + (16 + 28 * L + 16 * R + 16 * E + 16)   # path loop + shadow flush + fold
-    return path if path_kernel_only else 48 + path + 16
+    U = 4.0 if L >= 2.0 else 8.0                                                          # samples per pixel of a work unit (make_batch)
+    path = (48 + 28 * L + 16 * E + 16) + 16 * R + (16 + 28 * L + 16 * R + 16 * E + 64.0 / U)   # path loop + shadow flush + fold
+    return path if path_kernel_only else 48 + path
 
 
 def host_cpu_info():

@@ -219,6 +219,9 @@ void orc_render_sample(const orc_color*, const orc_scene*, orc_rng*, size_t i, s
  * pixel rectangle [i0,i1)x[j0,j1); out is float4 XYZA per pixel, row 0 = bottom, full W*H
  * indexing (j*W+i).  sample range [k0,k1) of spp_total (the mean divides by spp_total).
  * nthreads<=0: hardware concurrency; 8x8 tile queue like renderer.cpp:340-379,396-409. */
+/* the reference's own one-thread ordering: thread 0's stream through the whole image in render_start's tile order (oracle_render.c) */
+int orc_render_reference_native(const orc_color*, const orc_scene*, size_t W, size_t H, size_t spp, int indirect_only,
+                                float* out_xyza, orc_rng* rng_out);
 int orc_render(const orc_color*, const orc_scene*, uint64_t seed, size_t W, size_t H,
                size_t i0, size_t j0, size_t i1, size_t j1, size_t spp, int indirect_only,
                int nthreads, float* out_xyza, orc_stats* stats_or_null);

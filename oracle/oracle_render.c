@@ -181,6 +181,46 @@ static void render_pixel(const orc_color* cd, const orc_scene* sc, uint64_t seed
 }
 
 typedef struct { size_t x, y, w, h; } tile_t;
+
+/* The reference AS SHIPPED, in its one deterministic configuration (the one-thread toggle of renderer.cpp:41-46): thread 0's
+ * stream -- seeded with u32(get_hashed(0u)), or 1 (renderer.cpp:335-337) -- consumed sequentially over the whole image, tiles in
+ * the order of render_start's list (renderer.cpp:396-409: row-major 8x8 tiles, reversed, popped from the back: the bottom-left
+ * tile first), pixels of a tile row by row (:374-378), a pixel's samples one after the other from the SAME stream (:292-295).
+ * No GPU can mirror one stream running through every pixel; this mode exists so that the restatement also covers the
+ * reference's own T1/T2/T3 ordering ("reference-native mode"), for the day a reference binary can be run
+ * beside it.  Returns the stream's final state in *rng_out (may be NULL). */
+int orc_render_reference_native(const orc_color* cd, const orc_scene* sc, size_t W, size_t H, size_t spp, int indirect_only,
+                                float* out_xyza, orc_rng* rng_out) {
+	orc_rng rng;
+	uint64_t seed = orc_get_hashed_u32(0u); /* thread_index = _num_rendering++ of the only worker */
+	if (seed == 0) ++seed;
+	orc_rng_seed_u32(&rng, (uint32_t)seed);
+	size_t n_tiles = 0, cap = ((W + ORC_TILE_SIZE - 1) / ORC_TILE_SIZE) * ((H + ORC_TILE_SIZE - 1) / ORC_TILE_SIZE);
+	tile_t* tiles = (tile_t*)malloc(sizeof(tile_t) * (cap ? cap : 1));
+	for (size_t j = 0; j < H; j += ORC_TILE_SIZE) for (size_t i = 0; i < W; i += ORC_TILE_SIZE) {
+		tile_t t = { i, j, (W - i < ORC_TILE_SIZE) ? W - i : ORC_TILE_SIZE, (H - j < ORC_TILE_SIZE) ? H - j : ORC_TILE_SIZE };
+		tiles[n_tiles++] = t;
+	}
+	for (size_t a = 0, b = n_tiles; a + 1 < b; ++a, --b) { tile_t t = tiles[a]; tiles[a] = tiles[b - 1]; tiles[b - 1] = t; } /* std::reverse */
+	while (n_tiles) {
+		const tile_t t = tiles[--n_tiles]; /* _tiles.back(); pop_back() (:361-362) */
+		for (size_t j = t.y; j < t.y + t.h; ++j) for (size_t i = t.x; i < t.x + t.w; ++i) {
+			double avg[4] = { 0, 0, 0, 0 };
+			for (size_t k = 0; k < spp; ++k) {
+				float s[4];
+				orc_render_sample(cd, sc, &rng, i, j, W, H, indirect_only, s, NULL);
+				if (cd->rgb_mode) for (int c = 0; c < 4; ++c) avg[c] += (double)s[c];
+				else for (int c = 0; c < 4; ++c) avg[c] += (double)(s[c] * 0.001f);
+			}
+			float* out = out_xyza + 4 * (j * W + i);
+			if (cd->rgb_mode) for (int c = 0; c < 4; ++c) out[c] = (float)(avg[c] / (double)spp);
+			else { const double sc_ = 1000.0 / (double)spp; for (int c = 0; c < 4; ++c) out[c] = (float)(avg[c] * sc_); }
+		}
+	}
+	free(tiles);
+	if (rng_out) *rng_out = rng;
+	return 0;
+}
 typedef struct {
 	const orc_color* cd; const orc_scene* sc; uint64_t seed; size_t W, H, spp; int indirect_only;
 	float* out; tile_t* tiles; size_t n_tiles; pthread_mutex_t mutex; int want_stats;

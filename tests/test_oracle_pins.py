@@ -178,3 +178,44 @@ def test_libm_sensitivity_statistic_matches_survey():
     assert 0.26 < nd / n < 0.36          # survey: 0.308
     assert 0.035 < n5 / n < 0.07         # survey: 0.053
     assert 0.001 < n4 / n < 0.009        # survey: 0.0044
+
+
+def test_reference_native_mode_follows_the_references_own_ordering():
+    """SURVEY 8(c) "reference-native mode": the restatement also runs the way the shipped reference does in its one
+    deterministic configuration (one worker, renderer.cpp:41-46): thread 0's FNV-seeded stream (:335-337) through the whole
+    image, tiles in render_start's order (:396-409: reversed row-major list popped from the back = bottom-left tile first),
+    pixels row by row (:374-378), samples back to back (:292-295).  Checked against an independent walk in that order written
+    here, on a ragged image; the stream starts with the survey's known answers for thread 0."""
+    import ctypes as C
+    lib = ol.load()
+    o = ol.Oracle("cornell-srgb", texture="test-img.png")
+    W, H, spp = 19, 13, 2
+    lib.orc_render_reference_native.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(ol.Rng)]
+    out = np.zeros((H, W, 4), dtype=np.float32); end = ol.Rng()
+    assert lib.orc_render_reference_native(o.color, o.scene, W, H, spp, 0, out.ctypes.data, C.byref(end)) == 0
+    out2 = np.zeros_like(out)
+    lib.orc_render_reference_native(o.color, o.scene, W, H, spp, 0, out2.ctypes.data, None)
+    assert np.array_equal(out.view(np.uint32), out2.view(np.uint32))             # deterministic, as the one-thread reference is
+    # the walk, written out again: tiles row-major, reversed, popped from the back
+    rng = ol.Rng()
+    lib.orc_rng_seed_u32.argtypes = [C.POINTER(ol.Rng), C.c_uint32]
+    lib.orc_get_hashed_u32.restype = C.c_uint64
+    lib.orc_rng_seed_u32(C.byref(rng), lib.orc_get_hashed_u32(0) & 0xFFFFFFFF)
+    assert rng.state == rng.inc == 0x9DCE13F59DCE13F5                            # SURVEY 8(a) T2
+    tiles = [(i, j) for j in range(0, H, 8) for i in range(0, W, 8)][::-1]
+    want = np.zeros((H, W, 4), dtype=np.float32)
+    s = (C.c_float * 4)()
+    first = True
+    while tiles:
+        ti, tj = tiles.pop()
+        if first:
+            assert (ti, tj) == (0, 0); first = False
+        for j in range(tj, min(tj + 8, H)):
+            for i in range(ti, min(ti + 8, W)):
+                acc = np.zeros(4, dtype=np.float64)
+                for k in range(spp):
+                    lib.orc_render_sample(o.color, o.scene, C.byref(rng), i, j, W, H, 0, s, None)
+                    acc += (np.array(s[:], dtype=np.float32) * np.float32(0.001)).astype(np.float64)
+                want[j, i] = (acc * (1000.0 / spp)).astype(np.float32)
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32)) and end.state == rng.state
+    assert not np.array_equal(out, o.render(W, H, spp))                          # (not the per-sample seeding contract of the GPU path)
