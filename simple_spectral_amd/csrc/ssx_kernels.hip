@@ -1170,9 +1170,9 @@ __device__ __forceinline__ float4 nee_term(const SsxKernelArgs& a, uint32_t i, b
 	return make_float4(v ? c.x : 0.0f, v ? c.y : 0.0f, v ? c.z : 0.0f, v ? c.w : 0.0f);
 }
 // fs_base / nee_base: index of slot 0 of the cohort's logs (log_rec * 9, log_rec * 10); rc0: the lane's pixel of the tile
-// (its first sample within the cohort; way s is sample rc0 + 64 s)
+// (its first sample within the cohort; way s is sample rc0 + 64 s); acc: the lane's pixel sums (unit_fold)
 template <uint32_t WAYS, bool NARROW>
-__device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count, uint32_t fs_base, uint32_t nee_base, uint32_t rc0, double* px, double* acc_regs = nullptr) {
+__device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count, uint32_t fs_base, uint32_t nee_base, uint32_t rc0, double acc[4]) {
 	float rad[WAYS][4];
 	uint32_t depth[WAYS]; // hit_anything << 4 | number of continued levels
 	uint32_t K[WAYS]; // chain word of the level about to be folded: its entry's `link` (parent slot | nee slot << 13 | emission << 26)
@@ -1229,12 +1229,6 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 				rad[s][3] = D[s].w + ssx_exact::div64_by((rad[s][3] * NP[s].x) * F[s].w, pdf_recip);
 			}
 	}
-	// the pixel's running sums (unit_fold): loaded here, behind the chain walk, whose registers they would otherwise take
-#ifdef SSX_ACC_REGS
-	double* const acc = acc_regs; (void)px;
-#else
-	double acc[4] = { ld_agent(px), ld_agent(px + 64), ld_agent(px + 128), ld_agent(px + 192) };
-#endif
 #pragma unroll
 	for (uint32_t s = 0; s < WAYS; ++s)
 		if (s < count) {
@@ -1257,9 +1251,6 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 			else { acc[0] += (double)(xyz[0] * 0.001f); acc[1] += (double)(xyz[1] * 0.001f); acc[2] += (double)(xyz[2] * 0.001f); acc[3] += (double)(alpha * 0.001f); }
 			if (a.keep_samples) a.ray[r0 + s * stride] = make_float4(xyz[0], xyz[1], xyz[2], alpha); // ssx_debug_samples: what _render_sample returns
 		}
-#ifndef SSX_ACC_REGS
-	st_agent(px, acc[0]); st_agent(px + 64, acc[1]); st_agent(px + 128, acc[2]); st_agent(px + 192, acc[3]);
-#endif
 }
 
 } // namespace
@@ -1433,18 +1424,13 @@ __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, 
 	}
 	if ((lane & 7u) < u.tw() && (lane >> 3) < u.th()) {
 		double* const px = a.accum + (size_t)u.tile * 256u + lane; // [tile][component][pixel of the tile]: components 64 doubles apart
-#ifdef SSX_ACC_REGS
+		// the pixel's running sums: in registers across the unit's passes (one load and one store per unit; per pass, 0.6 % slower)
 		double acc[4] = { ld_agent(px), ld_agent(px + 64), ld_agent(px + 128), ld_agent(px + 192) };
-#else
-		double* const acc = nullptr;
-#endif
 		for (uint32_t kq = 0, n_kq = u.n_kq(), rec_base = u.rec_base(a); kq < n_kq; kq += SSX_RESOLVE_WAYS) { // one cohort per pass
 			const uint32_t log_rec = log_region(a, wave_slot, tag, kq / SSX_COHORT_KS);
-			resolve_records<SSX_RESOLVE_WAYS, NARROW>(L, a, rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, n_kq - kq), log_rec * SSX_MAX_FRAMES, log_rec * SSX_MAX_LEVELS, lane, px, acc);
+			resolve_records<SSX_RESOLVE_WAYS, NARROW>(L, a, rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, n_kq - kq), log_rec * SSX_MAX_FRAMES, log_rec * SSX_MAX_LEVELS, lane, acc);
 		}
-#ifdef SSX_ACC_REGS
 		st_agent(px, acc[0]); st_agent(px + 64, acc[1]); st_agent(px + 128, acc[2]); st_agent(px + 192, acc[3]);
-#endif
 	}
 #ifdef SSX_ACCUM_FORMAL
 	if (lane == 0u) __hip_atomic_store(a.tile_done + u.slot, u.k_off + u.n_kq(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1603,9 +1589,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		}
 		rotate_fetch(); // (3)
 		if (!a.pre_hits) refill(false); // the new samples' camera rays ride in the trace (4): their loads are in flight during (2)
-#ifndef SSX_LOOP_FLUSH_LAST
 		flush_fold(); // (2)
-#endif
 		// (4)
 		if (__any(active)) {
 			HitInfo hit;
@@ -1624,9 +1608,6 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			p.hit_st_x = st_x; p.hit_st_y = st_y;
 		}
 		if (a.pre_hits) refill(true); // (5)
-#ifdef SSX_LOOP_FLUSH_LAST
-		flush_fold(); // (2) moved behind (5): the loads of the new samples are in flight during the flush; four more values live across it
-#endif
 		// nothing runs, nothing is left to hand out, nothing waits for its flush or fold
 		if (!__any(active) && !cur_valid && !more && !old_pending && sq.count == 0u) break;
 	}
