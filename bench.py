@@ -324,7 +324,7 @@ def main():
                          "traffic": traffic,
                          "traffic_source": "replayed from profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, corrected by factors calibrated on known byte counts in the same access patterns; NOT measured in this run" if traffic else None,
                          "traffic_detail": traffic_detail,
-                         "kernel": "%s + %s" % ((plan.get("kernel") or "ssx_render_kernel").replace("render", "generate").replace("_nq", ""), plan.get("kernel") or "ssx_render_kernel"),
+                         "kernel": "ssx_generate_kernel + %s" % (plan.get("kernel") or "ssx_render_kernel"),
                          "kernel_ms": round(kernel_ms, 3), "path_kernel_ms": round(path_ms, 3),
                          "pipeline_ms": round(pipeline_ms, 3), "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
                          "flop_per_sample": flop,

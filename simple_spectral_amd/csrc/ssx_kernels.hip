@@ -1,13 +1,15 @@
 // ssx_kernels.hip -- the per-pixel spectral integrator as a gfx950 megakernel.
 //
 // Path covered (reference file:line, paths relative to the reference's src/):
-//   renderer.cpp:309-395  tile loop            -> persistent waves fetching work units (8x8 tile x 8
+//   renderer.cpp:309-395  tile loop            -> persistent waves fetching work units (8x8 tile x 4 or 8
 //                                                 samples per pixel); lanes take (pixel, k) items
 //   renderer.cpp:278-299  _render_pixel        -> the f64 XYZA pixel sums, continued in ascending k by the fold of every work unit (unit_fold)
-//   renderer.cpp:104-277  _render_sample / L   -> ssx_generate_kernel (camera ray, lambda_0), then the
-//                                                 iterative path loop of ssx_render_kernel with the
-//                                                 shadow rays parked and traced 64 at a time, and the
-//                                                 post-order fold + XYZ when a unit is complete
+//   renderer.cpp:104-277  _render_sample / L   -> ssx_generate_kernel (camera ray, lambda_0 and -- where rays leave the scene
+//                                                 often enough -- the camera ray's closest hit, restricted to the pixel
+//                                                 tile's frustum: ssx_tile_mask_kernel), then the iterative path loop of
+//                                                 ssx_render_kernel: shade the hit a lane holds, trace the continuation
+//                                                 rays, shadow rays parked and traced 64 at a time, post-order fold + XYZ
+//                                                 + pixel sums when a unit is complete
 //   scene.cpp:433-445, geometry.cpp:12-139     -> trace(): quad-batched watertight test
 //   scene.cpp:417-431, geometry.cpp:103-145, util/spherical-tri.cpp, util/random.cpp:101-154
 //                                              -> sample_light()
