@@ -758,6 +758,7 @@ __device__ __forceinline__ V3 func_bar(V3 x, V3 y) { // util/random.cpp:139-144
 	float lensq = dot3(dir, dir);
 	if (lensq == 0.0f) return mk(0, 0, 0);
 	float is = inversesqrt_(lensq);
+	if (lensq < 0x1p-100f) is = 1.0f / __builtin_sqrtf(lensq); // below ssx_exact::sqrt_normal's proven domain (two unit vectors that differ in their smallest components only): plain IEEE
 	return mk(dir.x * is, dir.y * is, dir.z * is);
 }
 

@@ -109,3 +109,14 @@ def many_prims_scene(n_prims, observer=1931, seed=9):
             c.add_quad(p00, p10, p11, p01, m)
     c.set_camera((3.6, 0.2, -3.6), (0.0, 0.0, 0.0), up=(0, 1, 0), vfov_deg=70.0)
     return c
+
+
+def origin_light_scene():
+    """A light with a vertex exactly at the origin: shading points a denormal-ish distance from it give squared lengths below
+    2^-100, outside the proven domain of the kernel's fast exact sqrt (csrc/ssx_exact.h) -- the kernel must take the plain IEEE
+    path there (normalize3_any, func_bar) and still equal the reference's glm::normalize."""
+    c = cs.CustomScene("cornell", keep_quads=False)
+    _room(c)
+    c.add_quad((0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 0, 1), LIGHT)
+    c.set_camera((2.0, 2.0, -3.0), (0.5, 0.0, 0.5), up=(0, 1, 0), vfov_deg=40.0)
+    return c

@@ -12,6 +12,7 @@ import crafted
 import custom_scene as cs
 import oracle_lib as ol
 import unit_cases as uc
+from unit_cases import unit
 from simple_spectral_amd import Options, Renderer, _capi
 
 pytestmark = pytest.mark.gpu
@@ -307,3 +308,22 @@ def test_scene_limits_are_errors_not_surprises():
     with pytest.raises(Exception) as e:
         r.upload_scene_desc(c.desc(c.oracle()))
     assert "2^30" in str(e.value)
+
+
+def test_light_sampling_a_hair_from_a_light_vertex_at_the_origin():
+    """ADVICE r02: ssx_exact::sqrt_normal is exact for x >= 2^-100 only; squared distances below that (possible only next to the
+    origin) must take the plain IEEE sequence.  Shading points 1e-16 ... 1e-30 from a light vertex at (0, 0, 0): direction, pdf
+    and stream equal the oracle's, bit for bit (NaN where the reference produces NaN)."""
+    c = crafted.origin_light_scene()
+    r, orc = custom_pair(c)
+    g = np.random.default_rng(21)
+    mags = 10.0 ** g.uniform(-30, -14, size=(3000, 1))
+    pts = (unit(g.normal(size=(3000, 3))) * mags).astype(np.float32)
+    pts[:50, 1] = 0.0                                        # in the light's plane
+    pts[50:100] = np.abs(pts[50:100])                        # inside the light's corner
+    assert (np.sum(pts.astype(np.float64) ** 2, axis=1) < 2.0 ** -100).sum() > 1500
+    w = uc.sample_light_inputs(pts)
+    ref = uc.oracle_sample_light(orc, w)
+    got = r.debug_eval(_capi.SSX_DBG_SAMPLE_LIGHT, w, 7)
+    ok = same_bits_or_both_nan(got, ref, (0, 1, 2, 4))
+    assert ok.all(), (np.argwhere(~ok)[:5], pts[np.argwhere(~ok)[0][0]])
