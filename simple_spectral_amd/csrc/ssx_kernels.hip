@@ -912,8 +912,12 @@ __device__ __forceinline__ uint32_t log_append(const LogRef& lg, uint32_t which)
 // renderer.cpp:114-131 up to the normalisation: the (unnormalised, binary64) direction from the camera through the image point
 // (x, y) in pixel units
 __device__ __forceinline__ void camera_dir(const SsxBlobHeader& h, const SsxKernelArgs& a, double x, double y, double& dx, double& dy, double& dz) {
-	double st_x = x / (double)a.width;
-	double st_y = y / (double)a.height;
+	// (i + subpixel) / res: for a power-of-two image size the division is exact, and so is the multiplication by the exact
+	// reciprocal -- the same binary64 in 2 instead of ~28 instructions (every BASELINE configuration; wave-uniform test)
+	const bool pow2 = ((a.width & (a.width - 1u)) | (a.height & (a.height - 1u))) == 0u;
+	double st_x, st_y;
+	if (pow2) { st_x = x * (1.0 / (double)a.width); st_y = y * (1.0 / (double)a.height); }
+	else { st_x = x / (double)a.width; st_y = y / (double)a.height; }
 	double ndc_x = st_x * 2.0 - 1.0, ndc_y = st_y * 2.0 - 1.0;
 	double q[4];
 #pragma unroll
