@@ -210,6 +210,10 @@ int ssx_read_framebuffer(ssx_ctx* ctx, float* xyza_out); /* device framebuffer -
  * is nonzero on exactly one device (tile_first/tile_stride), so the sum is exact.  Synchronous. */
 int ssx_accumulate_peer(ssx_ctx* ctx, void* d_dst, int src_device, const void* d_src, uint32_t width, uint32_t height, void* hip_stream);
 
+/* The same combine as one RCCL reduce (sum, float) of the n contexts' device framebuffers into ctxs[0]'s: one rank per
+ * context of this process (ncclCommInitAll), the contexts on n different devices.  RCCL is loaded on first use. */
+int ssx_reduce_rccl(ssx_ctx** ctxs, int n, uint32_t width, uint32_t height);
+
 /* Last error text for ctx (or for ssx_create when ctx is NULL). */
 const char* ssx_last_error(const ssx_ctx* ctx);
 

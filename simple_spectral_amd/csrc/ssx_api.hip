@@ -1024,6 +1024,53 @@ int ssx_accumulate_peer(ssx_ctx* ctx, void* d_dst, int src_device, const void* d
 	return SSX_OK;
 }
 
+// The C++ host's combine over RCCL (north_star: "a final RCCL reduce over xGMI of the per-GPU framebuffer"): one communicator
+// per context of this process (ncclCommInitAll), one grouped ncclReduce(sum, float) of the device framebuffers into
+// ctxs[0]'s.  RCCL is opened with dlopen: a process that combines by peer copies (ssx_accumulate_peer) never loads it.
+// Every pixel is nonzero on exactly one device, so the sum is exact whatever the reduction tree.
+int ssx_reduce_rccl(ssx_ctx** ctxs, int n, uint32_t width, uint32_t height) {
+	if (!ctxs || n <= 0 || !ctxs[0] || width == 0 || height == 0) return SSX_ERR_ARG;
+	ssx_ctx* root = ctxs[0];
+	typedef void* comm_t;
+	static void* lib = nullptr;
+	static int (*init_all)(comm_t*, int, const int*) = nullptr;
+	static int (*group_start)() = nullptr;
+	static int (*group_end)() = nullptr;
+	static int (*reduce)(const void*, void*, size_t, int, int, int, comm_t, hipStream_t) = nullptr;
+	static int (*comm_destroy)(comm_t) = nullptr;
+	static const char* (*error_string)(int) = nullptr;
+	if (!lib) {
+		for (const char* name : { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" }) if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+		if (!lib) return fail(root, SSX_ERR_DEVICE, std::string("RCCL is not available (") + dlerror() + ")");
+		init_all = (decltype(init_all))dlsym(lib, "ncclCommInitAll"); group_start = (decltype(group_start))dlsym(lib, "ncclGroupStart");
+		group_end = (decltype(group_end))dlsym(lib, "ncclGroupEnd"); reduce = (decltype(reduce))dlsym(lib, "ncclReduce");
+		comm_destroy = (decltype(comm_destroy))dlsym(lib, "ncclCommDestroy"); error_string = (decltype(error_string))dlsym(lib, "ncclGetErrorString");
+		if (!init_all || !group_start || !group_end || !reduce || !comm_destroy || !error_string) { lib = nullptr; return fail(root, SSX_ERR_DEVICE, "RCCL lacks an entry point"); }
+	}
+	std::vector<int> devs(n);
+	for (int i = 0; i < n; ++i) {
+		if (!ctxs[i] || !ctxs[i]->d_out) return fail(root, SSX_ERR_STATE, "ssx_reduce_rccl: a context has no rendered framebuffer");
+		devs[i] = ctxs[i]->device;
+		for (int k = 0; k < i; ++k) if (devs[k] == devs[i]) return fail(root, SSX_ERR_ARG, "ssx_reduce_rccl: two contexts on one device (RCCL wants one rank per device; use ssx_accumulate_peer)");
+	}
+	std::vector<comm_t> comms(n, nullptr);
+	int rc = init_all(comms.data(), n, devs.data());
+	if (rc) return fail(root, SSX_ERR_DEVICE, std::string("ncclCommInitAll: ") + error_string(rc));
+	const size_t count = (size_t)width * height * 4u;
+	rc = group_start();
+	for (int i = 0; i < n && !rc; ++i) {
+		if (hipSetDevice(devs[i]) != hipSuccess) { rc = -1; break; }
+		rc = reduce(ctxs[i]->d_out, ctxs[i]->d_out, count, 7 /* ncclFloat */, 0 /* ncclSum */, 0, comms[i], ctxs[i]->stream);
+	}
+	const int rc_end = group_end();
+	if (!rc) rc = rc_end;
+	for (int i = 0; i < n; ++i) { (void)hipSetDevice(devs[i]); (void)hipStreamSynchronize(ctxs[i]->stream); }
+	for (comm_t c : comms) if (c) (void)comm_destroy(c);
+	(void)hipSetDevice(root->device);
+	if (rc) return fail(root, SSX_ERR_DEVICE, std::string("ncclReduce: ") + (rc > 0 ? error_string(rc) : "hipSetDevice failed"));
+	return SSX_OK;
+}
+
 // ---- diagnostics for the parity tests (never called during a normal render) ----------------------
 
 int ssx_debug_eval(ssx_ctx* ctx, uint32_t op, const void* in, uint32_t in_words, void* out, uint32_t out_words, uint32_t n) {

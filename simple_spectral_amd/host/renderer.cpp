@@ -39,6 +39,7 @@ struct Renderer::Api {
 	int (*read_framebuffer)(ssx_ctx*, float*) = nullptr;
 	int (*accumulate_peer)(ssx_ctx*, void*, int, const void*, uint32_t, uint32_t, void*) = nullptr;
 	uint32_t (*done_spp)(ssx_ctx*) = nullptr;
+	int (*reduce_rccl)(ssx_ctx**, int, uint32_t, uint32_t) = nullptr;
 
 	explicit Api(const std::string& path) {
 		handle = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
@@ -62,6 +63,7 @@ struct Renderer::Api {
 		read_framebuffer = reinterpret_cast<decltype(read_framebuffer)>(sym("ssx_read_framebuffer"));
 		accumulate_peer = reinterpret_cast<decltype(accumulate_peer)>(sym("ssx_accumulate_peer"));
 		done_spp = reinterpret_cast<decltype(done_spp)>(sym("ssx_done_spp"));
+		reduce_rccl = reinterpret_cast<decltype(reduce_rccl)>(sym("ssx_reduce_rccl"));
 	}
 	~Api() { if (handle) dlclose(handle); }
 };
@@ -215,6 +217,10 @@ void Renderer::render_wait() {
 			std::fprintf(stderr, "Render stopped: device %d accumulated %u of %zu samples per pixel; its tiles hold the mean over those.\n", api_->device_index(ctxs_[d]), done, static_cast<size_t>(options.spp));
 	}
 	ssx_ctx* root = ctxs_[0];
+	if (options.reduce_rccl) { // one RCCL reduce over all devices (a single context: RCCL with one rank)
+		int rc = api_->reduce_rccl(ctxs_.data(), static_cast<int>(ctxs_.size()), static_cast<uint32_t>(options.res[0]), static_cast<uint32_t>(options.res[1]));
+		if (rc) throw HostError{ rc, std::string("ssx_reduce_rccl: ") + api_->last_error(root) };
+	} else
 	for (size_t d = 1; d < ctxs_.size(); ++d) {
 		int rc = api_->accumulate_peer(root, api_->device_framebuffer(root), api_->device_index(ctxs_[d]), api_->device_framebuffer(ctxs_[d]),
 		                               static_cast<uint32_t>(options.res[0]), static_cast<uint32_t>(options.res[1]), nullptr);

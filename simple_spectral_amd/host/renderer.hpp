@@ -44,6 +44,7 @@ public:
 		std::string texture_path;    // default: data/scenes/crystal-lizard-4096.png, else the 512 version
 		float light_scale = 30.0f;   // lightsc (src/scene.cpp:291-293)
 		bool explicit_light_sampling = true; // EXPLICIT_LIGHT_SAMPLING (src/stdafx.hpp:44)
+		bool reduce_rccl = false;            // --reduce=rccl: combine the devices' framebuffers with one RCCL reduce instead of peer copies + adds
 		bool flat_field_correction = true;   // FLAT_FIELD_CORRECTION (src/stdafx.hpp:55); false: flux = radiance * dot(ray dir, camera.dir) (src/renderer.cpp:264-265)
 		bool rgb_mode = false;       // RENDER_MODE_RGB (src/stdafx.hpp:91-93) instead of spectral rendering; `uplift` is then unused
 		int uplift = 1;              // RENDER_MODE_SPECTRAL_ALGNUM: 1 = basis (ours), 2 = Meng et al. 2015, 3 = Jakob-Hanika 2019

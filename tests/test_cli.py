@@ -131,3 +131,23 @@ def test_cli_procedural_texture(cli, tmp_path):
     assert r.returncode == 0, r.stderr
     o = ol.Oracle("plane-srgb", texture=textures.procedural_texture(1024, 3))
     assert np.array_equal(np.asarray(Image.open(out)), _png_of(o.to_srgba(o.render(48, 48, 3))))
+
+
+@pytest.mark.gpu
+def test_cli_combine_through_rccl(cli, tmp_path):
+    """`--reduce=rccl`: the C++ host's combine of the per-device framebuffers as ONE RCCL reduce (ssx_reduce_rccl: ncclCommInitAll
+    over the contexts' devices, grouped ncclReduce(sum) into device 0's buffer) instead of peer copies + adds.  On this one-GPU
+    box the communicator has one rank; the file equals the default path's byte for byte.  Several contexts on ONE device (the
+    test mode of the multi-device path) are refused: RCCL wants one rank per device."""
+    a, b = str(tmp_path / "a.pfm"), str(tmp_path / "b.pfm")
+    common = ["-s=cornell-srgb", "-w=48", "-h=32", "-spp=5", "--texture=data/scenes/test-img.png", "--seed=4"]
+    r = run(cli, *common, "-o=" + a)
+    assert r.returncode == 0, r.stderr
+    r = run(cli, *common, "-o=" + b, "--reduce=rccl")
+    assert r.returncode == 0, r.stderr
+    assert open(a, "rb").read() == open(b, "rb").read()
+    env = dict(os.environ, SSX_TEST_ONE_GPU="1")
+    r = subprocess.run([cli] + common + ["-o=" + b, "--reduce=rccl", "--gpus=2"], cwd=ROOT, capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "one rank per device" in (r.stderr + r.stdout)
+    r = run(cli, *common, "-o=" + b, "--reduce=tree")
+    assert r.returncode == 255
