@@ -367,8 +367,8 @@ int ensure_buffers(ssx_ctx* ctx, uint32_t width, uint32_t height, bool need_out)
 	return SSX_OK;
 }
 
-// Every launch keeps 48 bytes per sample ([tile slot][k][64]: camera ray / XYZA result, stream / tail, camera hit) until the
-// ordered accumulate pass has consumed them; the buffer bounds how many samples per pixel one launch may cover.  The
+// Every launch keeps 48 bytes per sample ([tile slot][k][64]: camera ray, stream / tail word, camera hit) from the generate
+// kernel until the path kernel has folded the sample; the buffer bounds how many samples per pixel one launch may cover.  The
 // levels of the recursion live in the persistent waves' logs (ensure_logs), whose size does not depend on the launch.
 constexpr size_t kSampleBufferBudget = (size_t)16 << 30; // bytes of per-sample arrays one launch may use (512^2 x 256 spp = 3.2 GB; 16 GiB = 358 M samples ~ 110 ms of rendering)
 constexpr size_t kBytesPerSampleInFlight = SSX_BYTES_PER_SAMPLE;
@@ -1039,6 +1039,8 @@ int ssx_reduce_rccl(ssx_ctx** ctxs, int n, uint32_t width, uint32_t height) {
 	static int (*reduce)(const void*, void*, size_t, int, int, int, comm_t, hipStream_t) = nullptr;
 	static int (*comm_destroy)(comm_t) = nullptr;
 	static const char* (*error_string)(int) = nullptr;
+	static std::mutex load_mutex;
+	std::lock_guard<std::mutex> load_guard(load_mutex); // one combine at a time per process (loading the library, and the communicators below)
 	if (!lib) {
 		for (const char* name : { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" }) if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
 		if (!lib) return fail(root, SSX_ERR_DEVICE, std::string("RCCL is not available (") + dlerror() + ")");
