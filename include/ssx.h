@@ -39,7 +39,7 @@ enum {
 #define SSX_MAX_DEPTH 10u          /* MAX_DEPTH */
 #define SSX_TILE_SIZE 8u           /* TILE_SIZE */
 #define SSX_SAMPLE_WAVELENGTHS 4u  /* SAMPLE_WAVELENGTHS */
-#define SSX_MAX_TEXTURES 4u        /* texture descriptors staged per workgroup */
+#define SSX_MAX_TEXTURES 64u       /* texture descriptors (16 bytes each) staged per workgroup; the texels stay in HBM */
 #define SSX_MAX_QUADS 128u         /* Scene::primitives: the per-quad records are staged in LDS (160 bytes each; with more than
                                       32 primitives the intersection works through them in groups of 32 and, where the
                                       48 KB of scene tables would overflow, keeps its permuted vertex table in HBM) */

@@ -111,6 +111,24 @@ def many_prims_scene(n_prims, observer=1931, seed=9):
     return c
 
 
+def many_textures_scene(n_textures=9, seed=4):
+    """The Cornell box with every wall, the floor and the faces of the short block on textures of their own (different sizes,
+    incl. 1 x 1 and non-square): more textures than the reference's scenes use (src/scene.cpp: one); MaterialLambertian holds
+    any texture per material (src/material.cpp:10-29)."""
+    g = np.random.default_rng(seed)
+    c = cs.CustomScene("cornell-srgb")
+    sizes = [(1, 1), (2, 3), (7, 5), (16, 16), (33, 9), (64, 48), (5, 128), (31, 31), (256, 2), (12, 12), (3, 3), (8, 1)]
+    targets = [0, 6, 7, 9, 10, 11, 12, 13, 2, 3, 4, 5]
+    for k in range(n_textures - len(c.textures)):
+        h, w = sizes[k % len(sizes)]
+        c.textures.append(g.integers(0, 256, size=(h, w, 3), dtype=np.uint8))
+        if k < len(targets): # (textures beyond the quads at hand are uploaded and unused)
+            m = c.add_material(albedo_texture=len(c.textures) - 1)
+            pos, st, _ = c.quads[targets[k]]
+            c.quads[targets[k]] = (pos, st, m)
+    return c
+
+
 def origin_light_scene():
     """A light with a vertex exactly at the origin: shading points a denormal-ish distance from it give squared lengths below
     2^-100, outside the proven domain of the kernel's fast exact sqrt (csrc/ssx_exact.h) -- the kernel must take the plain IEEE

@@ -294,6 +294,22 @@ def test_more_than_32_primitives(n_prims, observer):
     assert np.array_equal(bits(r.xyza), bits(ref)) and ref[..., :3].max() > 0
 
 
+def test_many_textures():
+    """Nine textures of different sizes (1 x 1, non-square, 256 x 2) on the walls, the floor and the short block: each
+    Lambertian material holds its own texture (src/material.cpp:10-29); the reference's scenes use one."""
+    c = crafted.many_textures_scene(9)
+    r, orc = custom_pair(c)
+    W, H, spp = 40, 40, 4
+    r.options.res = (W, H); r.options.spp = spp; r.options.seed = 12
+    xyza, state, _ = r.debug_samples()
+    ref_xyza, ref_state, st = orc.samples(W, H, spp, seed=12)
+    assert np.array_equal(state, ref_state) and np.array_equal(bits(xyza), bits(ref_xyza))
+    r.xyza = np.zeros((H, W, 4), dtype=np.float32)
+    r.render_start(); r.render_wait()
+    ref = orc.render(W, H, spp, seed=12)
+    assert np.array_equal(bits(r.xyza), bits(ref)) and ref[..., :3].max() > 0
+
+
 def test_scene_limits_are_errors_not_surprises():
     c = crafted.many_prims_scene(129)
     orc = c.oracle()
@@ -308,6 +324,10 @@ def test_scene_limits_are_errors_not_surprises():
     with pytest.raises(Exception) as e:
         r.upload_scene_desc(c.desc(c.oracle()))
     assert "2^30" in str(e.value)
+    c = crafted.many_textures_scene(65)
+    with pytest.raises(Exception) as e:
+        r.upload_scene_desc(c.desc(c.oracle()))
+    assert "too many textures" in str(e.value)
 
 
 def test_light_sampling_a_hair_from_a_light_vertex_at_the_origin():

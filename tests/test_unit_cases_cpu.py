@@ -104,3 +104,13 @@ def test_many_prims_scene_shapes():
         o = c.oracle()
         img, st = o.render(16, 12, 2, seed=6, stats=True)
         assert np.isfinite(img).all() and img[..., :3].max() > 0 and st.nee_visible > 50
+
+
+def test_many_textures_scene_shapes():
+    c = crafted.many_textures_scene(9)
+    assert len(c.textures) == 9 and len({t.shape for t in c.textures}) == 9
+    used = {c.materials[m]["albedo_texture"] for _, _, m in c.quads if c.materials[m]["albedo_mode"] == 1}
+    assert used == set(range(9))                                                     # every texture is some quad's albedo
+    o = c.oracle()
+    img, st = o.render(16, 16, 2, seed=12, stats=True)
+    assert np.isfinite(img).all() and img[..., :3].max() > 0
