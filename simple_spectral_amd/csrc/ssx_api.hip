@@ -1051,7 +1051,8 @@ int ssx_reduce_rccl(ssx_ctx** ctxs, int n, uint32_t width, uint32_t height) {
 	}
 	std::vector<int> devs(n);
 	for (int i = 0; i < n; ++i) {
-		if (!ctxs[i] || !ctxs[i]->d_out) return fail(root, SSX_ERR_STATE, "ssx_reduce_rccl: a context has no rendered framebuffer");
+		if (!ctxs[i] || !ctxs[i]->d_out || ctxs[i]->out_pixels < (size_t)width * height) return fail(root, SSX_ERR_STATE, "ssx_reduce_rccl: a context has no rendered framebuffer of that size");
+		if (ctxs[i]->rendering.load()) return fail(root, SSX_ERR_STATE, "ssx_reduce_rccl: render in progress");
 		devs[i] = ctxs[i]->device;
 		for (int k = 0; k < i; ++k) if (devs[k] == devs[i]) return fail(root, SSX_ERR_ARG, "ssx_reduce_rccl: two contexts on one device (RCCL wants one rank per device; use ssx_accumulate_peer)");
 	}
@@ -1082,7 +1083,7 @@ int ssx_debug_eval(ssx_ctx* ctx, uint32_t op, const void* in, uint32_t in_words,
 	SSX_HIP(ctx, hipSetDevice(ctx->device));
 	uint32_t *d_in = nullptr, *d_out = nullptr;
 	SSX_HIP(ctx, hipMalloc((void**)&d_in, (size_t)n * in_words * 4));
-	SSX_HIP(ctx, hipMalloc((void**)&d_out, (size_t)n * out_words * 4));
+	if (hipMalloc((void**)&d_out, (size_t)n * out_words * 4) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d_in); return fail(ctx, SSX_ERR_DEVICE, "out of device memory (ssx_debug_eval)"); }
 	int rc = SSX_OK;
 	auto run = [&]() -> int {
 		SSX_HIP(ctx, hipMemcpy(d_in, in, (size_t)n * in_words * 4, hipMemcpyHostToDevice));
