@@ -129,6 +129,46 @@ def many_textures_scene(n_textures=9, seed=4):
     return c
 
 
+def random_scene(seed):
+    """A scene drawn from `seed`: 3..40 quads and triangles of all sizes and orientations, sometimes inside a closed room, with
+    Lambertian (constant / textured), mirror and emissive materials, at least one light (quad or triangle), a random camera.
+    Returns (scene, render options): indirect_only / explicit light sampling / flat-field correction are drawn as well.  The
+    differential fuzz of the parity tests: combinations no hand-made scene has (a mirror next to a triangle light in a build
+    without explicit light sampling, textures on triangles, lights seen edge-on, ...)."""
+    g = np.random.default_rng(1000 + seed)
+    c = cs.CustomScene("cornell-srgb", keep_quads=False, observer=(1931, 2006)[int(g.integers(0, 4) == 0)])
+    mats = [WHITE, GREEN, RED]
+    white_spectrum = c.materials[WHITE]["albedo_spectrum"]
+    mats.append(c.add_material(kind=1, albedo_spectrum=white_spectrum))                 # a mirror (src/material.cpp:146-167)
+    for _ in range(int(g.integers(0, 3))):                                              # up to two more textures
+        h, w = (int(v) for v in g.integers(1, 24, size=2))
+        c.textures.append(g.integers(0, 256, size=(h, w, 3), dtype=np.uint8))
+    for t in range(len(c.textures)):
+        mats.append(c.add_material(albedo_texture=t))
+    if g.integers(0, 2):
+        _room(c, mat=mats[int(g.integers(0, len(mats)))])
+    n = int(g.integers(3, 41))
+    n_lights = 0
+    while len(c.quads) < n or n_lights == 0:
+        ctr = g.uniform(-3.0, 3.0, size=3)
+        u = g.normal(size=3); u /= np.linalg.norm(u)
+        v = np.cross(u, g.normal(size=3)); v /= np.linalg.norm(v)
+        su, sv = np.exp(g.uniform(np.log(0.05), np.log(2.5), size=2))
+        light = g.integers(0, 6) == 0 or (len(c.quads) >= n and n_lights == 0)
+        m = LIGHT if light else mats[int(g.integers(0, len(mats)))]
+        n_lights += int(light)
+        skew = g.uniform(-0.3, 0.3) * su * u if g.integers(0, 3) == 0 else 0.0 * u       # some quads are not rectangles
+        p00, p10, p11, p01 = ctr - su * u - sv * v, ctr + su * u - sv * v, ctr + su * u + sv * v + skew, ctr - su * u + sv * v
+        if g.integers(0, 4) == 0:
+            c.add_tri(p00, p10, p11, m)
+        else:
+            c.add_quad(p00, p10, p11, p01, m)
+    eye = g.uniform(-3.8, 3.8, size=3)
+    c.set_camera(tuple(eye), tuple(g.uniform(-1.0, 1.0, size=3)), up=(0, 1, 0), vfov_deg=float(g.uniform(20.0, 90.0)))
+    opts = dict(indirect_only=bool(g.integers(0, 4) == 0), els=bool(g.integers(0, 3) != 0), flat_field=bool(g.integers(0, 4) != 0))
+    return c, opts
+
+
 def origin_light_scene():
     """A light with a vertex exactly at the origin: shading points a denormal-ish distance from it give squared lengths below
     2^-100, outside the proven domain of the kernel's fast exact sqrt (csrc/ssx_exact.h) -- the kernel must take the plain IEEE

@@ -310,6 +310,25 @@ def test_many_textures():
     assert np.array_equal(bits(r.xyza), bits(ref)) and ref[..., :3].max() > 0
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_random_scenes(seed):
+    """Differential fuzz: a scene, a camera and the render switches drawn from the seed (tests/crafted.py random_scene), rendered
+    by both sides -- per sample (XYZA and the final PCG32 state, i.e. the draws consumed) and as an image."""
+    c, o = crafted.random_scene(seed)
+    r, orc = custom_pair(c)
+    W, H, spp = 24, 20, 3
+    r.options.res = (W, H); r.options.spp = spp; r.options.seed = seed
+    r.options.indirect_only = o["indirect_only"]; r.options.explicit_light_sampling = o["els"]; r.options.flat_field_correction = o["flat_field"]
+    xyza, state, _ = r.debug_samples()
+    ref_xyza, ref_state, st = orc.samples(W, H, spp, seed=seed, indirect_only=o["indirect_only"], els=o["els"], flat_field=o["flat_field"])
+    assert np.array_equal(state, ref_state)
+    assert np.array_equal(bits(xyza), bits(ref_xyza)) or same_bits_or_both_nan(bits(xyza).reshape(-1, 4), bits(ref_xyza).reshape(-1, 4), range(4)).all()
+    r.xyza = np.zeros((H, W, 4), dtype=np.float32)
+    r.render_start(); r.render_wait()
+    ref = orc.render(W, H, spp, seed=seed, indirect_only=o["indirect_only"], els=o["els"], flat_field=o["flat_field"])
+    assert np.array_equal(bits(r.xyza), bits(ref)) or same_bits_or_both_nan(bits(r.xyza).reshape(-1, 4), bits(ref).reshape(-1, 4), range(4)).all()
+
+
 def test_scene_limits_are_errors_not_surprises():
     c = crafted.many_prims_scene(129)
     orc = c.oracle()

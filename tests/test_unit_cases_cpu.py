@@ -114,3 +114,17 @@ def test_many_textures_scene_shapes():
     o = c.oracle()
     img, st = o.render(16, 16, 2, seed=12, stats=True)
     assert np.isfinite(img).all() and img[..., :3].max() > 0
+
+
+def test_random_scenes_are_valid_and_varied():
+    kinds, seen_opts = set(), set()
+    for seed in range(12):
+        c, opts = crafted.random_scene(seed)
+        assert 3 <= len(c.quads) <= 48 and any(m == crafted.LIGHT for _, _, m in c.quads)
+        kinds |= {c.materials[m]["kind"] for _, _, m in c.quads}
+        if c.kinds: kinds.add("tri")
+        if any(c.materials[m]["albedo_mode"] for _, _, m in c.quads): kinds.add("tex")
+        seen_opts.add(tuple(sorted(opts.items())))
+        img = c.oracle().render(12, 10, 2, seed=seed, indirect_only=opts["indirect_only"], els=opts["els"], flat_field=opts["flat_field"])
+        assert img.shape == (10, 12, 4)
+    assert kinds >= {0, 1, "tri", "tex"} and len(seen_opts) >= 4
