@@ -130,7 +130,7 @@ def many_textures_scene(n_textures=9, seed=4):
 
 
 def random_scene(seed):
-    """A scene drawn from `seed`: 3..40 quads and triangles of all sizes and orientations, sometimes inside a closed room, with
+    """A scene drawn from `seed`: 3..40 (one in six: up to 115) quads and triangles of all sizes and orientations, sometimes inside a closed room, with
     Lambertian (constant / textured), mirror and emissive materials, at least one light (quad or triangle), a random camera.
     Returns (scene, render options): indirect_only / explicit light sampling / flat-field correction are drawn as well.  The
     differential fuzz of the parity tests: combinations no hand-made scene has (a mirror next to a triangle light in a build
@@ -147,7 +147,7 @@ def random_scene(seed):
         mats.append(c.add_material(albedo_texture=t))
     if g.integers(0, 2):
         _room(c, mat=mats[int(g.integers(0, len(mats)))])
-    n = int(g.integers(3, 41))
+    n = int(g.integers(3, 41)) if g.integers(0, 6) else int(g.integers(41, 110))      # one scene in six: several groups of 32 primitives
     n_lights = 0
     while len(c.quads) < n or n_lights == 0:
         ctr = g.uniform(-3.0, 3.0, size=3)

@@ -120,7 +120,7 @@ def test_random_scenes_are_valid_and_varied():
     kinds, seen_opts = set(), set()
     for seed in range(12):
         c, opts = crafted.random_scene(seed)
-        assert 3 <= len(c.quads) <= 48 and any(m == crafted.LIGHT for _, _, m in c.quads)
+        assert 3 <= len(c.quads) <= 116 and any(m == crafted.LIGHT for _, _, m in c.quads)
         kinds |= {c.materials[m]["kind"] for _, _, m in c.quads}
         if c.kinds: kinds.add("tri")
         if any(c.materials[m]["albedo_mode"] for _, _, m in c.quads): kinds.add("tex")
