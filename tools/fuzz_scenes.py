@@ -18,13 +18,16 @@ from simple_spectral_amd.renderer import Options, Renderer  # noqa: E402
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 500
-    bad, t0, prims, nan_px = [], time.time(), 0, 0
+    bad, t0, prims, nan_px, samples = [], time.time(), 0, 0, 0
     for seed in range(first, first + count):
         c, o = crafted.random_scene(seed)
         orc = c.oracle()
         r = Renderer(Options(scene_name="cornell", res=(8, 8), spp=1, observer=c.observer))
         r.upload_scene_desc(c.desc(orc))
-        W, H, spp = 40, 32, 4
+        g = np.random.default_rng(77 + seed)                                   # image shape, samples and launch chunking vary too
+        W, H, spp = int(g.integers(1, 71)), int(g.integers(1, 61)), int(g.integers(1, 10))
+        r.options.spp_per_launch = int(g.integers(0, spp + 1))                  # 0: the library's choice
+        samples += W * H * spp
         r.options.res = (W, H); r.options.spp = spp; r.options.seed = seed
         r.options.indirect_only = o["indirect_only"]; r.options.explicit_light_sampling = o["els"]; r.options.flat_field_correction = o["flat_field"]
         r.xyza = np.zeros((H, W, 4), dtype=np.float32)
@@ -37,8 +40,8 @@ def main():
             bad.append((seed, int((~same).sum())))
             print("MISMATCH seed", seed, "floats", int((~same).sum()), o, flush=True)
         r.close()
-    print("scenes %d (seeds %d..%d), %d primitives, %d samples each; pixels with a NaN in the oracle's image (both sides agree): %d; mismatching scenes: %d; %.0f s"
-          % (count, first, first + count - 1, prims, 40 * 32 * 4, nan_px, len(bad), time.time() - t0))
+    print("scenes %d (seeds %d..%d), %d primitives, %d samples (images of 1..70 x 1..60 pixels, 1..9 spp, random launch chunking); pixels with a NaN in the oracle's image (both sides agree): %d; mismatching scenes: %d; %.0f s"
+          % (count, first, first + count - 1, prims, samples, nan_px, len(bad), time.time() - t0))
     return 1 if bad else 0
 
 
