@@ -60,7 +60,8 @@ struct ssx_ctx {
 	int gen_blocks = 0;                 // the same for the generate kernel
 	uint32_t max_wave_slots = 0;        // most waves of the path kernel the GPU can hold: CUs x 16
 	uint32_t queue_words = SSX_QUEUE_WORDS_WIDE; // entry size of the shadow-ray queues the launches use (pick_queue)
-	uint8_t* d_samples = nullptr; size_t sample_slots = 0; // per-sample arrays (ssx_blob.h), one allocation; record capacity
+	uint8_t* d_samples = nullptr; size_t sample_slots = 0; // per-sample arrays (ssx_blob.h), one allocation; record capacity.  Behind them, in the
+	                                                       // same allocation, the per-tile and per-unit words of a launch (kAuxBytesPerSlot, make_batch)
 	uint8_t* d_logs = nullptr; size_t log_records = 0;     // the persistent waves' level logs (ssx_blob.h); log-record capacity
 	float* d_out = nullptr;     size_t out_pixels = 0;
 	float* d_peer = nullptr;    size_t peer_pixels = 0; // staging buffer of ssx_accumulate_peer
@@ -75,8 +76,6 @@ struct ssx_ctx {
 	int worker_rc = 0;
 	ssx_render_params cur{};
 
-	uint32_t* d_tile_done = nullptr; size_t tile_done_slots = 0; // per tile slot: samples per pixel accumulated in the running launch (ssx_blob.h)
-	uint32_t* d_tile_mask = nullptr; // per tile slot 4 words (same capacity): primitives the tile's camera rays can hit
 
 	// optional per-kernel timing (ssx_set_timing): events around each stage of each batch
 	bool timing = false;
@@ -88,6 +87,9 @@ struct ssx_ctx {
 	// later entry points wait for this event before they touch them
 	hipEvent_t ev_device_done = nullptr;
 	bool device_pending = false;
+
+	// ssx_reduce_rccl: this context's communicator of the group it last combined with (kept for the next combine)
+	void* rccl_comm = nullptr; uint64_t rccl_group = 0; int rccl_rank = -1, rccl_size = 0;
 
 	std::mutex error_mutex; // `error` is written by the worker thread and read by ssx_last_error
 	std::string error;
@@ -108,6 +110,24 @@ void set_error(ssx_ctx* ctx, const std::string& msg) { std::lock_guard<std::mute
 	} while (0)
 
 int fail(ssx_ctx* ctx, int code, const std::string& msg) { set_error(ctx, msg); return code; }
+
+// RCCL through dlopen (ssx_reduce_rccl)
+struct RcclApi {
+	void* lib = nullptr;
+	int (*init_all)(void**, int, const int*) = nullptr;
+	int (*group_start)() = nullptr;
+	int (*group_end)() = nullptr;
+	int (*reduce)(const void*, void*, size_t, int, int, int, void*, hipStream_t) = nullptr;
+	int (*comm_destroy)(void*) = nullptr;
+	const char* (*error_string)(int) = nullptr;
+	uint64_t groups_made = 0;
+	std::mutex mutex;
+};
+RcclApi& rccl_api() { static RcclApi api; return api; }
+void drop_rccl_comm(ssx_ctx* ctx) {
+	if (ctx->rccl_comm && rccl_api().comm_destroy) { (void)hipSetDevice(ctx->device); (void)rccl_api().comm_destroy(ctx->rccl_comm); }
+	ctx->rccl_comm = nullptr; ctx->rccl_group = 0; ctx->rccl_rank = -1; ctx->rccl_size = 0;
+}
 
 uint32_t align4(uint32_t words) { return (words + 3u) & ~3u; }
 
@@ -372,6 +392,10 @@ int ensure_buffers(ssx_ctx* ctx, uint32_t width, uint32_t height, bool need_out)
 // levels of the recursion live in the persistent waves' logs (ensure_logs), whose size does not depend on the launch.
 constexpr size_t kSampleBufferBudget = (size_t)16 << 30; // bytes of per-sample arrays one launch may use (512^2 x 256 spp = 3.2 GB; 16 GiB = 358 M samples ~ 110 ms of rendering)
 constexpr size_t kBytesPerSampleInFlight = SSX_BYTES_PER_SAMPLE;
+// Behind the per-sample arrays, per launch: unit_state (1 word per work unit) and tile_mask (4 words per tile slot).  A launch of R records
+// has at most R / 64 tile slots and R / 64 units: 5 words per 64 records bound both, so the words are part of the sample allocation
+// (sized before anything is enqueued: ensure_samples) and never grown in the enqueue path.
+constexpr size_t kAuxWordsPer64Records = 5;
 constexpr uint32_t kMinUnits = 3072;                   // one wave work unit per wave slot of the GPU (256 CUs x 4 SIMDs x 3 waves)
 
 struct LaunchPlan { SsxKernelArgs args; size_t lds_bytes; uint32_t max_spp_per_launch; };
@@ -413,7 +437,7 @@ int ensure_samples(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t n_k) {
 	if (ctx->sample_slots < need) {
 		if (ctx->d_samples) (void)hipFree(ctx->d_samples);
 		ctx->d_samples = nullptr; ctx->sample_slots = 0;
-		hipError_t e = hipMalloc((void**)&ctx->d_samples, need * kBytesPerSampleInFlight);
+		hipError_t e = hipMalloc((void**)&ctx->d_samples, need * kBytesPerSampleInFlight + (need / 64u) * kAuxWordsPer64Records * sizeof(uint32_t));
 		if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(ctx, SSX_ERR_DEVICE, fmt("out of device memory for %zu samples in flight; lower spp_per_launch", need)); }
 		SSX_HIP(ctx, e);
 		ctx->sample_slots = need;
@@ -514,7 +538,11 @@ Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1) {
 	b.rc = ensure_logs(ctx, a.unit_cohorts);
 	if (b.rc == SSX_OK) bind_arrays(a, ctx->d_samples, a.n_records, ctx->d_logs, ctx->log_records);
 	a.accum = ctx->d_accum;
-	a.tile_done = ctx->d_tile_done;
+	// the launch's per-unit and per-tile words, behind the sample arrays' capacity: unit_state | tile_mask
+	uint32_t* const aux = reinterpret_cast<uint32_t*>(ctx->d_samples + ctx->sample_slots * kBytesPerSampleInFlight);
+	a.unit_state = aux;
+	a.tile_mask = aux + b.units;
+	if (b.rc == SSX_OK && (size_t)a.my_tiles * 4u + b.units > (ctx->sample_slots / 64u) * kAuxWordsPer64Records) b.rc = fail(ctx, SSX_ERR_STATE, "internal: launch larger than the sample allocation");
 	return b;
 }
 
@@ -570,15 +598,8 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	if (ctx->timing) { int r = timing_events(ctx, &b.tev); if (r) return r; SSX_HIP(ctx, hipEventRecord(b.tev[0], stream)); }
 	// the calibration render runs the generic kernels, which read the per-quad vertex table: they stage the whole blob
 	if (calibration) b.a.blob_words = ctx->blob_words;
-	// per-tile buffers of the launch: the progress words of the pixel sums, and the camera-ray primitive masks
-	if (ctx->tile_done_slots < b.a.my_tiles) { // (grown here, synchronously: the first launch of a larger image)
-		if (ctx->d_tile_done) { SSX_HIP(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->d_tile_done); (void)hipFree(ctx->d_tile_mask); }
-		ctx->d_tile_done = nullptr; ctx->d_tile_mask = nullptr; ctx->tile_done_slots = 0;
-		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_tile_done, (size_t)b.a.my_tiles * sizeof(uint32_t)));
-		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_tile_mask, (size_t)b.a.my_tiles * 4u * sizeof(uint32_t)));
-		ctx->tile_done_slots = b.a.my_tiles;
-	}
-	b.a.tile_done = ctx->d_tile_done; b.a.tile_mask = ctx->d_tile_mask;
+	// (the per-tile and per-unit words of the launch -- progress words and hand-over states of the pixel sums, camera-ray primitive
+	// masks -- live behind the sample arrays: make_batch)
 	{
 		// camera rays + (where the scene pre-traces them) their closest hits: persistent workgroups striding over the record
 		// waves; they stage the whole blob -- the trace is the generic one, restricted per tile to the primitives its frustum
@@ -604,7 +625,10 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	if (ctx->timing) SSX_HIP(ctx, hipEventRecord(b.tev[1], stream));
 	// persistent waves: as many workgroups as the GPU holds at once (or fewer, for a small launch); they
 	// fetch work units from a counter
-	if (!ctx->d_unit_counter) SSX_HIP(ctx, hipMalloc((void**)&ctx->d_unit_counter, 2 * sizeof(uint32_t))); // [1]: rays that left the scene (calibration render)
+	if (!ctx->d_unit_counter) { // [1]: rays that left the scene (calibration render); [2], [3]: units parked / added by the wave in front (ssx_sums_info; never reset)
+		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_unit_counter, 4 * sizeof(uint32_t)));
+		SSX_HIP(ctx, hipMemsetAsync(ctx->d_unit_counter, 0, 4 * sizeof(uint32_t), stream));
+	}
 	if (ctx->resident_blocks == 0 || calibration) {
 		int per_cu = 0;
 		hipDeviceProp_t prop;
@@ -623,7 +647,7 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	KernelRef path_kernel = path_kernel_ref(ctx, b.a.queue_words == SSX_QUEUE_WORDS_NARROW);
 	if (calibration) { path_kernel = KernelRef(); path_kernel.host = (const void*)ssx_calibrate_kernel; }
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_unit_counter, 0, 2 * sizeof(uint32_t), stream));
-	SSX_HIP(ctx, hipMemsetAsync(ctx->d_tile_done, 0, (size_t)b.a.my_tiles * sizeof(uint32_t), stream));
+	SSX_HIP(ctx, hipMemsetAsync(b.a.unit_state, 0, (size_t)b.units * sizeof(uint32_t), stream));
 	b.a.unit_counter = ctx->d_unit_counter;
 	const uint32_t want_blocks = (b.units + 3u) / 4u;
 	uint32_t blocks = want_blocks < (uint32_t)ctx->resident_blocks ? want_blocks : (uint32_t)ctx->resident_blocks;
@@ -792,8 +816,7 @@ void ssx_destroy(ssx_ctx* ctx) {
 	if (ctx->d_out) (void)hipFree(ctx->d_out);
 	if (ctx->d_peer) (void)hipFree(ctx->d_peer);
 	for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
-	if (ctx->d_tile_done) (void)hipFree(ctx->d_tile_done);
-	if (ctx->d_tile_mask) (void)hipFree(ctx->d_tile_mask);
+	if (ctx->rccl_comm) { std::lock_guard<std::mutex> g(rccl_api().mutex); drop_rccl_comm(ctx); }
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -1028,26 +1051,22 @@ int ssx_accumulate_peer(ssx_ctx* ctx, void* d_dst, int src_device, const void* d
 // per context of this process (ncclCommInitAll), one grouped ncclReduce(sum, float) of the device framebuffers into
 // ctxs[0]'s.  RCCL is opened with dlopen: a process that combines by peer copies (ssx_accumulate_peer) never loads it.
 // Every pixel is nonzero on exactly one device, so the sum is exact whatever the reduction tree.
+// The communicators are created on the first combine of a group of contexts and KEPT in the contexts (ncclCommInitAll costs
+// far more than the 4 MiB reduce it serves); a call with another group (other contexts, another order) replaces them, and
+// ssx_destroy destroys what its context holds.
 int ssx_reduce_rccl(ssx_ctx** ctxs, int n, uint32_t width, uint32_t height) {
 	if (!ctxs || n <= 0 || !ctxs[0] || width == 0 || height == 0) return SSX_ERR_ARG;
 	ssx_ctx* root = ctxs[0];
-	typedef void* comm_t;
-	static void* lib = nullptr;
-	static int (*init_all)(comm_t*, int, const int*) = nullptr;
-	static int (*group_start)() = nullptr;
-	static int (*group_end)() = nullptr;
-	static int (*reduce)(const void*, void*, size_t, int, int, int, comm_t, hipStream_t) = nullptr;
-	static int (*comm_destroy)(comm_t) = nullptr;
-	static const char* (*error_string)(int) = nullptr;
-	static std::mutex load_mutex;
-	std::lock_guard<std::mutex> load_guard(load_mutex); // one combine at a time per process (loading the library, and the communicators below)
-	if (!lib) {
-		for (const char* name : { "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so" }) if ((lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
-		if (!lib) return fail(root, SSX_ERR_DEVICE, std::string("RCCL is not available (") + dlerror() + ")");
-		init_all = (decltype(init_all))dlsym(lib, "ncclCommInitAll"); group_start = (decltype(group_start))dlsym(lib, "ncclGroupStart");
-		group_end = (decltype(group_end))dlsym(lib, "ncclGroupEnd"); reduce = (decltype(reduce))dlsym(lib, "ncclReduce");
-		comm_destroy = (decltype(comm_destroy))dlsym(lib, "ncclCommDestroy"); error_string = (decltype(error_string))dlsym(lib, "ncclGetErrorString");
-		if (!init_all || !group_start || !group_end || !reduce || !comm_destroy || !error_string) { lib = nullptr; return fail(root, SSX_ERR_DEVICE, "RCCL lacks an entry point"); }
+	RcclApi& rccl = rccl_api();
+	std::lock_guard<std::mutex> load_guard(rccl.mutex); // one combine at a time per process (loading the library, and the communicators below)
+	if (!rccl.lib) {
+		// the soname first: a process that already holds an RCCL under that name (torch's) must not map a second one
+		for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so" }) if ((rccl.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+		if (!rccl.lib) { const char* why = dlerror(); return fail(root, SSX_ERR_DEVICE, std::string("RCCL is not available (") + (why ? why : "dlopen failed") + ")"); }
+		rccl.init_all = (decltype(rccl.init_all))dlsym(rccl.lib, "ncclCommInitAll"); rccl.group_start = (decltype(rccl.group_start))dlsym(rccl.lib, "ncclGroupStart");
+		rccl.group_end = (decltype(rccl.group_end))dlsym(rccl.lib, "ncclGroupEnd"); rccl.reduce = (decltype(rccl.reduce))dlsym(rccl.lib, "ncclReduce");
+		rccl.comm_destroy = (decltype(rccl.comm_destroy))dlsym(rccl.lib, "ncclCommDestroy"); rccl.error_string = (decltype(rccl.error_string))dlsym(rccl.lib, "ncclGetErrorString");
+		if (!rccl.init_all || !rccl.group_start || !rccl.group_end || !rccl.reduce || !rccl.comm_destroy || !rccl.error_string) { dlclose(rccl.lib); rccl.lib = nullptr; return fail(root, SSX_ERR_DEVICE, "RCCL lacks an entry point"); }
 	}
 	std::vector<int> devs(n);
 	for (int i = 0; i < n; ++i) {
@@ -1056,23 +1075,38 @@ int ssx_reduce_rccl(ssx_ctx** ctxs, int n, uint32_t width, uint32_t height) {
 		devs[i] = ctxs[i]->device;
 		for (int k = 0; k < i; ++k) if (devs[k] == devs[i]) return fail(root, SSX_ERR_ARG, "ssx_reduce_rccl: two contexts on one device (RCCL wants one rank per device; use ssx_accumulate_peer)");
 	}
-	std::vector<comm_t> comms(n, nullptr);
-	int rc = init_all(comms.data(), n, devs.data());
-	if (rc) return fail(root, SSX_ERR_DEVICE, std::string("ncclCommInitAll: ") + error_string(rc));
+	// the group's communicators: those the contexts hold from an earlier combine of the same group, or new ones.  A group is
+	// named by the number ncclCommInitAll's call got here (rccl_group) -- the same in every context of it -- and the rank.
+	bool have = root->rccl_comm != nullptr && root->rccl_group != 0;
+	for (int i = 0; i < n && have; ++i) have = ctxs[i]->rccl_comm && ctxs[i]->rccl_group == root->rccl_group && ctxs[i]->rccl_rank == i && ctxs[i]->rccl_size == n;
+	int rc = 0;
+	if (!have) {
+		for (int i = 0; i < n; ++i) drop_rccl_comm(ctxs[i]);
+		std::vector<void*> comms(n, nullptr);
+		rc = rccl.init_all(comms.data(), n, devs.data());
+		if (rc) return fail(root, SSX_ERR_DEVICE, std::string("ncclCommInitAll: ") + rccl.error_string(rc));
+		const uint64_t group = ++rccl.groups_made;
+		for (int i = 0; i < n; ++i) { ctxs[i]->rccl_comm = comms[i]; ctxs[i]->rccl_group = group; ctxs[i]->rccl_rank = i; ctxs[i]->rccl_size = n; }
+	}
 	const size_t count = (size_t)width * height * 4u;
-	rc = group_start();
+	rc = rccl.group_start();
 	for (int i = 0; i < n && !rc; ++i) {
 		if (hipSetDevice(devs[i]) != hipSuccess) { rc = -1; break; }
-		rc = reduce(ctxs[i]->d_out, ctxs[i]->d_out, count, 7 /* ncclFloat */, 0 /* ncclSum */, 0, comms[i], ctxs[i]->stream);
+		rc = rccl.reduce(ctxs[i]->d_out, ctxs[i]->d_out, count, 7 /* ncclFloat */, 0 /* ncclSum */, 0, ctxs[i]->rccl_comm, ctxs[i]->stream);
 	}
-	const int rc_end = group_end();
+	const int rc_end = rccl.group_end();
 	if (!rc) rc = rc_end;
 	for (int i = 0; i < n; ++i) { (void)hipSetDevice(devs[i]); (void)hipStreamSynchronize(ctxs[i]->stream); }
-	for (comm_t c : comms) if (c) (void)comm_destroy(c);
 	(void)hipSetDevice(root->device);
-	if (rc) return fail(root, SSX_ERR_DEVICE, std::string("ncclReduce: ") + (rc > 0 ? error_string(rc) : "hipSetDevice failed"));
+	if (rc) {
+		for (int i = 0; i < n; ++i) drop_rccl_comm(ctxs[i]); // (a failed collective leaves the communicators in an unknown state)
+		return fail(root, SSX_ERR_DEVICE, std::string("ncclReduce: ") + (rc > 0 ? rccl.error_string(rc) : "hipSetDevice failed"));
+	}
 	return SSX_OK;
 }
+
+// communicators created so far in this process (tests: a second combine of the same contexts must not create any)
+uint64_t ssx_rccl_groups_made(void) { return rccl_api().groups_made; }
 
 // ---- diagnostics for the parity tests (never called during a normal render) ----------------------
 
@@ -1195,6 +1229,19 @@ int ssx_scratch_info(ssx_ctx* ctx, uint64_t* sample_bytes, uint64_t* log_bytes) 
 	if (!ctx) return SSX_ERR_ARG;
 	if (sample_bytes) *sample_bytes = (uint64_t)ctx->sample_slots * kBytesPerSampleInFlight;
 	if (log_bytes) *log_bytes = (uint64_t)ctx->log_records * SSX_LOG_BYTES_PER_RECORD;
+	return SSX_OK;
+}
+
+int ssx_sums_info(ssx_ctx* ctx, uint64_t* units_parked, uint64_t* units_chained) {
+	if (!ctx) return SSX_ERR_ARG;
+	uint32_t c[4] = { 0u, 0u, 0u, 0u };
+	if (ctx->d_unit_counter) {
+		SSX_HIP(ctx, hipSetDevice(ctx->device));
+		if (ctx->device_pending) { SSX_HIP(ctx, hipEventSynchronize(ctx->ev_device_done)); ctx->device_pending = false; }
+		SSX_HIP(ctx, hipMemcpy(c, ctx->d_unit_counter, sizeof c, hipMemcpyDeviceToHost));
+	}
+	if (units_parked) *units_parked = c[2];
+	if (units_chained) *units_chained = c[3];
 	return SSX_OK;
 }
 

@@ -1163,6 +1163,23 @@ static_assert(SSX_RESOLVE_WAYS == SSX_COHORT_KS, "a pass of the fold takes one c
 // accesses to the pixel sums, which waves on different XCDs hand to each other (unit_fold): performed at the device's point of coherence
 __device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// _render_pixel (renderer.cpp:292-295): avg += sample * 0.001f -- a float multiply of all four components, widened, added in
+// binary64; RENDER_MODE_RGB (:301-303) adds the sample as it is
+__device__ __forceinline__ void add_sample(const SsxKernelArgs& a, double acc[4], float x, float y, float z, float alpha) {
+	if (a.rgb_mode) { acc[0] += (double)x; acc[1] += (double)y; acc[2] += (double)z; acc[3] += (double)alpha; }
+	else { acc[0] += (double)(x * 0.001f); acc[1] += (double)(y * 0.001f); acc[2] += (double)(z * 0.001f); acc[3] += (double)(alpha * 0.001f); }
+}
+// a sample {X, Y, Z, alpha} parked in its ray[] record until its tile's turn reaches it, and fetched from there (device scope, two 8-byte accesses)
+__device__ __forceinline__ void stage_sample(float4* rec, float x, float y, float z, float alpha) {
+	uint64_t* const q = reinterpret_cast<uint64_t*>(rec);
+	__hip_atomic_store(q, (uint64_t)__float_as_uint(x) | ((uint64_t)__float_as_uint(y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	__hip_atomic_store(q + 1, (uint64_t)__float_as_uint(z) | ((uint64_t)__float_as_uint(alpha) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void add_staged_sample(const SsxKernelArgs& a, double acc[4], const float4* rec) {
+	const uint64_t* const q = reinterpret_cast<const uint64_t*>(rec);
+	const uint64_t lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	add_sample(a, acc, __uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi), __uint_as_float((uint32_t)(hi >> 32)));
+}
 // a level's next-event term where the level parked a shadow ray, else 0: nee[i] as the flush wrote it (wide queue
 // entries), or vis ? nee : 0 (narrow entries; both loads in flight together)
 template <bool NARROW>
@@ -1179,7 +1196,7 @@ __device__ __forceinline__ float4 nee_term(const SsxKernelArgs& a, uint32_t i, b
 // fs_base / nee_base: index of slot 0 of the cohort's logs (log_rec * 9, log_rec * 10); rc0: the lane's pixel of the tile
 // (its first sample within the cohort; way s is sample rc0 + 64 s); acc: the lane's pixel sums (unit_fold)
 template <uint32_t WAYS, bool NARROW>
-__device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count, uint32_t fs_base, uint32_t nee_base, uint32_t rc0, double acc[4]) {
+__device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArgs& a, uint32_t r0, uint32_t stride, uint32_t count, uint32_t fs_base, uint32_t nee_base, uint32_t rc0, double acc[4], bool stage) {
 	float rad[WAYS][4];
 	uint32_t depth[WAYS]; // hit_anything << 4 | number of continued levels
 	uint32_t K[WAYS]; // chain word of the level about to be folded: its entry's `link` (parent slot | nee slot << 13 | emission << 26)
@@ -1251,12 +1268,15 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 			if (a.rgb_mode) { xyz[0] = rad[s][0]; xyz[1] = rad[s][1]; xyz[2] = rad[s][2]; } // renderer.cpp:274-276: lRGB_A_F32(pixel_flux_est, hit)
 			else flux_to_xyz(L, flux, __uint_as_float(a.st[r0 + s * stride].x), xyz); // lambda_0 (re-read: a register per way less across the chain walk)
 			const float alpha = (depth[s] >> 4) ? 1.0f : 0.0f;
-			// _render_pixel (renderer.cpp:292-295): avg += sample * 0.001f -- a float multiply of all four components, widened, added
-			// in binary64 -- in ascending k: the ways are consecutive k, the passes of a unit ascend, and the units of a tile take
-			// turns in k order (unit_fold).  RENDER_MODE_RGB (:301-303) adds the sample as it is.
-			if (a.rgb_mode) { acc[0] += (double)xyz[0]; acc[1] += (double)xyz[1]; acc[2] += (double)xyz[2]; acc[3] += (double)alpha; }
-			else { acc[0] += (double)(xyz[0] * 0.001f); acc[1] += (double)(xyz[1] * 0.001f); acc[2] += (double)(xyz[2] * 0.001f); acc[3] += (double)(alpha * 0.001f); }
-			if (a.keep_samples) a.ray[r0 + s * stride] = make_float4(xyz[0], xyz[1], xyz[2], alpha); // ssx_debug_samples: what _render_sample returns
+			// _render_pixel (renderer.cpp:292-295) adds a pixel's samples in ascending k: the ways are consecutive k, the passes of a
+			// unit ascend, and the units of a tile are added in k order (unit_fold)
+			// Not this unit's turn in its tile's k order (stage, wave-uniform; unit_fold): the sample waits in ray[] -- written at device
+			// scope, the wave that adds it may sit behind another XCD's L2 -- for the wave whose turn reaches it.
+			if (stage) stage_sample(a.ray + (r0 + s * stride), xyz[0], xyz[1], xyz[2], alpha);
+			else {
+				add_sample(a, acc, xyz[0], xyz[1], xyz[2], alpha);
+				if (a.keep_samples) a.ray[r0 + s * stride] = make_float4(xyz[0], xyz[1], xyz[2], alpha); // ssx_debug_samples: what _render_sample returns
+			}
 		}
 }
 
@@ -1379,7 +1399,7 @@ extern "C" __global__ void __launch_bounds__(256) ssx_tile_mask_kernel(SsxKernel
 // reference is evaluated as a forward pass here (each level's direct light and continuation
 // factors go to the per-level arrays) and a backward fold over them when the wave has finished its unit.
 struct WorkUnit { // wave-uniform description of one work unit: 8x8 tile x a group of consecutive samples (four SGPRs: a wave holds two)
-	uint32_t slot, k_off;   // tile slot (index into the device's tiles) and first sample of the unit relative to the launch's k0
+	uint32_t slot, grp;     // tile slot (index into the device's tiles) and group of consecutive samples: the unit's first sample is k0 + grp * group_spp
 	uint32_t tile;          // the tile's index in the image's row-major tile list (its block of the pixel sums)
 	uint32_t dims;          // tile width | tile height << 4 | samples per pixel << 8
 	__device__ __forceinline__ uint32_t tw() const { return dims & 15u; }
@@ -1388,7 +1408,8 @@ struct WorkUnit { // wave-uniform description of one work unit: 8x8 tile x a gro
 	__device__ __forceinline__ uint32_t npx() const { return tw() * th(); }
 	__device__ __forceinline__ uint32_t n_items() const { return npx() * n_kq(); }
 	// first record: records are [tile slot][k - k0][pixel in tile]
-	__device__ __forceinline__ uint32_t rec_base(const SsxKernelArgs& a) const { return (slot * (a.k1 - a.k0) + k_off) * 64u; }
+	__device__ __forceinline__ uint32_t k_off(const SsxKernelArgs& a) const { return grp * a.group_spp; }
+	__device__ __forceinline__ uint32_t rec_base(const SsxKernelArgs& a) const { return (slot * (a.k1 - a.k0) + grp * a.group_spp) * 64u; }
 };
 __device__ __forceinline__ void unit_setup(const SsxKernelArgs& a, uint32_t unit, WorkUnit& u) {
 	const uint32_t slot = unit % a.my_tiles, grp = unit / a.my_tiles;
@@ -1397,21 +1418,66 @@ __device__ __forceinline__ void unit_setup(const SsxKernelArgs& a, uint32_t unit
 	const uint32_t ka = a.k0 + grp * a.group_spp;
 	const uint32_t kb = min(ka + a.group_spp, a.k1);
 	u.dims = min(8u, a.width - tx * 8u) | (min(8u, a.height - ty * 8u) << 4) | ((kb - ka) << 8);
-	u.slot = slot; u.k_off = ka - a.k0;
+	u.slot = slot; u.grp = grp;
 	u.tile = tile;
 }
 // Every lane folds the records of its own pixel of a finished unit.  The loads (levels and records
 // this wave wrote during the unit) overlap with the arithmetic of the other waves on the SIMD, which
 // a separate HBM-bound pass after the kernel could not.
 //
-// The pixel sums (renderer.cpp:292-295: binary64, samples added in ascending k) are kept in a.accum and continued here: a
-// tile's units -- consecutive groups of k, handed out in ascending order by the unit counter -- take turns.  a.tile_done[slot]
-// holds the number of samples per pixel of the tile already added in this launch; a unit waits until that equals its own
-// first sample, adds its samples, and publishes the new count.  The unit waited for was handed out a whole round of
-// tiles earlier, to a wave that is resident and running (persistent grid: every unit handed out is being worked on, and
-// waits only ever point to earlier units), so the wait is short and cannot deadlock.  accum and tile_done are touched only
-// with agent-scope atomic loads and stores (performed at the device's point of coherence, whichever XCD's L2 the two
-// waves sit behind); the sums are complete (s_waitcnt vmcnt(0)) before the count is published.
+// The pixel sums (renderer.cpp:292-295: binary64, samples added in ascending k -- binary64 addition is not associative, so the
+// order is part of the result) are kept in a.accum and continued here.  A tile's units -- consecutive groups of k, folded by
+// whichever waves took them, finishing in any order -- are added in k order WITHOUT ANY WAVE WAITING FOR ANOTHER.  One word per
+// unit, a.unit_state[tile slot][k group] (zeroed before the launch), carries the hand-over:
+//   * SSX_UNIT_TURN: everything in front of the unit has been added.  A unit that finds its word so (or is its tile's first of
+//     the launch) loads the sums, adds its samples as it folds them, and stores the sums.
+//   * A unit whose turn has not come folds all the same, but parks its samples {X, Y, Z, alpha} in their ray[] records (16 bytes
+//     per sample, dead by then) and then swaps its word 0 -> SSX_UNIT_PARKED; its wave goes on with its next unit.
+//   * Whoever has added a unit EXCHANGES the word of the unit behind it for SSX_UNIT_TURN.  If that returns SSX_UNIT_PARKED,
+//     the unit behind is waiting: the wave adds its parked samples too -- 16 bytes and four additions per sample, a tenth of a
+//     fold -- and goes on down the tile's chain the same way.  If it returns 0, the unit behind is still running and will find
+//     its turn has come.  A unit whose compare-and-swap to PARKED fails has been given the turn in the meantime: it adds its own
+//     parked samples and carries on as above.
+//   Every hand-over is ONE atomic read-modify-write of ONE word, so exactly one of the two waves involved adds the unit.
+// (Rounds 1-3 let a unit spin until its turn came.  With one GPU's 4096 tiles at most two units of a tile are in flight and the
+// spin was rare; a rank of an 8-GPU render owns 512 tiles at 8 x the samples per pixel, sixteen units of every tile are in flight
+// at once, and sixteen waves stood still behind every late one: -17 % there, tools/rank_share.py, profiles/r04/rank_share.log.)
+// Memory ordering: accum, unit_state and the parked samples are touched only with agent-scope atomics (performed at the
+// device's point of coherence, whichever XCD's L2 the waves sit behind).  Default build: relaxed atomics, and "the data is in
+// place before the word that announces it" is a wait for the wave's outstanding vector-memory operations (s_waitcnt vmcnt(0):
+// device-scope stores are acknowledged from the point of coherence) -- below the HIP memory model, validated on gfx950 with the
+// toolchains simple_spectral_amd/build.py lists.  -DSSX_ACCUM_FORMAL expresses the same protocol in the model (acquire /
+// release agent-scope atomics on the word, the other lanes' accesses chained to lane 0's through the wave's hand-over word):
+// the compiler then writes back and invalidates the XCD's L2 around every fold (-25 %); tools/test_kernel_variants.sh runs the
+// parity suites on that build too, so the default build is continuously compared with it.
+// "everything this wave has stored is in place": before the word that announces it is written
+__device__ __forceinline__ void sums_release(uint32_t* cnt) {
+#ifdef SSX_ACCUM_FORMAL
+	wave_release(cnt); // every lane's stores -> lane 0, which performs the announcing access
+	wave_acquire(cnt);
+#else
+	(void)cnt;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // (compiler: nothing moves below; emits no instruction)
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+// "what lane 0 has just learnt holds for every lane": behind the word that was read
+__device__ __forceinline__ void sums_acquire(uint32_t* cnt) {
+#ifdef SSX_ACCUM_FORMAL
+	wave_release(cnt);
+	wave_acquire(cnt);
+#else
+	(void)cnt;
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // (compiler: nothing moves above; emits no instruction)
+#endif
+}
+#ifdef SSX_ACCUM_FORMAL
+#define SSX_SUMS_ACQ __ATOMIC_ACQUIRE
+#define SSX_SUMS_ACQ_REL __ATOMIC_ACQ_REL
+#else
+#define SSX_SUMS_ACQ __ATOMIC_RELAXED
+#define SSX_SUMS_ACQ_REL __ATOMIC_RELAXED
+#endif
 template <bool NARROW>
 __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, const WorkUnit& u, uint32_t wave_slot, uint32_t tag, uint32_t* cnt) {
 	// see "Memory-ordering contract" above: the acquire side of the wave's hand-over; then wait for this wave's stores and
@@ -1420,37 +1486,59 @@ __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, 
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	const uint32_t lane = threadIdx.x & 63u;
-	// this unit's turn in the tile's k order?
-	if (u.k_off) {
-#ifdef SSX_ACCUM_FORMAL
-		while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.tile_done + u.slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) != u.k_off) __builtin_amdgcn_s_sleep(8);
-#else
-		while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(a.tile_done + u.slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != u.k_off) __builtin_amdgcn_s_sleep(8);
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#endif
+	const bool has_px = (lane & 7u) < u.tw() && (lane >> 3) < u.th();
+	uint32_t* state = a.unit_state + (u.slot * a.n_groups + u.grp); // this unit's word; the chain below moves on to the units behind it
+	double* const px = a.accum + (size_t)u.tile * 256u + lane; // [tile][component][pixel of the tile]: components 64 doubles apart
+	// this unit's turn in the tile's k order?  (The tile's first unit of the launch need not look.)
+	bool mine = true;
+	if (u.grp) {
+		mine = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(state, SSX_SUMS_ACQ, __HIP_MEMORY_SCOPE_AGENT)) == SSX_UNIT_TURN;
+		sums_acquire(cnt);
 	}
-	if ((lane & 7u) < u.tw() && (lane >> 3) < u.th()) {
-		double* const px = a.accum + (size_t)u.tile * 256u + lane; // [tile][component][pixel of the tile]: components 64 doubles apart
-		// the pixel's running sums: in registers across the unit's passes (one load and one store per unit; per pass, 0.6 % slower)
-		double acc[4] = { ld_agent(px), ld_agent(px + 64), ld_agent(px + 128), ld_agent(px + 192) };
+	double acc[4] = { 0.0, 0.0, 0.0, 0.0 }; // the pixel's running sums: in registers across the unit's passes (per pass: 0.6 % slower) and down the chain
+	if (mine && has_px) { acc[0] = ld_agent(px); acc[1] = ld_agent(px + 64); acc[2] = ld_agent(px + 128); acc[3] = ld_agent(px + 192); }
+	if (has_px)
 		for (uint32_t kq = 0, n_kq = u.n_kq(), rec_base = u.rec_base(a); kq < n_kq; kq += SSX_RESOLVE_WAYS) { // one cohort per pass
 			const uint32_t log_rec = log_region(a, wave_slot, tag, kq / SSX_COHORT_KS);
-			resolve_records<SSX_RESOLVE_WAYS, NARROW>(L, a, rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, n_kq - kq), log_rec * SSX_MAX_FRAMES, log_rec * SSX_MAX_LEVELS, lane, acc);
+			resolve_records<SSX_RESOLVE_WAYS, NARROW>(L, a, rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, n_kq - kq), log_rec * SSX_MAX_FRAMES, log_rec * SSX_MAX_LEVELS, lane, acc, !mine);
 		}
-		st_agent(px, acc[0]); st_agent(px + 64, acc[1]); st_agent(px + 128, acc[2]); st_agent(px + 192, acc[3]);
+	// (rec_at, grp): the unit whose samples are in acc or about to be -- this one, then the units behind it this wave takes over
+	uint32_t rec_at = u.rec_base(a), grp = u.grp;
+	bool parked = !mine; // its samples are still to be added from their ray[] records (this wave's own unit, folded in turn, is in acc already)
+	if (!mine) {
+		// the samples are parked: say so -- unless the turn has come in the meantime
+		sums_release(cnt);
+		uint32_t was = 0u;
+		if (lane == 0u) {
+			atomicAdd(a.unit_counter + 2, 1u); // statistics (ssx_sums_info): units parked
+			uint32_t expected = 0u;
+			(void)__hip_atomic_compare_exchange_strong(state, &expected, SSX_UNIT_PARKED, SSX_SUMS_ACQ_REL, SSX_SUMS_ACQ, __HIP_MEMORY_SCOPE_AGENT);
+			was = expected;
+		}
+		was = (uint32_t)__builtin_amdgcn_readfirstlane((int)was);
+		sums_acquire(cnt);
+		if (was != SSX_UNIT_TURN) return; // the wave that adds the unit in front will find this one parked
+		// the turn has come and nobody will take the unit: its samples are added from where they are parked, like anyone else's
+		if (has_px) { acc[0] = ld_agent(px); acc[1] = ld_agent(px + 64); acc[2] = ld_agent(px + 128); acc[3] = ld_agent(px + 192); }
 	}
-#ifdef SSX_ACCUM_FORMAL
-	if (lane == 0u) __hip_atomic_store(a.tile_done + u.slot, u.k_off + u.n_kq(), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-#else
-	// The sums must have reached the device's point of coherence before the count is published: device-scope (sc1) stores are
-	// acknowledged from there, so waiting for this wave's outstanding vector-memory operations is the release.  (A workgroup-scope
-	// fence compiles to nothing here -- the first version relied on it and lost samples when a tile's units ran neck and neck:
-	// tests/test_gpu_parity.py::test_config1 / test_pixel_sums_chain; an agent-scope release fence adds an L2 write-back of
-	// everything the wave has ever written: -25 %.)
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-	if (lane == 0u) __hip_atomic_store(a.tile_done + u.slot, u.k_off + u.n_kq(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
+	for (;;) {
+		const uint32_t k_at = grp * a.group_spp, n = min(a.group_spp, (a.k1 - a.k0) - k_at);
+		if (has_px) {
+			if (parked) for (uint32_t kq = 0; kq < n; ++kq) add_staged_sample(a, acc, a.ray + (rec_at + kq * 64u + lane));
+			st_agent(px, acc[0]); st_agent(px + 64, acc[1]); st_agent(px + 128, acc[2]); st_agent(px + 192, acc[3]);
+		}
+		if (++grp >= a.n_groups) return; // that was the tile's last unit of the launch
+		// the sums are in place before the unit behind is given the turn
+		sums_release(cnt);
+		uint32_t was = 0u;
+		++state;
+		if (lane == 0u) was = __hip_atomic_exchange(state, SSX_UNIT_TURN, SSX_SUMS_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		was = (uint32_t)__builtin_amdgcn_readfirstlane((int)was);
+		sums_acquire(cnt);
+		if (was != SSX_UNIT_PARKED) return; // still running: it will find its turn has come
+		if (lane == 0u) atomicAdd(a.unit_counter + 3, 1u); // statistics: parked units added by the wave in front of them
+		rec_at += a.group_spp * 64u; parked = true;
+	}
 }
 
 // CALIB: the calibration render of ssx_upload_scene (ssx_calibrate_kernel) also counts the rays that leave the scene

@@ -274,6 +274,14 @@ class Renderer:
             self._check(self._lib.ssx_scratch_info(self._ctx, C.byref(a), C.byref(b)))
         return {"sample_bytes": a.value, "log_bytes": b.value}
 
+    def sums_info(self):
+        """ssx_sums_info: work units that parked their samples instead of waiting for their tile's turn, and how many of those the
+        wave in front of them added (cumulative since the context was created)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        if hasattr(self._lib, "ssx_sums_info"):
+            self._check(self._lib.ssx_sums_info(self._ctx, C.byref(a), C.byref(b)))
+        return {"units_parked": a.value, "units_chained": b.value}
+
     def save(self, path):
         fb = np.ascontiguousarray(self.framebuffer, dtype=np.float32)
         rc = _capi.host_lib().ssh_save_image(path.encode(), fb.ctypes.data, fb.shape[1], fb.shape[0])

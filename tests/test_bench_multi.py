@@ -60,7 +60,7 @@ def test_bench_one_rank_through_rccl(tmp_path):
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 1 and "RCCL reduce (world size 1" in line["config"]["parallelism"]
-    assert line["value"] > 0 and line["value_host_inclusive"] > 0 and line["ms_per_step_host_inclusive"] > 0
+    assert line["value"] > 0 and line["value_device_resident"] > 0 and line["ms_per_step_device_resident"] > 0 and line["value_host_inclusive"] == line["value"]
     img = np.load(dump)
     ref = ol.Oracle("cornell-srgb", texture="test-img.png").render(64, 64, 8)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))

@@ -435,17 +435,34 @@ def test_camera_rays_pretraced_where_rays_leave_the_scene():
 
 def test_pixel_sums_chain_through_the_units_of_a_tile():
     """The binary64 pixel sums (src/renderer.cpp:292-295: ascending k) are continued inside the path kernel: the units of
-    a tile -- groups of consecutive samples, folded by whichever waves took them -- wait for each other in k order.  A tiny
-    image with many samples per pixel makes the chain long and the waves many (every unit waits on its predecessor); also
-    split over several launches (the sums continue) and on a ragged tile."""
+    a tile -- groups of consecutive samples, folded by whichever waves took them -- are added in k order, and no wave waits:
+    a unit that finishes before its turn parks its samples, and the wave in front of it adds them (ssx_kernels.hip unit_fold).
+    A tiny image with many samples per pixel makes the chains long and the waves many (hundreds of units of one tile in flight
+    at once); also split over several launches (the sums continue) and on a ragged tile.  ssx_sums_info proves that the renders
+    went through the parked and the chained branch."""
     for (W, H, spp, chunk) in ((16, 8, 2048, 0), (8, 8, 1536, 500), (11, 5, 777, 0)):
-        got, _ = gpu_render(scene_name="cornell-srgb", res=(W, H), spp=spp, seed=33, texture="test-img.png", spp_per_launch=chunk)
+        got, r = gpu_render(scene_name="cornell-srgb", res=(W, H), spp=spp, seed=33, texture="test-img.png", spp_per_launch=chunk)
         ref = ol.Oracle("cornell-srgb", texture="test-img.png").render(W, H, spp, seed=33)
         assert np.array_equal(bits(got), bits(ref)), (W, H, spp, chunk)
+        info = r.sums_info()
+        assert info["units_parked"] > 10 and 0 < info["units_chained"] <= info["units_parked"], info
+    # One rank's share of BASELINE configs[1] on 8 GPUs in miniature -- every eighth tile, eight times the samples per pixel:
+    # 8 tiles x 128 units each, all 1024 in flight at once -- on the specialised kernel, three times over (the order in which the
+    # units finish differs from run to run, the image must not), foreign tiles exactly zero.
+    import torch
+    r = Renderer(Options(scene_name="cornell-srgb", res=(64, 64), spp=512, seed=7, texture="test-img.png", tile_first=3, tile_stride=8))
+    ref = ol.Oracle("cornell-srgb", texture="test-img.png").render(64, 64, 512, seed=7)
+    mask = sdist.tile_owner_mask(64, 64, 3, 8)
+    ref[~mask] = 0.0
+    out = torch.zeros((64, 64, 4), device="cuda")
+    for _ in range(3):
+        r.render_device(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
+    assert r.sums_info()["units_parked"] > 100
     # Units that run neck and neck: 128 x 128 at 16 spp is 4096 units of ONE sample per pixel, all handed out at once, the 16 of a
     # tile finishing within microseconds of each other -- every hand-over of the sums happens while the predecessor's stores are
     # still on their way (this case lost samples before the hand-over waited for them).  40 renders, one oracle.
-    import torch
     r = Renderer(Options(scene_name="cornell-srgb", res=(128, 128), spp=16, seed=2, texture="test-img.png"))
     ref = ol.Oracle("cornell-srgb", texture="test-img.png").render(128, 128, 16, seed=2)
     out = torch.zeros((128, 128, 4), device="cuda")
