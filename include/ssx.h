@@ -24,7 +24,14 @@
 extern "C" {
 #endif
 
-#define SSX_ABI_VERSION 1
+/* Version of this interface: what ssx_abi_version() of a library built from this header returns.  A host compares the two at load
+ * (the C++ host in simple_spectral_amd/host/renderer.cpp and the Python binding do) and refuses a mismatch.
+ *   1  rounds 1-2
+ *   2  ssx_quad.is_light became the bitfield `flags` (SSX_PRIM_LIGHT | SSX_PRIM_TRI: other nonzero values are refused now);
+ *      ssx_render_params.reserved became no_flat_field_correction (a stale nonzero value changes the image); SSX_MAX_QUADS 32 -> 128,
+ *      SSX_MAX_TEXTURES and the struct sizes grew; ssx_set_jit takes a mode (default: background compilation); ssx_jit_status,
+ *      ssx_jit_counters, ssx_sums_info, ssx_rccl_groups_made are new. */
+#define SSX_ABI_VERSION 2
 
 enum {
 	SSX_OK = 0,
@@ -211,8 +218,12 @@ int ssx_read_framebuffer(ssx_ctx* ctx, float* xyza_out); /* device framebuffer -
 int ssx_accumulate_peer(ssx_ctx* ctx, void* d_dst, int src_device, const void* d_src, uint32_t width, uint32_t height, void* hip_stream);
 
 /* The same combine as one RCCL reduce (sum, float) of the n contexts' device framebuffers into ctxs[0]'s: one rank per
- * context of this process (ncclCommInitAll), the contexts on n different devices.  RCCL is loaded on first use. */
+ * context of this process (ncclCommInitAll), the contexts on n different devices.  RCCL is loaded on first use; the
+ * communicators are created by the first combine of a group of contexts and kept in them for the next (a call with other
+ * contexts, or the same in another order, replaces them; ssx_destroy releases a context's). */
 int ssx_reduce_rccl(ssx_ctx** ctxs, int n, uint32_t width, uint32_t height);
+/* Groups of communicators ssx_reduce_rccl has created in this process so far (a repeated combine must not add any). */
+uint64_t ssx_rccl_groups_made(void);
 
 /* Last error text for ctx (or for ssx_create when ctx is NULL). */
 const char* ssx_last_error(const ssx_ctx* ctx);
@@ -250,16 +261,33 @@ int ssx_sums_info(ssx_ctx* ctx, uint64_t* units_parked, uint64_t* units_chained)
 /* Which path kernel the uploaded scene runs: 0 = the generic one (pass 1 of the intersection loops over the
  * quads), 1 / 2 = the kernel whose pass 1 is specialised to the mesh topology of the reference's Cornell box /
  * plane scene (the scene's quad corners coincide in exactly that pattern; positions are free), 3 = specialised to
- * the scene's own topology at upload (ssx_set_jit).  A performance
+ * the scene's own topology at run time (ssx_set_jit).  A performance
  * choice only: same bits.  The environment variable SSX_GENERIC_KERNEL forces 0 at upload.  -1: no scene. */
 int ssx_kernel_variant(ssx_ctx* ctx);
-/* Pass 1 of the intersection is straight-line code for the two mesh topologies of the reference's built-in scenes; other
- * scenes run a generic loop (~12 % slower).  After ssx_set_jit(ctx, 1), ssx_upload_scene generates that straight-line code
- * for the uploaded scene's own sharing pattern (scenes of at most 32 primitives, all quads, that match no built-in one) and
- * compiles the path kernels around it with hipRTC -- about 5 s once per pattern and process; ssx_kernel_variant then returns 3.
- * Needs libhiprtc and /opt/rocm/include at run time; an upload fails with SSX_ERR_DEVICE if the compilation does.  Same
- * bits as the generic loop.  (The environment variable SSX_JIT_PASS1=1 at upload does the same.) */
-int ssx_set_jit(ssx_ctx* ctx, int enable);
+/* Pass 1 of the intersection is straight-line code for the two mesh topologies of the reference's built-in scenes; a scene whose
+ * corners coincide in another pattern starts on a generic loop (~25 % slower).  Such a scene (at most 32 primitives, all quads) gets
+ * kernels compiled for ITS pattern with hipRTC (a second or two per pattern), kept in this process's memory and in a disk cache
+ * ($SSX_CACHE_DIR, else $XDG_CACHE_HOME/ssx, else ~/.cache/ssx: a later process starts specialised at once, < 50 ms).  When:
+ *   SSX_JIT_BACKGROUND (default)  ssx_upload_scene never waits: code already in memory or on disk is used at once, else the generic
+ *                                 kernel serves the scene and a background thread compiles once the context has rendered 32 M samples on
+ *                                 it; the context switches kernels at the start of a later render (ssx_render_device / ssx_render_start,
+ *                                 and between the launches of an asynchronous render).
+ *   SSX_JIT_AT_UPLOAD             ssx_upload_scene compiles on the calling thread when nobody has the code yet.
+ *   SSX_JIT_OFF                   generic kernel.
+ * Same bits in every case.  A failure of any kind -- no libhiprtc, no HIP headers ($SSX_ROCM_INCLUDE, $ROCM_PATH/include,
+ * /opt/rocm/include), a compile error, an unwritable cache -- leaves the scene on the generic kernel; ssx_jit_status tells. */
+enum { SSX_JIT_OFF = 0, SSX_JIT_AT_UPLOAD = 1, SSX_JIT_BACKGROUND = 2 };
+int ssx_set_jit(ssx_ctx* ctx, int mode);
+/* Where the uploaded scene's own kernels stand.  wait_ms != 0 first asks for the compilation if nobody has (whatever the context has
+ * rendered so far), waits up to wait_ms milliseconds (< 0: until done) for it, and switches kernels if it has arrived.  message
+ * (optional) receives why a compilation failed.  Not while an asynchronous render runs. */
+enum { SSX_JIT_STATE_NONE = 0,              /* nothing to specialise: a built-in topology, triangles or > 32 primitives, or SSX_JIT_OFF */
+       SSX_JIT_STATE_GENERIC_MEANWHILE = 1, /* the generic kernel serves; the scene's own code is not there (yet) */
+       SSX_JIT_STATE_SPECIALISED = 2,       /* the scene's own kernels run (ssx_kernel_variant() == 3) */
+       SSX_JIT_STATE_FAILED = -1 };         /* the generic kernel serves for good; see message */
+int ssx_jit_status(ssx_ctx* ctx, int wait_ms, char* message, size_t message_size);
+/* Patterns compiled by this process so far, and patterns it took from the disk cache (tests, start-up reports). */
+void ssx_jit_counters(uint64_t* compiled, uint64_t* disk_hits);
 /* The name of the path kernel the context launches for the uploaded scene, as a profiler lists it
  * ("ssx_render_kernel", "..._cornell", "..._plane", each also with "_nq": the variants with narrow shadow-ray
  * queue entries, taken where they let one more workgroup live on a CU).  NULL: no scene. */

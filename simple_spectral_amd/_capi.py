@@ -66,13 +66,16 @@ class SsxRenderParams(C.Structure):
 SSX_MODE_RGB, SSX_UPLIFT_OURS, SSX_UPLIFT_MENG, SSX_UPLIFT_JH = 0, 1, 2, 3
 SSX_PRIM_LIGHT, SSX_PRIM_TRI = 1, 0x100
 SSX_OK, SSX_ERR_DATA, SSX_ERR_ARG, SSX_ERR_SCENE, SSX_ERR_DEVICE, SSX_ERR_STATE = 0, -1, -2, -3, -10, -11
+SSX_ABI_VERSION = 2   # include/ssx.h; checked against the library at load
+SSX_JIT_OFF, SSX_JIT_AT_UPLOAD, SSX_JIT_BACKGROUND = 0, 1, 2
+SSX_JIT_STATE_NONE, SSX_JIT_STATE_GENERIC_MEANWHILE, SSX_JIT_STATE_SPECIALISED, SSX_JIT_STATE_FAILED = 0, 1, 2, -1
 
 # every symbol include/ssx.h and include/ssx_host.h declare (tests check the libraries export them)
 HIP_SYMBOLS = ["ssx_create", "ssx_destroy", "ssx_upload_scene", "ssx_render_start", "ssx_render_stop",
                "ssx_is_rendering", "ssx_progress", "ssx_render_wait", "ssx_render_device", "ssx_last_error",
                "ssx_abi_version", "ssx_kernel_info", "ssx_plan_info", "ssx_set_timing", "ssx_get_timing",
                "ssx_device_framebuffer", "ssx_device_index", "ssx_read_framebuffer", "ssx_accumulate_peer",
-               "ssx_debug_eval", "ssx_debug_samples", "ssx_debug_sweep", "ssx_kernel_variant", "ssx_kernel_name", "ssx_scratch_info", "ssx_calibration_info", "ssx_set_jit", "ssx_debug_pass1_source", "ssx_done_spp", "ssx_reduce_rccl", "ssx_sums_info"]
+               "ssx_debug_eval", "ssx_debug_samples", "ssx_debug_sweep", "ssx_kernel_variant", "ssx_kernel_name", "ssx_scratch_info", "ssx_calibration_info", "ssx_set_jit", "ssx_debug_pass1_source", "ssx_done_spp", "ssx_reduce_rccl", "ssx_sums_info", "ssx_rccl_groups_made", "ssx_jit_status", "ssx_jit_counters"]
 (SSX_SWEEP_RCP, SSX_SWEEP_SQRT, SSX_SWEEP_INVERSESQRT, SSX_SWEEP_SIN, SSX_SWEEP_COS, SSX_SWEEP_ACOS, SSX_SWEEP_DIV_PI,
  SSX_SWEEP_RCP64, SSX_SWEEP_DIV_PAIRS, SSX_SWEEP_ACOS_SIN) = range(1, 11)
 # ssx_debug_eval ops (include/ssx.h)
@@ -111,25 +114,67 @@ def host_lib():
     return _host
 
 
+def mapped_hip_runtimes():
+    """The distinct libamdhip64 files mapped into this process."""
+    out = set()
+    try:
+        for ln in open("/proc/self/maps"):
+            f = ln.split(None, 5)
+            if len(f) == 6 and "libamdhip64.so" in os.path.basename(f[5].strip()):
+                out.add(os.path.realpath(f[5].strip()))
+    except OSError:
+        pass
+    return sorted(out)
+
+
+def _one_hip_runtime_before_load():
+    """ONE HIP runtime per process, whatever the import order (this used to be a usage rule).
+    libssx_hip.so needs "libamdhip64.so.7"; torch bundles its own copy under that soname.  Streams, events and device pointers
+    are handed between torch and this library (bench.py, dist.py), which only works inside one runtime.  So:
+      * a runtime is already mapped (torch was imported first, or the host linked one): the loader binds libssx_hip.so to it
+        by soname -- nothing to do;
+      * none is mapped and torch is installed: its bundled copy is mapped NOW (RTLD_GLOBAL), so that libssx_hip.so binds to it
+        and a later `import torch` finds its own runtime already in place;
+      * no torch: libssx_hip.so brings /opt/rocm's through its RUNPATH.
+    _one_hip_runtime_after_load checks the outcome instead of trusting it."""
+    if mapped_hip_runtimes():
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.submodule_search_locations:
+            cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass  # (then the library's own RUNPATH decides; the check below still holds)
+
+
+def _one_hip_runtime_after_load(path):
+    rts = mapped_hip_runtimes()
+    if len(rts) > 1:
+        raise RuntimeError("two HIP runtimes are mapped into this process (%s) after loading %s: streams and device pointers cannot be "
+                           "handed between them.  Import simple_spectral_amd (or torch) before whatever loaded the other one, or "
+                           "point LD_LIBRARY_PATH at one of them." % (", ".join(rts), path))
+
+
 def hip_lib():
     """The HIP library.  There is no fallback: a missing library is an error."""
     global _hip
     if _hip is None:
-        path = os.environ.get("SSX_HIP_LIB_OVERRIDE") or _build.HIP_LIB  # override: A/B and profiling builds (tools/ab_bench.sh, tools/lanestat.py)
+        # SSX_HIP_LIB_OVERRIDE: A/B and profiling builds (tools/ab_bench.sh, tools/lanestat.py); like the library's own A/B
+        # switches it is honoured only under the master switch SSX_DEBUG_ENV=1
+        path = (os.environ.get("SSX_HIP_LIB_OVERRIDE") if os.environ.get("SSX_DEBUG_ENV") == "1" else None) or _build.HIP_LIB
         if not os.path.exists(path):
             raise RuntimeError("%s is missing: run `python -m simple_spectral_amd.build` (needs hipcc). "
                                "simple_spectral_amd has no CPU or PyTorch fallback path." % path)
-        # torch ships its own HIP runtime; if the process uses torch on the GPU, let it initialise
-        # first (initialising it after this library has opened the device is not reliable)
-        import sys
-        if "torch" in sys.modules:
-            try:
-                t = sys.modules["torch"]
-                if t.cuda.is_available():
-                    t.cuda.init()
-            except Exception:
-                pass
+        _one_hip_runtime_before_load()
         lib = C.CDLL(path)
+        _one_hip_runtime_after_load(path)
+        override = path != _build.HIP_LIB
+        if not override and lib.ssx_abi_version() != SSX_ABI_VERSION:  # (an A/B library of an older revision is loaded as it is)
+            raise RuntimeError("%s implements ABI version %d, this binding version %d (include/ssx.h): rebuild with `python -m simple_spectral_amd.build`"
+                               % (path, lib.ssx_abi_version(), SSX_ABI_VERSION))
         vp = C.c_void_p
         lib.ssx_last_error.restype = C.c_char_p
         lib.ssx_last_error.argtypes = [vp]
@@ -156,17 +201,22 @@ def hip_lib():
         lib.ssx_debug_eval.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32]
         lib.ssx_debug_samples.argtypes = [vp, C.POINTER(SsxRenderParams), vp, vp, vp]
         lib.ssx_debug_sweep.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64)]
-        if "SSX_HIP_LIB_OVERRIDE" not in os.environ or hasattr(lib, "ssx_scratch_info"):
+        if not override or hasattr(lib, "ssx_scratch_info"):
             lib.ssx_calibration_info.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int)]
             lib.ssx_scratch_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-        if "SSX_HIP_LIB_OVERRIDE" not in os.environ or hasattr(lib, "ssx_set_jit"):
+        if not override or hasattr(lib, "ssx_set_jit"):
             lib.ssx_set_jit.argtypes = [vp, C.c_int]
             lib.ssx_done_spp.argtypes = [vp]
             lib.ssx_done_spp.restype = C.c_uint32
             lib.ssx_reduce_rccl.argtypes = [C.POINTER(vp), C.c_int, C.c_uint32, C.c_uint32]
             lib.ssx_debug_pass1_source.argtypes = [C.POINTER(C.c_uint8), C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t]
-        if "SSX_HIP_LIB_OVERRIDE" not in os.environ or hasattr(lib, "ssx_sums_info"):
+        if not override or hasattr(lib, "ssx_sums_info"):
             lib.ssx_sums_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        if not override or hasattr(lib, "ssx_jit_status"):
+            lib.ssx_jit_status.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
+            lib.ssx_jit_counters.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+            lib.ssx_jit_counters.restype = None
+            lib.ssx_rccl_groups_made.restype = C.c_uint64
         lib.ssx_kernel_variant.argtypes = [vp]
         lib.ssx_kernel_name.argtypes = [vp]
         lib.ssx_kernel_name.restype = C.c_char_p

@@ -19,14 +19,25 @@
 #include <thread>
 #include <vector>
 
+#include <limits.h>
+#include <set>
+
 #include "ssx_jit.h"
 
 namespace {
 
 thread_local std::string g_create_error;
 
-// environment switches of the A/B runs and tests: set and not "0" / empty
-bool env_on(const char* name) { const char* e = getenv(name); return e && e[0] != '\0' && e[0] != '0'; }
+// Environment switches of the A/B runs and tests (SSX_GENERIC_KERNEL, SSX_JIT_PASS1, SSX_UNIT_SPP, SSX_NARROW_QUEUE, SSX_PRE_HITS).
+// None changes a result bit, all change the kernel plan -- so none is looked at unless the master switch SSX_DEBUG_ENV=1 is set:
+// a variable inherited from somebody's shell cannot silently change what a production process launches.
+const char* debug_env(const char* name) {
+	const char* m = getenv("SSX_DEBUG_ENV");
+	if (!m || m[0] != '1' || m[1] != '\0') return nullptr;
+	return getenv(name);
+}
+// set and not "0" / empty
+bool env_on(const char* name) { const char* e = debug_env(name); return e && e[0] != '\0' && e[0] != '0'; }
 
 struct HostError { int code; std::string msg; };
 
@@ -45,8 +56,16 @@ struct ssx_ctx {
 	uint32_t blob_words = 0;      // whole blob (generic / calibration / debug kernels stage all of it)
 	uint32_t path_blob_words = 0; // what the path kernel stages: without the per-quad vertex table when a specialised kernel runs
 	uint32_t topology = 0;        // 0, the built-in mesh topology the scene matched (csrc/ssx_pass1_gen.h), or 3: its own, compiled at upload
-	bool jit = false;             // ssx_set_jit: specialise pass 1 for scenes that match no built-in topology
+	int jit_mode = SSX_JIT_BACKGROUND; // ssx_set_jit: how pass 1 gets specialised for scenes that match no built-in topology
 	const ssx_jit::Kernels* jit_kernels = nullptr; // the run-time compiled kernels of the uploaded scene (topology 3)
+	// A scene waiting for its own kernels runs the generic one meanwhile: its second blob (packed for topology 3 at upload, the
+	// caller's description is gone later) waits on the device, and the context swaps at the start of a render once the code is
+	// there (maybe_swap_jit).  The compilation is asked for once the context has launched kJitAfterSamples on the generic kernel.
+	bool jit_pending = false, jit_requested = false;
+	ssx_jit::VidTable jit_vid;
+	uint32_t* d_blob_jit = nullptr; uint32_t blob_jit_words = 0, path_blob_jit_words = 0;
+	uint64_t generic_samples = 0;
+	int jit_state = SSX_JIT_STATE_NONE; std::string jit_message;
 	std::vector<uint8_t*> d_textures;
 	float* d_jh_data = nullptr;
 	bool rgb_mode = false;     // scene uploaded with uplift == SSX_MODE_RGB
@@ -132,7 +151,10 @@ void drop_rccl_comm(ssx_ctx* ctx) {
 uint32_t align4(uint32_t words) { return (words + 3u) & ~3u; }
 
 // Packs ssx_scene_desc into the blob layout of ssx_blob.h.
-int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>& d_tex, const float* d_jh, std::vector<uint32_t>& blob) {
+// force_topology: -1 = the built-in topology the scene's sharing pattern matches, else 0 (generic); 3 = the tables of a kernel
+// compiled for the scene's own pattern.  info: what the pattern is (ssx_upload_scene decides about run-time specialisation).
+struct PackInfo { bool candidate = false; ssx_jit::VidTable vid; };
+int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>& d_tex, const float* d_jh, std::vector<uint32_t>& blob, int force_topology = -1, PackInfo* info = nullptr) {
 	if (s->n_quads == 0 || s->n_quads > SSX_MAX_QUADS) return fail(ctx, SSX_ERR_SCENE, fmt("n_quads=%u outside 1..%u", s->n_quads, SSX_MAX_QUADS));
 	if (s->n_lights == 0) return fail(ctx, SSX_ERR_SCENE, "scene has no lights (reference asserts !lights.empty(), scene.cpp:30)");
 	if (s->n_textures > SSX_MAX_TEXTURES) return fail(ctx, SSX_ERR_SCENE, "too many textures");
@@ -211,13 +233,8 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 		if (same) h.topology = t.id;
 	}
 	if (env_on("SSX_GENERIC_KERNEL")) h.topology = 0; // A/B measurements and tests of the generic loop on the built-in scenes
-	else if (h.topology == 0 && topo_candidate && (ctx->jit || env_on("SSX_JIT_PASS1"))) {
-		// no built-in topology: generate and compile pass 1 for this scene's own sharing pattern (csrc/ssx_jit.h)
-		std::string err;
-		ctx->jit_kernels = ssx_jit::get(ctx->device, vid, &err);
-		if (!ctx->jit_kernels) return fail(ctx, SSX_ERR_DEVICE, err);
-		h.topology = 3;
-	}
+	if (info) { info->candidate = topo_candidate && h.topology == 0 && !env_on("SSX_GENERIC_KERNEL"); info->vid = vid; }
+	if (force_topology == 3 && topo_candidate) h.topology = 3; // (the caller holds, or waits for, kernels compiled for this pattern: csrc/ssx_jit.h)
 
 	uint32_t off = (uint32_t)(sizeof(SsxBlobHeader) / 4);
 	h.off_quads = off;     off = align4(off + s->n_quads * (uint32_t)(sizeof(SsxBlobQuad) / 4));
@@ -511,7 +528,7 @@ struct Batch { SsxKernelArgs a; uint32_t units; uint64_t n_rec; hipEvent_t* tev;
 // samples per pixel of a work unit for the uploaded scene (before make_batch halves it for small launches)
 uint32_t unit_spp_of(const ssx_ctx* ctx) {
 	uint32_t g = ctx->calib_frames >= 2.0f ? SSX_MAX_UNIT_KS / 2u : SSX_MAX_UNIT_KS;
-	if (const char* e = getenv("SSX_UNIT_SPP")) { const int v = atoi(e); if (v >= 1 && v <= (int)SSX_MAX_UNIT_KS) g = (uint32_t)v; } // A/B runs
+	if (const char* e = debug_env("SSX_UNIT_SPP")) { const int v = atoi(e); if (v >= 1 && v <= (int)SSX_MAX_UNIT_KS) g = (uint32_t)v; } // A/B runs
 	return g;
 }
 
@@ -658,6 +675,31 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	return SSX_OK;
 }
 
+// A scene that waits for kernels of its own (ssx_upload_scene): are they there?  Called at the start of a render (and between the
+// launches of an asynchronous one), `samples` = what the caller is about to launch.  Ready: the context switches to its second
+// blob and the compiled kernels -- work already queued keeps the first blob, which stays allocated -- ; not asked for yet: the
+// compilation is requested once the generic kernel has served kJitAfterSamples (a test's 8 x 8 image is not worth a core-second
+// of hipRTC; a production render passes the mark in its first launch and has its kernels a second or two later).
+constexpr uint64_t kJitAfterSamples = (uint64_t)32 << 20;
+void maybe_swap_jit(ssx_ctx* ctx, uint64_t samples) {
+	if (!ctx->jit_pending) return;
+	std::string err;
+	const ssx_jit::Kernels* k = nullptr;
+	const ssx_jit::State st = ssx_jit::lookup(ctx->device, ctx->jit_vid, &k, &err);
+	if (st == ssx_jit::State::Ready) {
+		std::swap(ctx->d_blob, ctx->d_blob_jit);
+		ctx->blob_words = ctx->blob_jit_words; ctx->path_blob_words = ctx->path_blob_jit_words;
+		ctx->topology = 3u; ctx->jit_kernels = k;
+		ctx->resident_blocks = 0; ctx->gen_blocks = 0; // the blob's LDS footprint changed
+		ctx->jit_pending = false; ctx->jit_state = SSX_JIT_STATE_SPECIALISED;
+	} else if (st == ssx_jit::State::Failed) {
+		ctx->jit_pending = false; ctx->jit_state = SSX_JIT_STATE_FAILED; ctx->jit_message = err;
+	} else {
+		ctx->generic_samples += samples;
+		if (!ctx->jit_requested && ctx->generic_samples >= kJitAfterSamples) { ssx_jit::request(ctx->jit_vid); ctx->jit_requested = true; }
+	}
+}
+
 // samples [k0, k1) of every owned pixel, in stream order
 int launch_range(ssx_ctx* ctx, LaunchPlan& pl, uint32_t k0, uint32_t k1, hipStream_t stream) {
 	if (pl.args.my_tiles == 0 || k1 <= k0) return SSX_OK;
@@ -704,7 +746,7 @@ int calibrate(ssx_ctx* ctx) {
 	// instructions per 64 samples) and saves, per ray that leaves the scene, the lane-iteration such a ray otherwise idles
 	// through (a trace + a shading, ~2300 per 64 lanes): it pays from ~0.3 such rays per sample (Cornell box: 0.87; plane-srgb: 0).
 	ctx->pre_hits = ctx->calib_left >= 0.3f;
-	if (const char* e = getenv("SSX_PRE_HITS")) ctx->pre_hits = e[0] != '0'; // A/B runs and tests
+	if (const char* e = debug_env("SSX_PRE_HITS")) { if (e[0] != '\0') ctx->pre_hits = e[0] != '0'; } // A/B runs and tests (an empty value changes nothing)
 	ctx->fuse_resolve = true;
 	// the waves' level logs for the unit size this scene renders with: allocated here, once (the device is idle)
 	return ensure_logs(ctx, (unit_spp_of(ctx) + SSX_COHORT_KS - 1u) / SSX_COHORT_KS);
@@ -727,6 +769,7 @@ void worker_main(ssx_ctx* ctx) {
 		SSX_HIP(ctx, hipSetDevice(ctx->device));
 		size_t pixels = (size_t)p.width * p.height;
 		SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, accum_slots(p.width, p.height) * 4 * sizeof(double), ctx->stream));
+		maybe_swap_jit(ctx, 0);
 		LaunchPlan pl = make_plan(ctx, &p);
 		// progress / cancel granularity: 1/32 of the render, but at least ~32 M samples (~20 ms) per launch so
 		// that the synchronisation between launches stays a few percent
@@ -740,6 +783,10 @@ void worker_main(ssx_ctx* ctx) {
 		{ int r = ensure_samples(ctx, pl, chunk < p.spp ? chunk : p.spp); if (r) return r; }
 		for (uint32_t k0 = 0; k0 < p.spp && !ctx->stop_flag.load(); k0 += chunk) {
 			uint32_t k1 = (p.spp - k0 < chunk) ? p.spp : k0 + chunk;
+			if (ctx->jit_pending) { // between launches the device is idle: the kernels may change here (same bits)
+				maybe_swap_jit(ctx, (uint64_t)pixels * (k1 - k0) / p.tile_stride);
+				if (!ctx->jit_pending) { const uint32_t cap = pl.max_spp_per_launch; pl = make_plan(ctx, &p); pl.max_spp_per_launch = cap; }
+			}
 			int r = launch_range(ctx, pl, k0, k1, ctx->stream);
 			if (r) return r;
 			SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -774,9 +821,41 @@ const char* ssx_last_error(const ssx_ctx* ctx) {
 	return c->error_out.c_str();
 }
 
+// The distinct libamdhip64 files mapped into the process ("a, b"): more than one means that somebody -- typically a Python process
+// that loaded this library before torch without going through simple_spectral_amd/_capi.py -- brought a second HIP runtime, and
+// streams / device pointers handed across the C ABI would belong to the other one.
+static int mapped_hip_runtimes(std::string* names) {
+	std::set<std::string> found;
+	if (FILE* f = fopen("/proc/self/maps", "r")) {
+		char line[4352];
+		while (fgets(line, sizeof line, f)) {
+			const char* path = strchr(line, '/');
+			if (!path) continue;
+			const char* base = strrchr(path, '/') + 1;
+			if (strncmp(base, "libamdhip64.so", 14) != 0) continue;
+			std::string p(path);
+			while (!p.empty() && (p.back() == '\n' || p.back() == ' ')) p.pop_back();
+			char real[PATH_MAX];
+			found.insert(realpath(p.c_str(), real) ? std::string(real) : p);
+		}
+		fclose(f);
+	}
+	names->clear();
+	for (const std::string& p : found) { if (!names->empty()) *names += ", "; *names += p; }
+	return (int)found.size();
+}
+
 int ssx_create(int device, ssx_ctx** out) {
 	if (!out) { g_create_error = "out is NULL"; return SSX_ERR_ARG; }
 	*out = nullptr;
+	{
+		std::string names;
+		if (mapped_hip_runtimes(&names) > 1) {
+			g_create_error = "two HIP runtimes are mapped into this process (" + names + "): the hip_stream and device pointers of this interface must belong to "
+			                 "the runtime this library is bound to.  Load one runtime only (Python: import simple_spectral_amd before, or together with, torch)";
+			return SSX_ERR_DEVICE;
+		}
+	}
 	int n = 0;
 	hipError_t e = hipGetDeviceCount(&n);
 	if (e != hipSuccess || n == 0) {
@@ -806,6 +885,7 @@ void ssx_destroy(ssx_ctx* ctx) {
 	if (ctx->worker.joinable()) { ctx->stop_flag.store(1); ctx->worker.join(); }
 	(void)hipSetDevice(ctx->device);
 	if (ctx->d_blob) (void)hipFree(ctx->d_blob);
+	if (ctx->d_blob_jit) (void)hipFree(ctx->d_blob_jit);
 	if (ctx->d_jh_data) (void)hipFree(ctx->d_jh_data);
 	for (uint8_t* t : ctx->d_textures) (void)hipFree(t);
 	if (ctx->d_accum) (void)hipFree(ctx->d_accum);
@@ -885,10 +965,37 @@ int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_jh_data, bytes));
 		SSX_HIP(ctx, hipMemcpy(ctx->d_jh_data, s->jh_data, bytes, hipMemcpyHostToDevice));
 	}
-	std::vector<uint32_t> blob;
+	std::vector<uint32_t> blob, blob_jit;
 	ctx->jit_kernels = nullptr;
-	int rc = pack_blob(ctx, s, ctx->d_textures, ctx->d_jh_data, blob);
+	ctx->jit_pending = ctx->jit_requested = false; ctx->generic_samples = 0; ctx->jit_vid.clear();
+	ctx->jit_state = SSX_JIT_STATE_NONE; ctx->jit_message.clear();
+	if (ctx->d_blob_jit) { (void)hipFree(ctx->d_blob_jit); ctx->d_blob_jit = nullptr; }
+	PackInfo info;
+	int rc = pack_blob(ctx, s, ctx->d_textures, ctx->d_jh_data, blob, -1, &info);
 	if (rc) return rc;
+	// A scene whose corners coincide in no built-in pattern: kernels specialised to ITS pattern (csrc/ssx_jit.h) -- from this
+	// process's memory or the disk cache at once; else compiled here (mode 1) or by the background thread later (mode 2), the
+	// generic kernel serving meanwhile.  A failure of any kind leaves the scene on the generic kernel: same bits.
+	const int jit_mode = env_on("SSX_JIT_PASS1") ? SSX_JIT_AT_UPLOAD : ctx->jit_mode;
+	if (info.candidate && jit_mode != SSX_JIT_OFF) {
+		std::string err;
+		const ssx_jit::Kernels* k = nullptr;
+		ssx_jit::State st = ssx_jit::lookup(ctx->device, info.vid, &k, &err);
+		if (st != ssx_jit::State::Ready && st != ssx_jit::State::Failed && jit_mode == SSX_JIT_AT_UPLOAD) {
+			k = ssx_jit::get(ctx->device, info.vid, &err);
+			st = k ? ssx_jit::State::Ready : ssx_jit::State::Failed;
+		}
+		if (st == ssx_jit::State::Failed) { ctx->jit_state = SSX_JIT_STATE_FAILED; ctx->jit_message = err; }
+		else if ((rc = pack_blob(ctx, s, ctx->d_textures, ctx->d_jh_data, blob_jit, 3, nullptr))) return rc;
+		else if (st == ssx_jit::State::Ready) { blob.swap(blob_jit); blob_jit.clear(); ctx->jit_kernels = k; ctx->jit_state = SSX_JIT_STATE_SPECIALISED; }
+		else { ctx->jit_pending = true; ctx->jit_vid = info.vid; ctx->jit_state = SSX_JIT_STATE_GENERIC_MEANWHILE; ctx->jit_requested = (st == ssx_jit::State::Pending); }
+	}
+	if (ctx->jit_pending) {
+		SSX_HIP(ctx, hipMalloc((void**)&ctx->d_blob_jit, blob_jit.size() * 4));
+		SSX_HIP(ctx, hipMemcpy(ctx->d_blob_jit, blob_jit.data(), blob_jit.size() * 4, hipMemcpyHostToDevice));
+		const SsxBlobHeader* bh = reinterpret_cast<const SsxBlobHeader*>(blob_jit.data());
+		ctx->blob_jit_words = (uint32_t)blob_jit.size(); ctx->path_blob_jit_words = bh->words_without_perm;
+	}
 	if (ctx->d_blob) { (void)hipFree(ctx->d_blob); ctx->d_blob = nullptr; }
 	SSX_HIP(ctx, hipMalloc((void**)&ctx->d_blob, blob.size() * 4));
 	SSX_HIP(ctx, hipMemcpy(ctx->d_blob, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
@@ -934,6 +1041,7 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	}
 	if ((rc = ensure_buffers(ctx, p->width, p->height, false))) return rc;
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, accum_slots(p->width, p->height) * 4 * sizeof(double), stream));
+	maybe_swap_jit(ctx, (uint64_t)p->width * p->height * p->spp / p->tile_stride);
 	LaunchPlan pl = make_plan(ctx, p);
 	// one batch when the whole render fits the buffer budget, else batches back to back
 	uint32_t batch = p->spp_per_launch ? p->spp_per_launch : p->spp;
@@ -1201,10 +1309,30 @@ int ssx_lanestat(unsigned long long* out, int reset) {
 }
 #endif
 
-int ssx_set_jit(ssx_ctx* ctx, int enable) {
-	if (!ctx) return SSX_ERR_ARG;
-	ctx->jit = enable != 0;
+int ssx_set_jit(ssx_ctx* ctx, int mode) {
+	if (!ctx || mode < SSX_JIT_OFF || mode > SSX_JIT_BACKGROUND) return SSX_ERR_ARG;
+	ctx->jit_mode = mode;
 	return SSX_OK;
+}
+
+int ssx_jit_status(ssx_ctx* ctx, int wait_ms, char* message, size_t message_size) {
+	if (!ctx) return SSX_ERR_ARG;
+	if (ctx->rendering.load()) return fail(ctx, SSX_ERR_STATE, "render in progress");
+	if (ctx->jit_pending && wait_ms != 0) {
+		if (hipSetDevice(ctx->device) != hipSuccess) return fail(ctx, SSX_ERR_DEVICE, "hipSetDevice failed");
+		if (!ctx->jit_requested) { ssx_jit::request(ctx->jit_vid); ctx->jit_requested = true; }
+		(void)ssx_jit::wait(ctx->jit_vid, wait_ms < 0 ? 600000 : wait_ms);
+		maybe_swap_jit(ctx, 0);
+	}
+	if (message && message_size) { const size_t n = ctx->jit_message.size() < message_size - 1 ? ctx->jit_message.size() : message_size - 1; memcpy(message, ctx->jit_message.data(), n); message[n] = '\0'; }
+	return ctx->jit_state;
+}
+
+void ssx_jit_counters(uint64_t* compiled, uint64_t* disk_hits) {
+	ssx_jit::Shared& S = ssx_jit::shared();
+	std::lock_guard<std::mutex> g(S.m);
+	if (compiled) *compiled = S.compiled;
+	if (disk_hits) *disk_hits = S.disk_hits;
 }
 
 int ssx_debug_pass1_source(const uint8_t* vid, uint32_t n_quads, const char* name, char* out, size_t out_size) {

@@ -139,7 +139,7 @@ struct SsxBlobTexture { // 4 words: device pointer of the RGB8 texels (rows top 
 #define SSX_MAX_UNIT_KS 8u        // most samples per pixel in a work unit: four cohorts (the host picks 4 or 8 per scene, make_batch)
 #endif
 #define SSX_UNIT_COHORTS (SSX_MAX_UNIT_KS / SSX_COHORT_KS)  // a power of two
-#define SSX_WAVE_COUNTER_WORDS (4u * SSX_UNIT_COHORTS + 4u) // per wave, behind the shadow-ray queues: fill counts [unit tag 2][cohort][fs, nee], then the wave's hand-over word (wave_release / wave_acquire; 3 words of padding)
+#define SSX_WAVE_COUNTER_WORDS (4u * SSX_UNIT_COHORTS + 4u) // per wave, behind the shadow-ray queues: fill counts [unit tag 2][cohort][fs, nee], then the wave's hand-over word (wave_release / wave_acquire); 3 words of padding
 #define SSX_UNIT_PARKED 1u
 #define SSX_UNIT_TURN 2u
 #define SSX_BYTES_PER_SAMPLE (16u + 16u + 16u)         // ray, st, hit
@@ -171,7 +171,7 @@ struct SsxKernelArgs {
 	double* accum;            // per pixel 4 x binary64: the running sums of _render_pixel (renderer.cpp:292-295), continued across launches
 	uint32_t* tile_mask;      // per tile slot 4 words: the primitives a camera ray through the tile can hit (ssx_tile_mask_kernel), for ssx_generate_kernel
 	uint32_t* unit_state;     // per work unit [tile slot][k group] (zeroed before the launch): the hand-over of the ordered pixel sums from unit to
-	                          // unit of a tile -- 0, SSX_UNIT_PARKED (its samples wait in ray[] for the tile's turn to reach them) or
+	                          // unit of a tile -- bits SSX_UNIT_PARKED (its samples wait in ray[] for the tile's turn to reach them) and
 	                          // SSX_UNIT_TURN (everything in front of it has been added): ssx_kernels.hip unit_fold
 	uint32_t no_flat_field;   // 1: flux = radiance * dot(camera_ray_dir, camera.dir) (renderer.cpp:264-265: built without FLAT_FIELD_CORRECTION)
 	uint32_t keep_samples;    // 1: the fold also writes each sample's {X, Y, Z, alpha} to ray[] (ssx_debug_samples)

@@ -1014,7 +1014,11 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	// :178 `if (depth+1u<MAX_DEPTH)`: with ELS a ray at depth MAX_DEPTH-1 is never started (below);
 	// without it that ray exists (its hit may emit) and ends here
 	if (p.depth + 1u >= SSX_MAX_DEPTH_) return false;
-	V3 hit_pos = add(p.orig, scl(p.hit_dist, p.dir)); // Ray::at
+	const V3 hit_pos = add(p.orig, scl(p.hit_dist, p.dir)); // Ray::at
+	// the ray's origin has done its part: the next ray, if there is one, starts here (and a path that ends takes its next origin from
+	// the refill).  Assigned HERE, not where the path continues, so that the old origin does not stay live -- three registers -- through
+	// the light sampling, which runs at the kernel's register limit.
+	p.orig = hit_pos;
 	if (M.albedo_mode != 0u) { SSX_STAT(6); } else { SSX_STAT(7); } // textured / constant albedo
 	// albedo(lambda) is shared by evaluate_bsdf and interact_bsdf (material.cpp:120-143)
 	Hero alb = material_albedo(L, Q, p.hit_st_x, p.hit_st_y, p.lambda_0);
@@ -1102,7 +1106,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	log_link(a, entry) = p.prev_slot | level_word;
 	wave_release(lg.cnt); // publishes this lane's stores of the level to the lane of this wave that will fold them ("Memory-ordering contract")
 	p.prev_slot = slot;
-	p.orig = hit_pos; p.dir = w_i; p.ignore = (int)hq;
+	p.dir = w_i; p.ignore = (int)hq;
 	++p.depth;
 	return true;
 }
@@ -1160,13 +1164,21 @@ __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& 
 #define SSX_RESOLVE_WAYS SSX_COHORT_KS // measured: 4 ways spill 13 VGPRs in the path loop (-1.3 %), 3: +2.4 %, 2: +2.7 % (one box, r02t)
 #endif
 static_assert(SSX_RESOLVE_WAYS == SSX_COHORT_KS, "a pass of the fold takes one cohort");
+// The kernel's arguments once more, for code that runs once per work unit (fold, hand-over, unit set-up): read from the kernarg
+// segment through a pointer the compiler cannot see through, where they are needed -- not kept in SGPRs across the path loop, which
+// has none to spare (every spilled SGPR costs the hot code a v_readlane, and the allocator a VGPR copy of what it cannot keep).
+__device__ __forceinline__ const __attribute__((address_space(4))) SsxKernelArgs& cold_args() {
+	auto p = __builtin_amdgcn_kernarg_segment_ptr();
+	asm volatile("" : "+s"(p));
+	return *(const __attribute__((address_space(4))) SsxKernelArgs*)p;
+}
 // accesses to the pixel sums, which waves on different XCDs hand to each other (unit_fold): performed at the device's point of coherence
 __device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // _render_pixel (renderer.cpp:292-295): avg += sample * 0.001f -- a float multiply of all four components, widened, added in
 // binary64; RENDER_MODE_RGB (:301-303) adds the sample as it is
-__device__ __forceinline__ void add_sample(const SsxKernelArgs& a, double acc[4], float x, float y, float z, float alpha) {
-	if (a.rgb_mode) { acc[0] += (double)x; acc[1] += (double)y; acc[2] += (double)z; acc[3] += (double)alpha; }
+__device__ __forceinline__ void add_sample(bool rgb_mode, double acc[4], float x, float y, float z, float alpha) {
+	if (rgb_mode) { acc[0] += (double)x; acc[1] += (double)y; acc[2] += (double)z; acc[3] += (double)alpha; }
 	else { acc[0] += (double)(x * 0.001f); acc[1] += (double)(y * 0.001f); acc[2] += (double)(z * 0.001f); acc[3] += (double)(alpha * 0.001f); }
 }
 // a sample {X, Y, Z, alpha} parked in its ray[] record until its tile's turn reaches it, and fetched from there (device scope, two 8-byte accesses)
@@ -1175,10 +1187,10 @@ __device__ __forceinline__ void stage_sample(float4* rec, float x, float y, floa
 	__hip_atomic_store(q, (uint64_t)__float_as_uint(x) | ((uint64_t)__float_as_uint(y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	__hip_atomic_store(q + 1, (uint64_t)__float_as_uint(z) | ((uint64_t)__float_as_uint(alpha) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void add_staged_sample(const SsxKernelArgs& a, double acc[4], const float4* rec) {
+__device__ __forceinline__ void add_staged_sample(bool rgb_mode, double acc[4], const float4* rec) {
 	const uint64_t* const q = reinterpret_cast<const uint64_t*>(rec);
 	const uint64_t lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	add_sample(a, acc, __uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi), __uint_as_float((uint32_t)(hi >> 32)));
+	add_sample(rgb_mode, acc, __uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi), __uint_as_float((uint32_t)(hi >> 32)));
 }
 // a level's next-event term where the level parked a shadow ray, else 0: nee[i] as the flush wrote it (wide queue
 // entries), or vis ? nee : 0 (narrow entries; both loads in flight together)
@@ -1253,11 +1265,13 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 				rad[s][3] = D[s].w + ssx_exact::div64_by((rad[s][3] * NP[s].x) * F[s].w, pdf_recip);
 			}
 	}
+	const __attribute__((address_space(4))) SsxKernelArgs& c = cold_args(); // (the render's switches: read where they are needed, once per pass)
+	const bool rgb_mode = c.rgb_mode != 0u, keep_samples = c.keep_samples != 0u, no_flat_field = c.no_flat_field != 0u;
 #pragma unroll
 	for (uint32_t s = 0; s < WAYS; ++s)
 		if (s < count) {
 			SSX_STAT(15); // flux -> XYZ
-			if (a.no_flat_field) { // renderer.cpp:264-265 (built without FLAT_FIELD_CORRECTION): pixel_rad_est * glm::dot(camera_ray_dir, camera.dir)
+			if (no_flat_field) { // renderer.cpp:264-265 (built without FLAT_FIELD_CORRECTION): pixel_rad_est * glm::dot(camera_ray_dir, camera.dir)
 				const float4 cr = a.ray[r0 + s * stride]; // {camera ray dir, lambda_0}: still what the generate kernel wrote
 				const SsxBlobHeader& hh = L.hdr();
 				const float d = dot3(mk(cr.x, cr.y, cr.z), mk(hh.cam_dir[0], hh.cam_dir[1], hh.cam_dir[2]));
@@ -1265,7 +1279,7 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 			}
 			Hero flux; flux.v[0] = rad[s][0]; flux.v[1] = rad[s][1]; flux.v[2] = rad[s][2]; flux.v[3] = rad[s][3];
 			float xyz[3];
-			if (a.rgb_mode) { xyz[0] = rad[s][0]; xyz[1] = rad[s][1]; xyz[2] = rad[s][2]; } // renderer.cpp:274-276: lRGB_A_F32(pixel_flux_est, hit)
+			if (rgb_mode) { xyz[0] = rad[s][0]; xyz[1] = rad[s][1]; xyz[2] = rad[s][2]; } // renderer.cpp:274-276: lRGB_A_F32(pixel_flux_est, hit)
 			else flux_to_xyz(L, flux, __uint_as_float(a.st[r0 + s * stride].x), xyz); // lambda_0 (re-read: a register per way less across the chain walk)
 			const float alpha = (depth[s] >> 4) ? 1.0f : 0.0f;
 			// _render_pixel (renderer.cpp:292-295) adds a pixel's samples in ascending k: the ways are consecutive k, the passes of a
@@ -1274,8 +1288,8 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 			// scope, the wave that adds it may sit behind another XCD's L2 -- for the wave whose turn reaches it.
 			if (stage) stage_sample(a.ray + (r0 + s * stride), xyz[0], xyz[1], xyz[2], alpha);
 			else {
-				add_sample(a, acc, xyz[0], xyz[1], xyz[2], alpha);
-				if (a.keep_samples) a.ray[r0 + s * stride] = make_float4(xyz[0], xyz[1], xyz[2], alpha); // ssx_debug_samples: what _render_sample returns
+				add_sample(rgb_mode, acc, xyz[0], xyz[1], xyz[2], alpha);
+				if (keep_samples) a.ray[r0 + s * stride] = make_float4(xyz[0], xyz[1], xyz[2], alpha); // ssx_debug_samples: what _render_sample returns
 			}
 		}
 }
@@ -1411,7 +1425,9 @@ struct WorkUnit { // wave-uniform description of one work unit: 8x8 tile x a gro
 	__device__ __forceinline__ uint32_t k_off(const SsxKernelArgs& a) const { return grp * a.group_spp; }
 	__device__ __forceinline__ uint32_t rec_base(const SsxKernelArgs& a) const { return (slot * (a.k1 - a.k0) + grp * a.group_spp) * 64u; }
 };
-__device__ __forceinline__ void unit_setup(const SsxKernelArgs& a, uint32_t unit, WorkUnit& u) {
+__device__ __forceinline__ void unit_setup(const SsxKernelArgs& hot, uint32_t unit, WorkUnit& u) {
+	(void)hot;
+	const __attribute__((address_space(4))) SsxKernelArgs& a = cold_args();
 	const uint32_t slot = unit % a.my_tiles, grp = unit / a.my_tiles;
 	const uint32_t tile = a.tile_first + slot * a.tile_stride;
 	const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
@@ -1428,27 +1444,30 @@ __device__ __forceinline__ void unit_setup(const SsxKernelArgs& a, uint32_t unit
 // The pixel sums (renderer.cpp:292-295: binary64, samples added in ascending k -- binary64 addition is not associative, so the
 // order is part of the result) are kept in a.accum and continued here.  A tile's units -- consecutive groups of k, folded by
 // whichever waves took them, finishing in any order -- are added in k order WITHOUT ANY WAVE WAITING FOR ANOTHER.  One word per
-// unit, a.unit_state[tile slot][k group] (zeroed before the launch), carries the hand-over:
-//   * SSX_UNIT_TURN: everything in front of the unit has been added.  A unit that finds its word so (or is its tile's first of
-//     the launch) loads the sums, adds its samples as it folds them, and stores the sums.
+// unit, a.unit_state[tile slot][k group] (zeroed before the launch), carries the hand-over; its two bits only ever get set:
+//   * SSX_UNIT_TURN: everything in front of the unit has been added.  A unit that finds the bit (or is its tile's first of the
+//     launch) loads the sums, adds its samples as it folds them, and stores the sums.
 //   * A unit whose turn has not come folds all the same, but parks its samples {X, Y, Z, alpha} in their ray[] records (16 bytes
-//     per sample, dead by then) and then swaps its word 0 -> SSX_UNIT_PARKED; its wave goes on with its next unit.
-//   * Whoever has added a unit EXCHANGES the word of the unit behind it for SSX_UNIT_TURN.  If that returns SSX_UNIT_PARKED,
-//     the unit behind is waiting: the wave adds its parked samples too -- 16 bytes and four additions per sample, a tenth of a
-//     fold -- and goes on down the tile's chain the same way.  If it returns 0, the unit behind is still running and will find
-//     its turn has come.  A unit whose compare-and-swap to PARKED fails has been given the turn in the meantime: it adds its own
-//     parked samples and carries on as above.
-//   Every hand-over is ONE atomic read-modify-write of ONE word, so exactly one of the two waves involved adds the unit.
+//     per sample, dead by then) and then marks itself: compare-and-swap 0 -> SSX_UNIT_PARKED.  Its wave goes on with its next unit.
+//   * Whoever has added a unit sets SSX_UNIT_TURN in the word of the unit behind it (atomic OR).
+//   * Both read-modify-writes return what the word was, and one word orders them:
+//       the OR finds PARKED     the mark was first: the unit waits parked, and the wave that gives the turn adds its samples too --
+//                               16 bytes and four additions per sample, a tenth of a fold -- and goes on down the tile's chain;
+//       the swap finds TURN     the turn was first (the swap fails): the unit adds its own parked samples and goes on as above;
+//       the swap finds 0        parked: the turn will come, with somebody who adds.
+//     So every unit is added exactly once, by one of the two waves involved.
 // (Rounds 1-3 let a unit spin until its turn came.  With one GPU's 4096 tiles at most two units of a tile are in flight and the
 // spin was rare; a rank of an 8-GPU render owns 512 tiles at 8 x the samples per pixel, sixteen units of every tile are in flight
-// at once, and sixteen waves stood still behind every late one: -17 % there, tools/rank_share.py, profiles/r04/rank_share.log.)
+// at once, and sixteen waves stood still behind every late one: -17 % there, tools/rank_share.py, profiles/r04/rank_share.log.
+// Not waiting for the read-modify-write either -- the word read back into LDS by global_load_lds and looked at an iteration
+// later -- was built and measured: no gain, profiles/r04/NOTES.md.)
 // Memory ordering: accum, unit_state and the parked samples are touched only with agent-scope atomics (performed at the
 // device's point of coherence, whichever XCD's L2 the waves sit behind).  Default build: relaxed atomics, and "the data is in
 // place before the word that announces it" is a wait for the wave's outstanding vector-memory operations (s_waitcnt vmcnt(0):
 // device-scope stores are acknowledged from the point of coherence) -- below the HIP memory model, validated on gfx950 with the
 // toolchains simple_spectral_amd/build.py lists.  -DSSX_ACCUM_FORMAL expresses the same protocol in the model (acquire /
-// release agent-scope atomics on the word, the other lanes' accesses chained to lane 0's through the wave's hand-over word):
-// the compiler then writes back and invalidates the XCD's L2 around every fold (-25 %); tools/test_kernel_variants.sh runs the
+// release agent-scope read-modify-writes; the other lanes' accesses chained to lane 0's through the wave's hand-over word): the
+// compiler then writes back and invalidates the XCD's L2 around every fold (-25 %); tools/test_kernel_variants.sh runs the
 // parity suites on that build too, so the default build is continuously compared with it.
 // "everything this wave has stored is in place": before the word that announces it is written
 __device__ __forceinline__ void sums_release(uint32_t* cnt) {
@@ -1478,6 +1497,34 @@ __device__ __forceinline__ void sums_acquire(uint32_t* cnt) {
 #define SSX_SUMS_ACQ __ATOMIC_RELAXED
 #define SSX_SUMS_ACQ_REL __ATOMIC_RELAXED
 #endif
+// The unit (slot, grp) has the turn and its samples are parked, and nobody else will add them: add them, give the turn to the unit
+// behind, and go on while that one is parked too.
+__device__ __forceinline__ void sums_chain(uint32_t slot, uint32_t grp, uint32_t lane, uint32_t* cnt) {
+	const __attribute__((address_space(4))) SsxKernelArgs& a = cold_args();
+	const uint32_t tile = a.tile_first + slot * a.tile_stride, tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+	const bool has_px = (lane & 7u) < min(8u, a.width - tx * 8u) && (lane >> 3) < min(8u, a.height - ty * 8u);
+	double* const px = a.accum + (size_t)tile * 256u + lane;
+	uint32_t* state = a.unit_state + (slot * a.n_groups + grp);
+	uint32_t rec_at = (slot * (a.k1 - a.k0) + grp * a.group_spp) * 64u;
+	double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+	if (has_px) { acc[0] = ld_agent(px); acc[1] = ld_agent(px + 64); acc[2] = ld_agent(px + 128); acc[3] = ld_agent(px + 192); }
+	for (;;) {
+		const uint32_t n = min(a.group_spp, (a.k1 - a.k0) - grp * a.group_spp);
+		if (has_px) {
+			for (uint32_t kq = 0; kq < n; ++kq) add_staged_sample(a.rgb_mode != 0u, acc, a.ray + (rec_at + kq * 64u + lane));
+			st_agent(px, acc[0]); st_agent(px + 64, acc[1]); st_agent(px + 128, acc[2]); st_agent(px + 192, acc[3]);
+		}
+		if (++grp >= a.n_groups) return; // that was the tile's last unit of the launch
+		sums_release(cnt); // the sums are in place before the unit behind is given the turn
+		++state; rec_at += a.group_spp * 64u;
+		uint32_t was = 0u;
+		if (lane == 0u) was = __hip_atomic_fetch_or(state, SSX_UNIT_TURN, SSX_SUMS_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		was = (uint32_t)__builtin_amdgcn_readfirstlane((int)was);
+		sums_acquire(cnt);
+		if (was != SSX_UNIT_PARKED) return; // still running: it will find its turn has come
+		if (lane == 0u) atomicAdd(a.unit_counter + 3, 1u); // statistics (ssx_sums_info): parked units added by the wave in front of them
+	}
+}
 template <bool NARROW>
 __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, const WorkUnit& u, uint32_t wave_slot, uint32_t tag, uint32_t* cnt) {
 	// see "Memory-ordering contract" above: the acquire side of the wave's hand-over; then wait for this wave's stores and
@@ -1487,57 +1534,47 @@ __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, 
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 	const uint32_t lane = threadIdx.x & 63u;
 	const bool has_px = (lane & 7u) < u.tw() && (lane >> 3) < u.th();
-	uint32_t* state = a.unit_state + (u.slot * a.n_groups + u.grp); // this unit's word; the chain below moves on to the units behind it
-	double* const px = a.accum + (size_t)u.tile * 256u + lane; // [tile][component][pixel of the tile]: components 64 doubles apart
+	const __attribute__((address_space(4))) SsxKernelArgs& c = cold_args();
+	uint32_t* const state = c.unit_state + (u.slot * c.n_groups + u.grp); // this unit's word
+	double* const px = c.accum + (size_t)u.tile * 256u + lane; // [tile][component][pixel of the tile]: components 64 doubles apart
 	// this unit's turn in the tile's k order?  (The tile's first unit of the launch need not look.)
 	bool mine = true;
 	if (u.grp) {
-		mine = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(state, SSX_SUMS_ACQ, __HIP_MEMORY_SCOPE_AGENT)) == SSX_UNIT_TURN;
+		mine = ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(state, SSX_SUMS_ACQ, __HIP_MEMORY_SCOPE_AGENT)) & SSX_UNIT_TURN) != 0u;
 		sums_acquire(cnt);
 	}
-	double acc[4] = { 0.0, 0.0, 0.0, 0.0 }; // the pixel's running sums: in registers across the unit's passes (per pass: 0.6 % slower) and down the chain
+	double acc[4] = { 0.0, 0.0, 0.0, 0.0 }; // the pixel's running sums: in registers across the unit's passes (per pass: 0.6 % slower)
 	if (mine && has_px) { acc[0] = ld_agent(px); acc[1] = ld_agent(px + 64); acc[2] = ld_agent(px + 128); acc[3] = ld_agent(px + 192); }
 	if (has_px)
 		for (uint32_t kq = 0, n_kq = u.n_kq(), rec_base = u.rec_base(a); kq < n_kq; kq += SSX_RESOLVE_WAYS) { // one cohort per pass
 			const uint32_t log_rec = log_region(a, wave_slot, tag, kq / SSX_COHORT_KS);
 			resolve_records<SSX_RESOLVE_WAYS, NARROW>(L, a, rec_base + kq * 64u + lane, 64u, min(SSX_RESOLVE_WAYS, n_kq - kq), log_rec * SSX_MAX_FRAMES, log_rec * SSX_MAX_LEVELS, lane, acc, !mine);
 		}
-	// (rec_at, grp): the unit whose samples are in acc or about to be -- this one, then the units behind it this wave takes over
-	uint32_t rec_at = u.rec_base(a), grp = u.grp;
-	bool parked = !mine; // its samples are still to be added from their ray[] records (this wave's own unit, folded in turn, is in acc already)
-	if (!mine) {
-		// the samples are parked: say so -- unless the turn has come in the meantime
+	if (mine) {
+		if (has_px) { st_agent(px, acc[0]); st_agent(px + 64, acc[1]); st_agent(px + 128, acc[2]); st_agent(px + 192, acc[3]); }
+		if (u.grp + 1u >= c.n_groups) return; // that was the tile's last unit of the launch
+		// the sums are in place before the unit behind is given the turn; if that one waits parked, its samples are this wave's to add
+		sums_release(cnt);
+		uint32_t was = 0u;
+		if (lane == 0u) was = __hip_atomic_fetch_or(state + 1, SSX_UNIT_TURN, SSX_SUMS_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		was = (uint32_t)__builtin_amdgcn_readfirstlane((int)was);
+		sums_acquire(cnt);
+		if (was != SSX_UNIT_PARKED) return;
+		if (lane == 0u) atomicAdd(c.unit_counter + 3, 1u); // statistics (ssx_sums_info): parked units added by the wave in front of them
+		sums_chain(u.slot, u.grp + 1u, lane, cnt);
+	} else {
+		// the samples are parked: say so -- unless the turn has come in the meantime: then nobody else will add them
 		sums_release(cnt);
 		uint32_t was = 0u;
 		if (lane == 0u) {
-			atomicAdd(a.unit_counter + 2, 1u); // statistics (ssx_sums_info): units parked
+			atomicAdd(c.unit_counter + 2, 1u); // statistics: units parked
 			uint32_t expected = 0u;
 			(void)__hip_atomic_compare_exchange_strong(state, &expected, SSX_UNIT_PARKED, SSX_SUMS_ACQ_REL, SSX_SUMS_ACQ, __HIP_MEMORY_SCOPE_AGENT);
 			was = expected;
 		}
 		was = (uint32_t)__builtin_amdgcn_readfirstlane((int)was);
 		sums_acquire(cnt);
-		if (was != SSX_UNIT_TURN) return; // the wave that adds the unit in front will find this one parked
-		// the turn has come and nobody will take the unit: its samples are added from where they are parked, like anyone else's
-		if (has_px) { acc[0] = ld_agent(px); acc[1] = ld_agent(px + 64); acc[2] = ld_agent(px + 128); acc[3] = ld_agent(px + 192); }
-	}
-	for (;;) {
-		const uint32_t k_at = grp * a.group_spp, n = min(a.group_spp, (a.k1 - a.k0) - k_at);
-		if (has_px) {
-			if (parked) for (uint32_t kq = 0; kq < n; ++kq) add_staged_sample(a, acc, a.ray + (rec_at + kq * 64u + lane));
-			st_agent(px, acc[0]); st_agent(px + 64, acc[1]); st_agent(px + 128, acc[2]); st_agent(px + 192, acc[3]);
-		}
-		if (++grp >= a.n_groups) return; // that was the tile's last unit of the launch
-		// the sums are in place before the unit behind is given the turn
-		sums_release(cnt);
-		uint32_t was = 0u;
-		++state;
-		if (lane == 0u) was = __hip_atomic_exchange(state, SSX_UNIT_TURN, SSX_SUMS_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-		was = (uint32_t)__builtin_amdgcn_readfirstlane((int)was);
-		sums_acquire(cnt);
-		if (was != SSX_UNIT_PARKED) return; // still running: it will find its turn has come
-		if (lane == 0u) atomicAdd(a.unit_counter + 3, 1u); // statistics: parked units added by the wave in front of them
-		rec_at += a.group_spp * 64u; parked = true;
+		if (was == SSX_UNIT_TURN) sums_chain(u.slot, u.grp, lane, cnt);
 	}
 }
 
@@ -1549,13 +1586,12 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 
 	const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u; // (wave: an SGPR, and with it everything derived from it)
 	const uint32_t wave_slot = blockIdx.x * 4u + wave; // this wave's place in the persistent grid: owner of a region of the level logs
-	const uint32_t total_units = a.my_tiles * a.n_groups;
 	// the camera position from the blob's copy in HBM: wave-uniform scalar loads (SGPRs; LDS reads would hold three VGPRs for the whole kernel)
 	const SsxBlobHeader& hg = *reinterpret_cast<const SsxBlobHeader*>(a.blob);
 	const V3 cam = mk(hg.cam_pos[0], hg.cam_pos[1], hg.cam_pos[2]);
 
 	Path p;
-	p.orig = cam; p.dir = mk(0.0f, 0.0f, 1.0f); p.ignore = -1; p.depth = 0; p.rec_index = 0; p.lambda_0 = 0.0f; p.prev_slot = SSX_NO_SLOT;
+	p.orig = mk(0.0f, 0.0f, 0.0f); p.dir = mk(0.0f, 0.0f, 1.0f); p.ignore = -1; p.depth = 0; p.rec_index = 0; p.lambda_0 = 0.0f; p.prev_slot = SSX_NO_SLOT;
 	p.hit_tri = 0; p.hit_dist = 0.0f; p.hit_st_x = p.hit_st_y = 0.0f;
 	p.rng.state = 0; p.rng.inc = 1;
 	bool active = false;
@@ -1646,10 +1682,11 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			cur_valid = false;
 		}
 		if (!cur_valid && more) {
+			const __attribute__((address_space(4))) SsxKernelArgs& c = cold_args(); // (once per unit: not worth SGPRs across the loop)
 			uint32_t u = 0;
-			if (lane == 0u) u = atomicAdd(a.unit_counter, 1u);
+			if (lane == 0u) u = atomicAdd(c.unit_counter, 1u);
 			u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
-			if (u < total_units) {
+			if (u < c.my_tiles * c.n_groups) {
 				unit_setup(a, u, cur); cur_tag ^= 1u; next_item = 0; cur_valid = true;
 				if (lane < 2u * SSX_UNIT_COHORTS) log_cnt[2u * SSX_UNIT_COHORTS * cur_tag + lane] = 0u; // the logs of its cohorts are empty (the last unit with this tag has been folded)
 			}

@@ -49,6 +49,9 @@ struct Renderer::Api {
 			if (!p) throw HostError{ SSX_ERR_DEVICE, std::string("libssx_hip.so lacks symbol ") + name };
 			return p;
 		};
+		// one interface version on both sides of the boundary (include/ssx.h: what changed between versions)
+		const int abi = reinterpret_cast<int (*)(void)>(sym("ssx_abi_version"))();
+		if (abi != SSX_ABI_VERSION) throw HostError{ SSX_ERR_DEVICE, "libssx_hip.so implements ABI version " + std::to_string(abi) + ", this host was built against version " + std::to_string(SSX_ABI_VERSION) + " (include/ssx.h)" };
 		create = reinterpret_cast<decltype(create)>(sym("ssx_create"));
 		destroy = reinterpret_cast<decltype(destroy)>(sym("ssx_destroy"));
 		upload_scene = reinterpret_cast<decltype(upload_scene)>(sym("ssx_upload_scene"));

@@ -50,7 +50,9 @@ class Options:
     meng_grid_path: Optional[str] = None  # "SSXMENG1" file converted from the authors' header (simple_spectral_amd/meng.py)
     jh_res: int = 64                     # resolution of the fitted JH model when no coefficient file exists
     jh_coeff_path: Optional[str] = None  # data/jakob-and-hanika-2019-srgb.coeff in the reference (missing blob)
-    jit_pass1: bool = False              # ssx_set_jit: compile pass 1 for the mesh topology of scenes that match no built-in one (hipRTC, ~5 s)
+    jit_pass1: Optional[bool] = None     # ssx_set_jit: kernels compiled for the mesh topology of a scene that matches no built-in one (hipRTC).
+    #                                       None: in the background, when the scene has rendered enough (the library's default);
+    #                                       True: at upload, on the calling thread; False: never (generic kernel)
     device: int = 0
     tile_first: int = 0
     tile_stride: int = 1
@@ -154,8 +156,8 @@ class Renderer:
         rc = self._lib.ssx_create(options.device, C.byref(self._ctx))
         if rc != 0:
             raise SsxError(rc, self._lib.ssx_last_error(None).decode())
-        if options.jit_pass1:
-            self._check(self._lib.ssx_set_jit(self._ctx, 1))
+        if options.jit_pass1 is not None:
+            self._check(self._lib.ssx_set_jit(self._ctx, _capi.SSX_JIT_AT_UPLOAD if options.jit_pass1 else _capi.SSX_JIT_OFF))
         self._check(self._lib.ssx_upload_scene(self._ctx, self.scene.desc))
         W, H = options.res
         self.xyza = np.zeros((H, W, 4), dtype=np.float32)
@@ -209,8 +211,18 @@ class Renderer:
         p = self.params(**over)
         self._check(self._lib.ssx_render_device(self._ctx, C.byref(p), C.c_void_p(d_ptr), C.c_void_p(stream)))
 
-    def set_jit(self, enable=True):
-        self._check(self._lib.ssx_set_jit(self._ctx, int(enable)))
+    def set_jit(self, mode=_capi.SSX_JIT_AT_UPLOAD):
+        """ssx_set_jit: SSX_JIT_OFF / SSX_JIT_AT_UPLOAD / SSX_JIT_BACKGROUND (True / False: at upload / off)."""
+        self._check(self._lib.ssx_set_jit(self._ctx, int(mode)))
+
+    def jit_status(self, wait_ms=0):
+        """ssx_jit_status -> (state, message): SSX_JIT_STATE_NONE / _GENERIC_MEANWHILE / _SPECIALISED / _FAILED.  wait_ms != 0 asks
+        for the compilation now and waits for it (< 0: until done)."""
+        buf = C.create_string_buffer(1024)
+        st = self._lib.ssx_jit_status(self._ctx, int(wait_ms), buf, len(buf))
+        if st < -1:
+            self._check(st)
+        return st, buf.value.decode(errors="replace")
 
     def upload_scene_desc(self, desc):
         """Replace the scene by an arbitrary ssx_scene_desc (the flat description the C ABI takes)."""

@@ -27,11 +27,5 @@ def have_gpu():
     return _have_gpu()
 
 
-@pytest.fixture(scope="session", autouse=True)
-def _torch_hip_runtime_first():
-    """torch bundles its own libamdhip64; when a GPU is present initialise it before
-    libssx_hip.so (which links /opt/rocm's) creates its contexts, the order bench.py uses too."""
-    if _have_gpu():
-        import torch
-        torch.cuda.init()
-    yield
+# (No "torch first" fixture any more: simple_spectral_amd/_capi.py puts ONE HIP runtime into the process whatever the import order,
+# and ssx_create refuses to run with two -- tests/test_host_and_abi.py::test_one_hip_runtime_whatever_the_import_order.)

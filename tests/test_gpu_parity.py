@@ -30,7 +30,7 @@ def bits(a):
 
 def test_hip_library_is_the_one_running():
     lib = _capi.hip_lib()
-    assert lib.ssx_abi_version() == 1
+    assert lib.ssx_abi_version() == _capi.SSX_ABI_VERSION == 2
     _, r = gpu_render(scene_name="cornell", res=(16, 16), spp=1)
     info = r.kernel_info()
     assert info["vgprs"] > 0 and info["lds_bytes"] > 4096  # the scene blob is staged in LDS
@@ -427,7 +427,7 @@ def test_camera_rays_pretraced_where_rays_leave_the_scene():
     info = Renderer(Options(scene_name="plane-srgb", res=(8, 8), spp=1, texture="test-img.png")).plan_info()
     assert info["camera_rays"] == "path loop" and info["rays_left_per_sample"] < 0.05
     for mode in ("0", "1"):
-        env = dict(os.environ, SSX_PRE_HITS=mode)
+        env = dict(os.environ, SSX_DEBUG_ENV="1", SSX_PRE_HITS=mode)
         out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
                               "bit_exact_against_oracle or config1 or launch_chunking or per_sample or without_explicit or mirror"], env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
         assert out.returncode == 0, out.stdout[-3000:]
@@ -514,7 +514,7 @@ def test_pass1_variants_specialised_for_builtin_topologies_generic_otherwise():
     r.xyza = np.zeros((32, 40, 4), dtype=np.float32)
     r.render_start(); r.render_wait()
     assert np.array_equal(bits(r.xyza), bits(orc.render(40, 32, 4, seed=3)))
-    env = dict(os.environ, SSX_GENERIC_KERNEL="1")
+    env = dict(os.environ, SSX_DEBUG_ENV="1", SSX_GENERIC_KERNEL="1")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
                           "bit_exact_against_oracle or config1 or many_units or jakob_hanika_uplift"], env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
     assert out.returncode == 0, out.stdout[-3000:]
@@ -564,6 +564,104 @@ def test_pass1_compiled_at_upload_for_any_topology():
     assert rt.plan_info()["pass1"] == "generic"
 
 
+_JIT_CHILD = r"""
+import os, sys, time, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import ctypes as C
+import numpy as np
+import custom_scene as cs
+from simple_spectral_amd import Options, Renderer, _capi
+c = cs.CustomScene("cornell-srgb")
+pos, st, m = c.quads[1]; pos = pos.copy(); pos[2, 1] += 0.5; c.quads[1] = (pos, st, m)
+orc = c.oracle()
+r = Renderer(Options(scene_name="cornell-srgb", res=(40, 32), spp=4, seed=3, texture="test-img.png"))
+t = time.time(); r.upload_scene_desc(c.desc(orc)); up = time.time() - t
+state, msg = r.jit_status()
+a, b = C.c_uint64(), C.c_uint64(); _capi.hip_lib().ssx_jit_counters(C.byref(a), C.byref(b))
+r.render_start(); r.render_wait()
+same = bool(np.array_equal(r.xyza.view(np.uint32), orc.render(40, 32, 4, seed=3).view(np.uint32)))
+print(json.dumps({"state": state, "msg": msg, "compiled": a.value, "disk_hits": b.value, "upload_s": up, "kernel": r.plan_info()["kernel"], "same": same}))
+"""
+
+
+def test_pass1_compiled_in_the_background_and_kept_on_disk(tmp_path):
+    """the specialisation of pass 1 to a scene's own mesh topology is ON by default and costs the caller nothing.
+    A scene that matches no built-in pattern starts on the generic kernel at once; the compilation runs on a background thread once
+    the scene has rendered enough (or is asked for through ssx_jit_status), the context switches kernels at the start of a later
+    render -- same bits before and after -- and the code object goes to the disk cache, from which a second PROCESS starts
+    specialised without compiling.  A damaged cache file is ignored; a failing compiler leaves the generic kernel in place."""
+    import json, subprocess, sys, time
+    import torch
+    import custom_scene as cs
+    cache = tmp_path / "cache"
+    old = os.environ.get("SSX_CACHE_DIR")
+    os.environ["SSX_CACHE_DIR"] = str(cache)
+    try:
+        lib = _capi.hip_lib()
+        counters = lambda: (lambda a, b: (lib.ssx_jit_counters(C.byref(a), C.byref(b)), (a.value, b.value))[1])(C.c_uint64(), C.c_uint64())
+        c = cs.CustomScene("cornell-srgb")
+        pos, st, m = c.quads[1]
+        pos = pos.copy(); pos[2, 1] += 0.5                  # a pattern no other test compiles (the in-memory cache is per process)
+        c.quads[1] = (pos, st, m)
+        orc = c.oracle()
+        r = Renderer(Options(scene_name="cornell-srgb", res=(40, 32), spp=4, seed=3, texture="test-img.png"))
+        compiled0, hits0 = counters()
+        t = time.time(); r.upload_scene_desc(c.desc(orc)); upload = time.time() - t
+        assert r.jit_status()[0] == _capi.SSX_JIT_STATE_GENERIC_MEANWHILE and r.plan_info()["pass1"] == "generic"
+        ref = orc.render(40, 32, 4, seed=3)
+        r.render_start(); r.render_wait()
+        assert np.array_equal(bits(r.xyza), bits(ref))
+        assert counters() == (compiled0, hits0) and not cache.exists()       # 5120 samples: nobody asked the compiler
+        # a render large enough asks for it (32 M samples on the generic kernel); it arrives a second or two later
+        out = torch.zeros((512, 512, 4), device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        r.render_device(out.data_ptr(), stream, width=512, height=512, spp=128)
+        small = torch.zeros((32, 40, 4), device="cuda")
+        t0 = time.time()
+        while r.jit_status()[0] == _capi.SSX_JIT_STATE_GENERIC_MEANWHILE and time.time() - t0 < 120:
+            r.render_device(small.data_ptr(), stream)                          # every render polls; this one also checks the bits
+            torch.cuda.synchronize()
+            assert np.array_equal(bits(small.cpu().numpy()), bits(ref))
+            time.sleep(0.05)
+        waited = time.time() - t0
+        assert r.jit_status() == (_capi.SSX_JIT_STATE_SPECIALISED, ""), (r.jit_status(), waited)
+        assert r.plan_info()["kernel"] == "ssx_render_kernel_jit" and counters() == (compiled0 + 1, hits0)
+        r.render_device(small.data_ptr(), stream); torch.cuda.synchronize()
+        assert np.array_equal(bits(small.cpu().numpy()), bits(ref))
+        files = sorted(cache.glob("pass1-*.co"))
+        assert len(files) == 1 and files[0].stat().st_size > 20000
+        # a second process: specialised straight from the upload, nothing compiled
+        child = _JIT_CHILD % {"root": os.path.dirname(HERE)}
+        run = lambda **env: json.loads(subprocess.run([sys.executable, "-c", child], env=dict(os.environ, **env), capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+        second = run()
+        assert second["state"] == _capi.SSX_JIT_STATE_SPECIALISED and second["compiled"] == 0 and second["disk_hits"] == 1 and second["same"] and second["kernel"] == "ssx_render_kernel_jit", second
+        assert second["upload_s"] < upload + 0.25, (second, upload)         # (both uploads include the calibration render; tools/jit_rate.py has the numbers)
+        # a damaged file is not trusted
+        data = files[0].read_bytes()
+        files[0].write_bytes(data[:len(data) // 2])
+        third = run()
+        assert third["state"] == _capi.SSX_JIT_STATE_GENERIC_MEANWHILE and third["disk_hits"] == 0 and third["same"], third
+        files[0].write_bytes(data[:-9] + bytes([data[-9] ^ 1]) + data[-8:])  # one payload bit flipped: the checksum says no
+        assert run()["state"] == _capi.SSX_JIT_STATE_GENERIC_MEANWHILE
+        # a compiler that fails (here: told to) leaves the scene on the generic kernel, with the reason
+        files[0].unlink()
+        failing = "import os; os.environ['SSX_DEBUG_ENV'] = '1'; os.environ['SSX_JIT_FAIL'] = '1'\n" + child.replace("state, msg = r.jit_status()", "state, msg = r.jit_status(-1)")
+        out = json.loads(subprocess.run([sys.executable, "-c", failing], env=dict(os.environ), capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+        assert out["state"] == _capi.SSX_JIT_STATE_FAILED and "SSX_JIT_FAIL" in out["msg"] and out["same"] and out["kernel"] == "ssx_render_kernel", out
+        # ... also when the caller wanted the compilation at upload (ADVICE r03: this used to fail the upload)
+        atup = failing.replace('texture="test-img.png"))', 'texture="test-img.png", jit_pass1=True))')
+        out = json.loads(subprocess.run([sys.executable, "-c", atup], env=dict(os.environ), capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+        assert out["state"] == _capi.SSX_JIT_STATE_FAILED and out["same"], out
+        # no cache directory at all: the code lives in the process only
+        nocache = run(SSX_CACHE_DIR="")
+        assert nocache["state"] == _capi.SSX_JIT_STATE_GENERIC_MEANWHILE and not list(cache.glob("pass1-*"))
+    finally:
+        if old is None:
+            os.environ.pop("SSX_CACHE_DIR", None)
+        else:
+            os.environ["SSX_CACHE_DIR"] = old
+
+
 def test_shadow_queue_layouts_wide_by_default_narrow_when_it_buys_a_workgroup():
     """The shadow-ray queues have 48-byte entries (the contribution rides along, the flush writes the finished
     next-event term) unless 32-byte entries (contribution to HBM at park time, visibility byte at flush time)
@@ -577,7 +675,30 @@ def test_shadow_queue_layouts_wide_by_default_narrow_when_it_buys_a_workgroup():
     r6 = Renderer(Options(scene_name="cornell-srgb", res=(8, 8), spp=1, texture="test-img.png", observer=2006))
     assert r6.kernel_info()["max_blocks_per_cu"] == 4                                              # narrow buys the fourth
     assert r6.plan_info()["kernel"] == "ssx_render_kernel_cornell_nq"
-    env = dict(os.environ, SSX_NARROW_QUEUE="1")
+    env = dict(os.environ, SSX_DEBUG_ENV="1", SSX_NARROW_QUEUE="1")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
                           "bit_exact_against_oracle or config1 or many_units or without_explicit"], env=env, capture_output=True, text=True, cwd=os.path.dirname(HERE))
     assert out.returncode == 0, out.stdout[-3000:]
+
+
+def test_rccl_communicators_are_kept_between_combines():
+    """ssx_reduce_rccl used to build and destroy its communicators at every call.  They now stay in the
+    contexts: a second combine of the same contexts creates none, the image is the one-rank sum (itself) both times, another
+    context gets its own group, and destroying a context releases its communicator."""
+    lib = _capi.hip_lib()
+    lib.ssx_rccl_groups_made.restype = C.c_uint64
+    _, r = gpu_render(scene_name="cornell-srgb", res=(32, 24), spp=4, seed=1, texture="test-img.png")
+    ref = r.xyza.copy()
+    ctxs = (C.c_void_p * 1)(r._ctx)
+    before = lib.ssx_rccl_groups_made()
+    for _ in range(3):
+        assert lib.ssx_reduce_rccl(ctxs, 1, 32, 24) == 0, lib.ssx_last_error(r._ctx)
+        out = np.zeros_like(ref)
+        assert lib.ssx_read_framebuffer(r._ctx, out.ctypes.data) == 0
+        assert np.array_equal(bits(out), bits(ref))
+    assert lib.ssx_rccl_groups_made() == before + 1
+    _, r2 = gpu_render(scene_name="cornell", res=(32, 24), spp=2)
+    assert lib.ssx_reduce_rccl((C.c_void_p * 1)(r2._ctx), 1, 32, 24) == 0
+    assert lib.ssx_rccl_groups_made() == before + 2
+    r2.close()                                      # releases its communicator; the first context's is untouched
+    assert lib.ssx_reduce_rccl(ctxs, 1, 32, 24) == 0 and lib.ssx_rccl_groups_made() == before + 2

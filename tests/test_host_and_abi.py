@@ -30,7 +30,7 @@ def test_libraries_export_every_declared_symbol():
     for s in fh:
         getattr(host, s)
     hip.ssx_abi_version.restype = C.c_int
-    assert hip.ssx_abi_version() == 1
+    assert hip.ssx_abi_version() == _capi.SSX_ABI_VERSION == 2
 
 
 def test_struct_layouts_match_the_headers():
@@ -296,3 +296,28 @@ def test_runtime_pass1_generator_equals_the_committed_one():
     text = buf.value.decode()
     assert text == "\n".join(gen_pass1.emit_topology("jit", vids)) + "\n"
     assert "10 distinct vertices of 12 corners, 14 distinct edges of 15" in text and text.count("// quads") == 2
+
+
+def test_one_hip_runtime_whatever_the_import_order():
+    """"torch must initialise first" was a usage rule.  Now a mechanism: simple_spectral_amd/_capi.py maps
+    ONE libamdhip64 into the process in either import order (torch's bundled copy when torch is installed, so that streams and
+    device pointers can be handed between the two), checks that it stayed one, and the C library itself refuses to create a
+    context in a process that holds two (a host that bypassed the Python loader).  No GPU needed: the checks precede any device call."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    head = "import sys; sys.path.insert(0, %r)\nfrom simple_spectral_amd import _capi\n" % root
+    for first in ("_capi.hip_lib()\nimport torch\n", "import torch\n_capi.hip_lib()\n"):
+        out = subprocess.run([sys.executable, "-c", head + first + "print(len(_capi.mapped_hip_runtimes()))"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "1", (first, out.stdout, out.stderr[-1500:])
+    # two runtimes on purpose: /opt/rocm's by path, then torch (which maps its own copy beside it)
+    two = head + ("import ctypes as C\nC.CDLL('/opt/rocm/lib/libamdhip64.so.7', mode=C.RTLD_GLOBAL)\nimport torch\n"
+                  "print('mapped', len(_capi.mapped_hip_runtimes()))\n"
+                  "lib = C.CDLL(_capi._build.HIP_LIB)\nlib.ssx_last_error.restype = C.c_char_p\nctx = C.c_void_p()\n"
+                  "print('create', lib.ssx_create(0, C.byref(ctx)), lib.ssx_last_error(None).decode())\n"
+                  "try:\n    _capi.hip_lib()\n    print('loader accepted')\nexcept RuntimeError as e:\n    print('loader refused:', e)\n")
+    out = subprocess.run([sys.executable, "-c", two], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-1500:]
+    if "mapped 2" not in out.stdout:
+        pytest.skip("could not provoke two HIP runtimes on this image: " + out.stdout)
+    assert ("create %d two HIP runtimes are mapped" % _capi.SSX_ERR_DEVICE) in out.stdout and "loader refused: two HIP runtimes" in out.stdout, out.stdout

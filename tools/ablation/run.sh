@@ -8,6 +8,7 @@
 # region twice with the first result kept alive.  Two traps met on the way (profiles/r03_end/time_budget.log):
 #   * removing the stores of a result lets the compiler remove what computed it (no fs/np/vis stores -> no shadow trace);
 #   * a textured quad given a constant zero albedo ends its paths early (ABL_NOTEX; ABL_NOTEX2 keeps a non-zero table).
+export SSX_DEBUG_ENV=1 # the master switch of the A/B environment variables (README)
 VARIANTS="acos:-DABL_ACOS acossc:-DABL_ACOS,-DABL_SINCOS noshadow:-DABL_NOSHADOW nofold:-DABL_NOFOLD notex2:-DABL_NOTEX2 trace2x:-DABL_TRACE2X light2x:-DABL_LIGHT2X bsdf2x:-DABL_BSDF2X albedo2x:-DABL_ALBEDO2X nee2x:-DABL_NEE2X smalllog:-DABL_SMALLLOG nt:-DABL_NT aos:-DABL_LOG_AOS"
 R=$(cd "$(dirname "$0")/../.." && pwd); cd $R
 if [ "$1" = build ]; then

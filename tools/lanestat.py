@@ -16,6 +16,7 @@ lib = os.path.join(ROOT, "gpurun_out", "libssx_hip_lanestat.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 from simple_spectral_amd import build as b
 subprocess.check_call([b.hipcc()] + b.HIP_FLAGS + ["-DSSX_LANESTAT"] + b.HIP_SRC + ["-o", lib, "-lpthread"])
+os.environ["SSX_DEBUG_ENV"] = "1"
 os.environ["SSX_HIP_LIB_OVERRIDE"] = lib
 import torch
 from simple_spectral_amd import Options, Renderer, _capi

@@ -1,6 +1,7 @@
 #!/bin/bash
 # One rocprofv3 --pmc pass (SQ instruction / cycle counters) of bench.py for the product library and for the variant
 # libraries given, printed per kernel: tools/pmc_quick.sh "<bench args>" [variant.so ...]
+export SSX_DEBUG_ENV=1 # the master switch of the A/B environment variables (README)
 R=$(pwd); ARGS=$1; shift
 cd /tmp && export TMPDIR=/tmp
 for V in product "$@"; do

@@ -63,12 +63,18 @@ def main():
                 ms = (time.perf_counter() - t0) / args.steps * 1e3
                 worst = max(worst, ms)
                 sums = rd.sums_info()
+                rd.set_timing(True)  # three more steps with HIP events around the kernels: which one carries a difference
+                for _ in range(3):
+                    rd.render_device(out.data_ptr(), stream.cuda_stream)
+                torch.cuda.synchronize()
+                stages = {k: round(v / 3, 3) for k, v in rd.get_timing().items() if k in ("generate", "path")}
+                rd.set_timing(False)
                 n_units = (args.warmup + args.steps) * (res // 8) ** 2 // n * ((spp * n + 3) // 4)  # (units of 4 samples per pixel: Cornell; the plane scene's have 8)
                 rd.close()
                 line = {"tag": args.tag, "config": name, "scene": scene, "res": res, "spp_per_gpu": spp, "observer": observer,
                         "N": n, "rank": r, "tiles": (res // 8) ** 2 // n, "spp": spp * n, "ms_per_step": round(ms, 3),
                         "Msamples_per_s": round(res * res * spp / ms / 1e3, 1),
-                        "units_parked_frac": round(sums["units_parked"] / n_units, 4), "units_chained_frac": round(sums["units_chained"] / n_units, 4)}
+                        "units_parked_frac": round(sums["units_parked"] / n_units, 4), "units_chained_frac": round(sums["units_chained"] / n_units, 4), "stage_ms": stages}
                 print(json.dumps(line), flush=True)
                 out_lines.append(line)
             if n == 1:
