@@ -30,7 +30,8 @@ extern "C" {
  *   2  ssx_quad.is_light became the bitfield `flags` (SSX_PRIM_LIGHT | SSX_PRIM_TRI: other nonzero values are refused now);
  *      ssx_render_params.reserved became no_flat_field_correction (a stale nonzero value changes the image); SSX_MAX_QUADS 32 -> 128,
  *      SSX_MAX_TEXTURES and the struct sizes grew; ssx_set_jit takes a mode (default: background compilation); ssx_jit_status,
- *      ssx_jit_counters, ssx_sums_info, ssx_rccl_groups_made are new. */
+ *      ssx_jit_counters, ssx_sums_info, ssx_rccl_groups_made, ssx_done_tiles and ssx_render_params.tile_major (+ reserved: the
+ *      struct grew by 8 bytes) are new. */
 #define SSX_ABI_VERSION 2
 
 enum {
@@ -164,6 +165,15 @@ typedef struct ssx_render_params {
 	uint32_t no_flat_field_correction;   /* 0 = FLAT_FIELD_CORRECTION defined (src/stdafx.hpp:55, the reference's default:
 	                             flux = radiance); 1 = the build without it: flux = radiance * dot(camera_ray_dir,
 	                             camera.dir) (src/renderer.cpp:262-266).  (Was `reserved`, 0.) */
+	uint32_t tile_major;      /* How ssx_render_start walks through the work, i.e. what a stopped render holds (the image of a finished render
+	                             does not depend on it).  0: all owned tiles together, a range of samples per launch; after ssx_render_stop
+	                             every pixel holds the mean over the samples done so far (ssx_done_spp).  1: the reference's way
+	                             (src/renderer.cpp:340-409: the tile list from tile (0,0) upwards, every tile rendered to the full sample
+	                             count): a range of tiles per launch; after ssx_render_stop the finished tiles hold their final value and the
+	                             others are returned as zeros -- ssx_done_tiles says how many of the device's tiles, in ascending tile order,
+	                             are finished, so that the host leaves its checkerboard where the reference does (src/renderer.cpp:388-394,
+	                             src/framebuffer.cpp:15-32).  Ignored by ssx_render_device (which cannot be stopped). */
+	uint32_t reserved;        /* 0 */
 	uint64_t seed;            /* seeding contract below */
 } ssx_render_params;
 
@@ -196,6 +206,9 @@ float ssx_progress(ssx_ctx* ctx);
  * full spp next to untouched checkerboard tiles (src/renderer.cpp:388-394, src/framebuffer.cpp:9-33); with several devices
  * each context may have stopped at another count, which the caller can read here. */
 uint32_t ssx_done_spp(ssx_ctx* ctx);
+/* tile_major renders: the device's tiles (those with t % tile_stride == tile_first, in ascending order) finished so far; after a
+ * completed render: all of them.  Other renders: 0 while rendering, all of them when done. */
+uint32_t ssx_done_tiles(ssx_ctx* ctx);
 /* Renderer::render_wait (src/renderer.cpp:423-430) + read-back of what `framebuffer(i,j)=...`
  * (src/renderer.cpp:298) would receive BEFORE ciexyz_to_srgb: float4 {X,Y,Z,alpha} per pixel,
  * index j*W+i, row 0 = bottom (src/framebuffer.hpp:26-34).  xyza_out may be NULL. */
@@ -324,7 +337,12 @@ enum {
 	SSX_SWEEP_DIV_PI = 7,      /* x / pi_f through the binary64 reciprocal constant vs IEEE division */
 	SSX_SWEEP_RCP64 = 8,       /* binary64 reciprocal of a float: result[1] = largest error in ulps of 1.0 / (double)x */
 	SSX_SWEEP_DIV_PAIRS = 9,   /* x / hash(x), x / (hash with x's exponent), hash(x) / x through div64 vs IEEE division */
-	SSX_SWEEP_ACOS_SIN = 10    /* |x| <= 1: fused {min(acos x, under_pi), its sine} vs ssx_acosf / ssx_sinf; result[1] = inputs sent to the fallback */
+	SSX_SWEEP_ACOS_SIN = 10,   /* |x| <= 1: fused {min(acos x, under_pi), its sine} vs ssx_acosf / ssx_sinf; result[1] = inputs sent to the fallback */
+	/* include/ssx_fmath.h against an INDEPENDENT evaluation (csrc/ssx_ddmath.h: double-double Taylor series, three-part pi/2, Newton on
+	 * the cosine -- nothing shared with the header), every float pattern: result[0] = inputs where ssx_*f is not the correctly rounded
+	 * value the independent evaluation decides on (or not NaN outside the domain), result[1] = inputs whose value lies within 2^-70 of a
+	 * float rounding boundary, which it does not decide; examples (result[3..]): the input pattern, | 1 << 32 for an undecided one */
+	SSX_SWEEP_SIN_PROOF = 11, SSX_SWEEP_COS_PROOF = 12, SSX_SWEEP_ACOS_PROOF = 13
 };
 int ssx_debug_sweep(ssx_ctx* ctx, uint32_t op, uint32_t lo, uint64_t count, uint64_t result[11]);
 /* The text of the pass-1 function ssx_set_jit would compile for the sharing pattern vid[n_quads][4] (distinct-vertex ids of

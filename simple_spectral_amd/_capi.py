@@ -60,7 +60,7 @@ class SsxRenderParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32),
                 ("indirect_only", C.c_uint32), ("tile_first", C.c_uint32), ("tile_stride", C.c_uint32),
                 ("spp_per_launch", C.c_uint32), ("no_explicit_light_sampling", C.c_uint32), ("no_flat_field_correction", C.c_uint32),
-                ("seed", C.c_uint64)]
+                ("tile_major", C.c_uint32), ("reserved", C.c_uint32), ("seed", C.c_uint64)]
 
 
 SSX_MODE_RGB, SSX_UPLIFT_OURS, SSX_UPLIFT_MENG, SSX_UPLIFT_JH = 0, 1, 2, 3
@@ -75,9 +75,9 @@ HIP_SYMBOLS = ["ssx_create", "ssx_destroy", "ssx_upload_scene", "ssx_render_star
                "ssx_is_rendering", "ssx_progress", "ssx_render_wait", "ssx_render_device", "ssx_last_error",
                "ssx_abi_version", "ssx_kernel_info", "ssx_plan_info", "ssx_set_timing", "ssx_get_timing",
                "ssx_device_framebuffer", "ssx_device_index", "ssx_read_framebuffer", "ssx_accumulate_peer",
-               "ssx_debug_eval", "ssx_debug_samples", "ssx_debug_sweep", "ssx_kernel_variant", "ssx_kernel_name", "ssx_scratch_info", "ssx_calibration_info", "ssx_set_jit", "ssx_debug_pass1_source", "ssx_done_spp", "ssx_reduce_rccl", "ssx_sums_info", "ssx_rccl_groups_made", "ssx_jit_status", "ssx_jit_counters"]
+               "ssx_debug_eval", "ssx_debug_samples", "ssx_debug_sweep", "ssx_kernel_variant", "ssx_kernel_name", "ssx_scratch_info", "ssx_calibration_info", "ssx_set_jit", "ssx_debug_pass1_source", "ssx_done_spp", "ssx_reduce_rccl", "ssx_sums_info", "ssx_rccl_groups_made", "ssx_jit_status", "ssx_jit_counters", "ssx_done_tiles"]
 (SSX_SWEEP_RCP, SSX_SWEEP_SQRT, SSX_SWEEP_INVERSESQRT, SSX_SWEEP_SIN, SSX_SWEEP_COS, SSX_SWEEP_ACOS, SSX_SWEEP_DIV_PI,
- SSX_SWEEP_RCP64, SSX_SWEEP_DIV_PAIRS, SSX_SWEEP_ACOS_SIN) = range(1, 11)
+ SSX_SWEEP_RCP64, SSX_SWEEP_DIV_PAIRS, SSX_SWEEP_ACOS_SIN, SSX_SWEEP_SIN_PROOF, SSX_SWEEP_COS_PROOF, SSX_SWEEP_ACOS_PROOF) = range(1, 14)
 # ssx_debug_eval ops (include/ssx.h)
 (SSX_DBG_FMATH, SSX_DBG_SPHTRI, SSX_DBG_ARVO, SSX_DBG_SAMPLE_LIGHT, SSX_DBG_COSHEMI, SSX_DBG_TRACE, SSX_DBG_RAND_CHOICE,
  SSX_DBG_ALBEDO, SSX_DBG_FLUX_TO_XYZ, SSX_DBG_RAND_1F) = range(1, 11)
@@ -217,6 +217,8 @@ def hip_lib():
             lib.ssx_jit_counters.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
             lib.ssx_jit_counters.restype = None
             lib.ssx_rccl_groups_made.restype = C.c_uint64
+            lib.ssx_done_tiles.argtypes = [vp]
+            lib.ssx_done_tiles.restype = C.c_uint32
         lib.ssx_kernel_variant.argtypes = [vp]
         lib.ssx_kernel_name.argtypes = [vp]
         lib.ssx_kernel_name.restype = C.c_char_p

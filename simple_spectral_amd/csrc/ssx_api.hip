@@ -91,6 +91,7 @@ struct ssx_ctx {
 	std::atomic<int> rendering{0};
 	std::atomic<int> stop_flag{0};
 	std::atomic<uint32_t> done_spp{0};
+	std::atomic<uint32_t> done_tiles{0}; // tile_major renders: the device's tiles finished so far (ssx_done_tiles)
 	uint32_t total_spp = 0;
 	int worker_rc = 0;
 	ssx_render_params cur{};
@@ -753,11 +754,11 @@ int calibrate(ssx_ctx* ctx) {
 }
 
 // `spp` = the samples per pixel actually accumulated (Options::spp, or fewer after ssx_render_stop)
-int launch_finalize(ssx_ctx* ctx, const ssx_render_params* p, uint32_t spp, float* d_out, hipStream_t stream) {
+int launch_finalize(ssx_ctx* ctx, const ssx_render_params* p, uint32_t spp, float* d_out, hipStream_t stream, uint32_t done_tiles = 0xFFFFFFFFu) {
 	uint32_t pixels = p->width * p->height;
 	hipLaunchKernelGGL(ssx_finalize_kernel, dim3((pixels + 255u) / 256u), dim3(256), 0, stream,
 	                   (const double*)ctx->d_accum, (float4*)d_out, p->width, p->height, (p->width + 7u) / 8u,
-	                   p->tile_first, p->tile_stride, spp, ctx->rgb_mode ? 1u : 0u);
+	                   p->tile_first, p->tile_stride, spp, ctx->rgb_mode ? 1u : 0u, done_tiles);
 	SSX_HIP(ctx, hipGetLastError());
 	return SSX_OK;
 }
@@ -780,6 +781,44 @@ void worker_main(ssx_ctx* ctx) {
 		}
 		if (chunk == 0) chunk = 1;
 		if (chunk > pl.max_spp_per_launch) chunk = pl.max_spp_per_launch;
+		if (p.tile_major) {
+			// The reference's walk (src/renderer.cpp:340-409): the tile list from tile (0,0) upwards, every tile to the full sample count.
+			// A launch takes as many of the device's tiles as make ~32 M samples (cancel granularity as below, at least one), all their
+			// samples (in sample ranges where one launch cannot hold them); a stop between launches leaves finished tiles next to
+			// untouched ones.  Same units, same kernels, same bits -- only the order of the work differs.
+			const uint32_t owned = pl.args.my_tiles;
+			uint32_t spp_l = p.spp_per_launch ? p.spp_per_launch : p.spp;
+			if (spp_l > p.spp) spp_l = p.spp;
+			uint64_t per_launch = (((uint64_t)32 << 20) / ((uint64_t)64 * p.spp)) + 1u;
+			if (const char* e = debug_env("SSX_TILES_PER_LAUNCH")) { const int v = atoi(e); if (v >= 1) per_launch = (uint64_t)v; } // tests (under SSX_DEBUG_ENV=1)
+			if (per_launch > owned) per_launch = owned;
+			{ // the sample arrays are sized by tiles x samples per launch: bring the launch under the budget of make_plan (it assumed all tiles)
+				const uint64_t budget_records = (uint64_t)pl.max_spp_per_launch * owned * 64u;
+				while (spp_l > 1u && (uint64_t)spp_l * 64u > budget_records) spp_l = (spp_l + 1u) / 2u;
+				const uint64_t fit = budget_records / ((uint64_t)spp_l * 64u);
+				if (per_launch > fit) per_launch = fit ? fit : 1u;
+			}
+			LaunchPlan sized = pl; sized.args.my_tiles = (uint32_t)per_launch;
+			{ int r = ensure_samples(ctx, sized, spp_l); if (r) return r; }
+			for (uint32_t j0 = 0; j0 < owned && !ctx->stop_flag.load(); j0 += (uint32_t)per_launch) {
+				const uint32_t j1 = (owned - j0 < per_launch) ? owned : j0 + (uint32_t)per_launch;
+				maybe_swap_jit(ctx, (uint64_t)(j1 - j0) * 64u * p.spp);
+				LaunchPlan part = make_plan(ctx, &p);
+				part.args.tile_first = p.tile_first + p.tile_stride * j0; // the device's tiles j0 .. j1-1 of its list
+				part.args.my_tiles = j1 - j0;
+				int r = launch_batches(ctx, part, p.spp, spp_l, ctx->stream);
+				if (r) return r;
+				SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+				ctx->done_tiles.store(j1);
+				ctx->done_spp.store((uint32_t)((uint64_t)p.spp * j1 / owned)); // (progress; the finished tiles hold all p.spp samples)
+			}
+			const uint32_t done = ctx->done_tiles.load();
+			if (done == owned) ctx->done_spp.store(p.spp);
+			int r = launch_finalize(ctx, &p, p.spp, ctx->d_out, ctx->stream, done);
+			if (r) return r;
+			SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			return SSX_OK;
+		}
 		{ int r = ensure_samples(ctx, pl, chunk < p.spp ? chunk : p.spp); if (r) return r; }
 		for (uint32_t k0 = 0; k0 < p.spp && !ctx->stop_flag.load(); k0 += chunk) {
 			uint32_t k1 = (p.spp - k0 < chunk) ? p.spp : k0 + chunk;
@@ -800,6 +839,7 @@ void worker_main(ssx_ctx* ctx) {
 		int r = launch_finalize(ctx, &p, done ? done : p.spp, ctx->d_out, ctx->stream);
 		if (r) return r;
 		SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		ctx->done_tiles.store(pl.args.my_tiles);
 		return SSX_OK;
 	};
 	rc = run();
@@ -1067,6 +1107,7 @@ int ssx_render_start(ssx_ctx* ctx, const ssx_render_params* p) {
 	ctx->cur = *p;
 	ctx->total_spp = p->spp;
 	ctx->done_spp.store(0);
+	ctx->done_tiles.store(0);
 	ctx->stop_flag.store(0);
 	ctx->worker_rc = 0;
 	ctx->rendering.store(1);
@@ -1088,6 +1129,8 @@ float ssx_progress(ssx_ctx* ctx) {
 }
 
 uint32_t ssx_done_spp(ssx_ctx* ctx) { return ctx ? ctx->done_spp.load() : 0u; }
+
+uint32_t ssx_done_tiles(ssx_ctx* ctx) { return ctx ? ctx->done_tiles.load() : 0u; }
 
 int ssx_render_wait(ssx_ctx* ctx, float* xyza_out) {
 	if (!ctx) return SSX_ERR_ARG;

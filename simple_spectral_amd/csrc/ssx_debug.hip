@@ -5,6 +5,7 @@
 // functions on edge cases the renders reach rarely or never (degenerate spherical triangles, rays
 // through shared vertices, the Lemire redraw, ...).  Nothing here runs during a render.
 #include "../../include/ssx.h"
+#include "ssx_ddmath.h" // the independent evaluation of sin / cos / acos that ssx_fmath.h is proved against (SSX_SWEEP_*_PROOF)
 
 namespace {
 
@@ -72,6 +73,25 @@ extern "C" __global__ void __launch_bounds__(256) ssx_debug_sweep_kernel(SsxKern
 			     same_float(ssx_exact::div64_by(b1, ssx_exact::div64_rcp_any(x)), b1 / x);
 			break;
 		}
+		case SSX_SWEEP_SIN_PROOF: case SSX_SWEEP_COS_PROOF: case SSX_SWEEP_ACOS_PROOF: { // ssx_fmath.h against csrc/ssx_ddmath.h
+			const bool arc = op == SSX_SWEEP_ACOS_PROOF;
+			const float got = op == SSX_SWEEP_SIN_PROOF ? ssx_sinf(x) : (arc ? ssx_acosf(x) : ssx_cosf(x));
+			if (!(__builtin_fabsf(x) <= (arc ? 1.0f : 0x1p20f))) { ok = got != got; break; } // outside the domain (and NaN): NaN
+			int decided = 1;
+			const float want = op == SSX_SWEEP_SIN_PROOF ? ssx_dd::sin_f32(x, &decided) : (arc ? ssx_dd::acos_f32(x, acos((double)x), &decided) : ssx_dd::cos_f32(x, &decided));
+			if (!decided) { // too close to a rounding boundary for ~100 bits: the host settles it (tests/test_fmath.py)
+				++mx;
+				const unsigned long long slot = atomicAdd(&res[2], 1ull);
+				if (slot < 8ull) res[3 + slot] = (unsigned long long)bits | (1ull << 32);
+				break;
+			}
+			if (__float_as_uint(got) != __float_as_uint(want)) { // every one of these is listed (the header's known exceptions: a handful)
+				atomicAdd(&res[0], 1ull);
+				const unsigned long long slot = atomicAdd(&res[2], 1ull);
+				if (slot < 8ull) res[3 + slot] = bits;
+			}
+			break;
+		}
 		default: break;
 		}
 		if (!ok) { ++bad; if (!have_example) { example = bits; have_example = true; } }
@@ -81,7 +101,7 @@ extern "C" __global__ void __launch_bounds__(256) ssx_debug_sweep_kernel(SsxKern
 		const unsigned long long slot = atomicAdd(&res[2], 1ull);
 		if (slot < 8ull) res[3 + slot] = example;
 	}
-	if (mx) { if (op == SSX_SWEEP_ACOS_SIN) atomicAdd(&res[1], mx); else atomicMax(&res[1], mx); }
+	if (mx) { if (op == SSX_SWEEP_ACOS_SIN || op >= SSX_SWEEP_SIN_PROOF) atomicAdd(&res[1], mx); else atomicMax(&res[1], mx); }
 }
 
 extern "C" __global__ void __launch_bounds__(256) ssx_debug_eval_kernel(SsxKernelArgs a, uint32_t op, const uint32_t* in, uint32_t in_words,

@@ -1774,14 +1774,17 @@ extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_pe
 #ifndef SSX_JIT_BUILD
 // renderer.cpp:296,298: avg *= 1000.0/spp, then the float conversion of CIEXYZ_32F(avg) / avg.a.
 // Pixels of tiles this device does not own are written as 0 (x+0 is exact in the framebuffer sum).
+// done_tiles: how many of the device's tiles (ascending tile order) hold a result -- all of them, except after a stopped tile-major
+// render (ssx_render_params::tile_major), whose unfinished tiles stay zero like foreign ones.
 extern "C" __global__ void __launch_bounds__(256) ssx_finalize_kernel(const double* accum, float4* out, uint32_t width, uint32_t height,
-                                                  uint32_t tiles_x, uint32_t tile_first, uint32_t tile_stride, uint32_t spp, uint32_t rgb_mode) {
+                                                  uint32_t tiles_x, uint32_t tile_first, uint32_t tile_stride, uint32_t spp, uint32_t rgb_mode, uint32_t done_tiles) {
 	uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
 	if (p >= width * height) return;
 	uint32_t i = p % width, j = p / width;
 	uint32_t tile = (j >> 3) * tiles_x + (i >> 3);
 	float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 	const double* const px = accum + (size_t)tile * 256u + ((j & 7u) * 8u + (i & 7u)); // [tile][component][pixel of the tile] (unit_fold)
+	if (tile % tile_stride != tile_first || tile / tile_stride >= done_tiles) { out[p] = o; return; }
 	if (tile % tile_stride == tile_first && rgb_mode) { // renderer.cpp:304: avg /= double(spp)
 		const double n = (double)spp;
 		o.x = (float)(px[0] / n);

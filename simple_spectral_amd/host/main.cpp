@@ -3,7 +3,7 @@
 // Flags, aliases, defaults and messages follow the reference (note: -h is HEIGHT, there is no
 // --help; `name=value` or bare flags; unknown arguments produce a warning).  Additive options,
 // long names only so that none collides: --gpus=N --seed=S --observer=1931|2006 --texture=PATH
-// --light-scale=X --data-dir=DIR --uplift=ours|meng|jh --jh-coeff=FILE --meng-grid=FILE --no-explicit-light-sampling --no-flat-field-correction --reduce=peer|rccl --rgb.
+// --light-scale=X --data-dir=DIR --uplift=ours|meng|jh --jh-coeff=FILE --meng-grid=FILE --no-explicit-light-sampling --no-flat-field-correction --tile-major --reduce=peer|rccl --rgb.
 #include "renderer.hpp"
 
 #include <chrono>
@@ -33,7 +33,7 @@ void print_usage() {
 		"    `--indirect-only`/`-io`\n"
 		"          Render only indirect illumination.\n"
 		"  MI355X build:\n"
-		"    `--gpus=<n>` `--seed=<n>` `--observer=1931|2006` `--uplift=ours|meng|jh` `--jh-coeff=<file>` `--meng-grid=<file>` `--rgb` `--no-explicit-light-sampling` `--no-flat-field-correction` `--reduce=peer|rccl`\n"
+		"    `--gpus=<n>` `--seed=<n>` `--observer=1931|2006` `--uplift=ours|meng|jh` `--jh-coeff=<file>` `--meng-grid=<file>` `--rgb` `--no-explicit-light-sampling` `--no-flat-field-correction` `--tile-major` `--reduce=peer|rccl`\n"
 		"    `--texture=<png>` `--light-scale=<x>` `--data-dir=<dir>`\n");
 }
 
@@ -105,6 +105,7 @@ void parse_arguments(int argc, char* argv[], ssx::Renderer::Options* o) {
 	if (a.take("--rgb", "", &v)) o->rgb_mode = true;
 	if (a.take("--no-explicit-light-sampling", "", &v)) o->explicit_light_sampling = false;
 	if (a.take("--no-flat-field-correction", "", &v)) o->flat_field_correction = false;
+	if (a.take("--tile-major", "", &v)) o->tile_major = true;
 	if (a.take("--reduce", "", &v)) {
 		if (v == "rccl") o->reduce_rccl = true;
 		else if (v != "peer") { std::fprintf(stderr, "Unrecognized --reduce \"%s\" (peer | rccl)\n", v.c_str()); throw -2; }

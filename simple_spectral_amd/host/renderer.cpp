@@ -39,6 +39,7 @@ struct Renderer::Api {
 	int (*read_framebuffer)(ssx_ctx*, float*) = nullptr;
 	int (*accumulate_peer)(ssx_ctx*, void*, int, const void*, uint32_t, uint32_t, void*) = nullptr;
 	uint32_t (*done_spp)(ssx_ctx*) = nullptr;
+	uint32_t (*done_tiles)(ssx_ctx*) = nullptr;
 	int (*reduce_rccl)(ssx_ctx**, int, uint32_t, uint32_t) = nullptr;
 
 	explicit Api(const std::string& path) {
@@ -66,6 +67,7 @@ struct Renderer::Api {
 		read_framebuffer = reinterpret_cast<decltype(read_framebuffer)>(sym("ssx_read_framebuffer"));
 		accumulate_peer = reinterpret_cast<decltype(accumulate_peer)>(sym("ssx_accumulate_peer"));
 		done_spp = reinterpret_cast<decltype(done_spp)>(sym("ssx_done_spp"));
+		done_tiles = reinterpret_cast<decltype(done_tiles)>(sym("ssx_done_tiles"));
 		reduce_rccl = reinterpret_cast<decltype(reduce_rccl)>(sym("ssx_reduce_rccl"));
 	}
 	~Api() { if (handle) dlclose(handle); }
@@ -154,6 +156,7 @@ void Renderer::render_start() {
 		p.no_flat_field_correction = options.flat_field_correction ? 0u : 1u;
 		p.tile_first = static_cast<uint32_t>(d); p.tile_stride = static_cast<uint32_t>(ctxs_.size());
 		p.spp_per_launch = 0;
+		p.tile_major = options.tile_major ? 1u : 0u;
 		p.seed = options.seed;
 		int rc = api_->render_start(ctxs_[d], &p);
 		if (rc) throw HostError{ rc, std::string("ssx_render_start: ") + api_->last_error(ctxs_[d]) };
@@ -214,9 +217,16 @@ void Renderer::render_wait() {
 	// a stopped render: every device's share is the mean over the samples IT accumulated (ssx.h: ssx_done_spp); say so when the
 	// counts differ from the request, as the image then is not what the reference would have left (finished tiles next to
 	// untouched ones, src/renderer.cpp:388-394)
+	const size_t tiles_x = (options.res[0] + 7) / 8, n_tiles = tiles_x * ((options.res[1] + 7) / 8);
+	std::vector<uint32_t> done_tiles(ctxs_.size());
+	bool partial_tiles = false;
 	for (size_t d = 0; d < ctxs_.size(); ++d) {
 		const uint32_t done = api_->done_spp(ctxs_[d]);
-		if (done != static_cast<uint32_t>(options.spp))
+		done_tiles[d] = api_->done_tiles(ctxs_[d]);
+		const size_t owned = n_tiles > d ? (n_tiles - d + ctxs_.size() - 1) / ctxs_.size() : 0;
+		if (options.tile_major) {
+			if (done_tiles[d] < owned) { partial_tiles = true; std::fprintf(stderr, "Render stopped: device %d finished %u of its %zu tiles; the others keep the checkerboard.\n", api_->device_index(ctxs_[d]), done_tiles[d], owned); }
+		} else if (done != static_cast<uint32_t>(options.spp))
 			std::fprintf(stderr, "Render stopped: device %d accumulated %u of %zu samples per pixel; its tiles hold the mean over those.\n", api_->device_index(ctxs_[d]), done, static_cast<size_t>(options.spp));
 	}
 	ssx_ctx* root = ctxs_[0];
@@ -235,7 +245,15 @@ void Renderer::render_wait() {
 	}
 	started_ = false;
 	// framebuffer(i,j) = sRGB_A_F32(ciexyz_to_srgb(XYZ), alpha)  (src/renderer.cpp:298)
-	color->xyza_to_srgba(xyza.data(), framebuffer.data(), options.res[0] * options.res[1]);
+	if (!partial_tiles) color->xyza_to_srgba(xyza.data(), framebuffer.data(), options.res[0] * options.res[1]);
+	else { // a stopped tile-major render: like the reference's, the framebuffer keeps its checkerboard where no tile was finished (src/framebuffer.cpp:15-32)
+		std::vector<float> all(xyza.size());
+		color->xyza_to_srgba(xyza.data(), all.data(), options.res[0] * options.res[1]);
+		for (size_t j = 0; j < options.res[1]; ++j) for (size_t i = 0; i < options.res[0]; ++i) {
+			const size_t tile = (j / 8) * tiles_x + i / 8, d = tile % ctxs_.size();
+			if (tile / ctxs_.size() < done_tiles[d]) std::memcpy(framebuffer(i, j), &all[4 * (j * options.res[0] + i)], 4 * sizeof(float));
+		}
+	}
 	print_progress();
 	if (!options.output_path.empty()) framebuffer.save(options.output_path); // src/renderer.cpp:393
 }

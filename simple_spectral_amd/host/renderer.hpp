@@ -46,6 +46,8 @@ public:
 		bool explicit_light_sampling = true; // EXPLICIT_LIGHT_SAMPLING (src/stdafx.hpp:44)
 		bool reduce_rccl = false;            // --reduce=rccl: combine the devices' framebuffers with one RCCL reduce instead of peer copies + adds
 		bool flat_field_correction = true;   // FLAT_FIELD_CORRECTION (src/stdafx.hpp:55); false: flux = radiance * dot(ray dir, camera.dir) (src/renderer.cpp:264-265)
+		bool tile_major = false;     // --tile-major: walk through the tiles like the reference (src/renderer.cpp:340-409), so that a stopped render holds finished
+		                             // tiles at the full sample count next to the untouched checkerboard (src/renderer.cpp:388-394) instead of a noisier whole image
 		bool rgb_mode = false;       // RENDER_MODE_RGB (src/stdafx.hpp:91-93) instead of spectral rendering; `uplift` is then unused
 		int uplift = 1;              // RENDER_MODE_SPECTRAL_ALGNUM: 1 = basis (ours), 2 = Meng et al. 2015, 3 = Jakob-Hanika 2019
 		std::string meng_grid_path;  // default data/meng-et-al-2015-grid.bin (converted from the authors' header, meng2015.hpp)

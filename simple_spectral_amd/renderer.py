@@ -57,6 +57,8 @@ class Options:
     tile_first: int = 0
     tile_stride: int = 1
     spp_per_launch: int = 0
+    tile_major: bool = False             # ssx_render_params.tile_major: walk through the tiles like the reference (a stopped render keeps
+    #                                       finished tiles at full sample count, the rest untouched) instead of through the samples
     data_dir: str = field(default=DEFAULT_DATA_DIR)
 
 
@@ -178,6 +180,7 @@ class Renderer:
         p.no_flat_field_correction = int(not o.flat_field_correction)
         p.tile_first, p.tile_stride = o.tile_first, o.tile_stride
         p.spp_per_launch = o.spp_per_launch
+        p.tile_major = int(o.tile_major)
         p.seed = o.seed
         for k, v in over.items():
             setattr(p, k, v)
@@ -198,6 +201,10 @@ class Renderer:
     def done_spp(self):
         """Samples per pixel accumulated so far (after render_stop: what the partial image is the mean of)."""
         return int(self._lib.ssx_done_spp(self._ctx))
+
+    def done_tiles(self):
+        """ssx_done_tiles: this device's tiles (ascending tile order) finished so far."""
+        return int(self._lib.ssx_done_tiles(self._ctx))
 
     def render_wait(self):
         self._check(self._lib.ssx_render_wait(self._ctx, self.xyza.ctypes.data))

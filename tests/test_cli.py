@@ -101,6 +101,36 @@ def test_cli_abort_saves_the_partial_render(cli, tmp_path):
     assert np.isfinite(data).all() and data.max() > 0.0
 
 
+@pytest.mark.gpu
+def test_cli_abort_of_a_tile_major_render_keeps_the_checkerboard(cli, tmp_path):
+    """`--tile-major`: the CLI walks through the tiles like the reference, so that the aborted image is what the reference's last
+    worker saves (src/renderer.cpp:388-394): finished tiles next to the framebuffer's untouched 8x8 checkerboard
+    (src/framebuffer.cpp:15-32: sRGB 0.7 / 0.3; the PFM holds their linear values); the tiles are finished from the bottom of the image up."""
+    import signal
+    import time
+    out = str(tmp_path / "partial.pfm")
+    p = subprocess.Popen([cli, "-s=cornell", "-w=2048", "-h=2048", "-spp=4096", "--tile-major", "-o=" + out], cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(4.0)
+    p.send_signal(signal.SIGINT)
+    so, se = p.communicate(timeout=120)
+    assert p.returncode == 0, se
+    assert "Aborting: saving the partial render" in se and "keep the checkerboard" in se
+    data = np.fromfile(out, dtype="<f4", offset=len("PF\n2048 2048\n-1.0\n")).reshape(2048, 2048, 3)
+    assert np.isfinite(data).all()
+    lin = lambda v: ((v + 0.055) / 1.055) ** 2.4
+    top = data[:8, :16, 0]                                # the file starts with the image's TOP row (src/framebuffer.cpp:112-140): the last tile row,
+    #                                                       never reached in 4 s of a 6 s render -> checkerboard
+    assert np.allclose(top[:, :8], lin(0.3), rtol=1e-3) or np.allclose(top[:, :8], lin(0.7), rtol=1e-3)
+    assert not np.allclose(top[:, :8], top[:, 8:])
+    floor = data[-256:]                                   # the image's bottom rows were rendered first: a floor, not a two-level pattern
+    assert len(np.unique(floor[..., 0])) > 1000
+    pattern = np.isclose(data[..., 0], lin(0.3), rtol=1e-3) | np.isclose(data[..., 0], lin(0.7), rtol=1e-3)
+    rows = pattern.all(axis=1)                            # rows that are checkerboard from end to end: a block at the top of the image, in whole tiles
+    n = int(rows.sum())
+    assert 0 < n < 2048 and rows[:n - 8].all() and not rows[n + 8:].any(), n
+
+
 def _png_of(srgba):
     return np.floor(np.clip(np.float32(255.0) * srgba, 0, 255) + np.float32(0.5)).astype(np.uint8)[::-1]   # std::round, src/framebuffer.cpp:141-165
 

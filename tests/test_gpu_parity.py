@@ -154,6 +154,42 @@ def test_async_interface_progress_and_stop():
     assert np.array_equal(bits(r.xyza), bits(full))
 
 
+def test_tile_major_render_keeps_finished_tiles_when_stopped():
+    """the reference's stop semantics on offer.  ssx_render_params.tile_major walks through the tile list like
+    the reference (src/renderer.cpp:340-409: tile (0,0) upwards, every tile to the full sample count).  A finished render is the same
+    image bit for bit; a stopped one holds finished tiles at their FINAL value next to tiles that were never touched (returned as
+    zeros; ssx_done_tiles tells the host where to leave its checkerboard, src/renderer.cpp:388-394), also on a device that owns
+    every third tile."""
+    import subprocess, sys
+    # complete renders, several launches (3 tiles per launch, samples in ranges of 5): the oracle's bits
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, oracle_lib as ol\nfrom simple_spectral_amd import Options, Renderer\n"
+            "r = Renderer(Options(scene_name='cornell-srgb', res=(50, 37), spp=12, seed=4, texture='test-img.png', tile_major=True, spp_per_launch=5))\n"
+            "r.render_start(); r.render_wait()\n"
+            "ref = ol.Oracle('cornell-srgb', texture='test-img.png').render(50, 37, 12, seed=4)\n"
+            "assert np.array_equal(r.xyza.view(np.uint32), ref.view(np.uint32)) and r.done_tiles() == 35 and r.done_spp() == 12\n" % (os.path.dirname(HERE), HERE))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SSX_DEBUG_ENV="1", SSX_TILES_PER_LAUNCH="3"), capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    # a stopped render
+    for first, stride in ((0, 1), (2, 3)):
+        o = dict(scene_name="cornell-srgb", res=(512, 512), spp=2048, seed=1, texture="test-img.png", tile_first=first, tile_stride=stride)
+        r = Renderer(Options(tile_major=True, **o))
+        owned = (4096 - first + stride - 1) // stride
+        r.render_start()
+        t0 = time.time()
+        while r.done_tiles() == 0 and r.is_rendering() and time.time() - t0 < 60:
+            time.sleep(0.002)
+        r.render_stop()
+        r.render_wait()
+        done = r.done_tiles()
+        assert 0 < done < owned, (done, owned)          # (512 x 512 x 2048 samples take ~170 ms; the first launch ~10 ms)
+        full, _ = gpu_render(**o)                        # the same render, finished (sample-major)
+        tile = (np.arange(512)[:, None] // 8) * 64 + np.arange(512)[None, :] // 8
+        finished = (tile % stride == first) & (tile // stride < done)
+        assert np.array_equal(bits(r.xyza[finished]), bits(full[finished])) and not r.xyza[~finished].any()
+        assert float(r.xyza[finished][:, 3].mean()) > 0.5
+
+
 def test_error_codes():
     lib = _capi.hip_lib()
     ctx = C.c_void_p()
