@@ -8,7 +8,8 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or, when WORLD_SIZ
 script spawns the N ranks itself (127.0.0.1 rendezvous) and relays rank 0's JSON line.
 
 A step = one full render of BASELINE.json configs[1] (cornell-srgb 512x512, hero-wavelength,
-CIE 1931, spp=256 per GPU): the 8x8 tile list is dealt round-robin over the N ranks, every rank
+CIE 1931, spp=256 per GPU): the 8x8 tile list is dealt round-robin over the N ranks -- each tile row rotated by its row number
+(tile_skew 1), so that a rank owns diagonals, not vertical stripes of unequal cost --, every rank
 renders its tiles at spp = 256*N (per-GPU work fixed -> weak scaling) into a zero-initialised
 full-size float4 XYZA buffer on its GPU, and one RCCL reduce(sum) to rank 0 combines them (x+0
 is exact, so the sum is the image).  Inputs (scene tables, texture) are resident in HBM before the
@@ -255,7 +256,7 @@ def main():
     spp_total = args.spp * world
     texture = args.texture
     r = Renderer(Options(scene_name=args.scene, res=(W, H), spp=spp_total, texture=texture, device=local_rank,
-                         tile_first=rank, tile_stride=world, seed=0, observer=args.observer, uplift=args.uplift,
+                         tile_first=rank, tile_stride=world, tile_skew=1 if world > 1 else 0, seed=0, observer=args.observer, uplift=args.uplift,
                          spp_per_launch=args.batch))
     out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
@@ -345,7 +346,7 @@ def main():
             "ms_per_step_device_resident": round(elapsed_resident / args.steps * 1e3, 3),
             "value_host_inclusive": round(value, 2),
             "config": {"workload": "%s %dx%d spp=%d/GPU (total spp %d) CIE%d uplift=%s hero-wavelength megakernel" % (args.scene, W, H, args.spp, spp_total, args.observer, args.uplift),
-                       "parallelism": "tile-split x%d + RCCL reduce" % world if world > 1 else ("single GPU + RCCL reduce (world size 1, SSX_BENCH_FORCE_DIST)" if force_dist else "single GPU"),
+                       "parallelism": "tile-split x%d (round-robin over the tile list, rows rotated: tile_skew 1) + RCCL reduce" % world if world > 1 else ("single GPU + RCCL reduce (world size 1, SSX_BENCH_FORCE_DIST)" if force_dist else "single GPU"),
                        "texture": texture, "seed": 0},
             "roofline": {"bound": "valu", "achieved": round(achieved_tflops, 3), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved_tflops / PEAK_VALU_TFLOPS, 4),

@@ -30,7 +30,7 @@ extern "C" {
  *   2  ssx_quad.is_light became the bitfield `flags` (SSX_PRIM_LIGHT | SSX_PRIM_TRI: other nonzero values are refused now);
  *      ssx_render_params.reserved became no_flat_field_correction (a stale nonzero value changes the image); SSX_MAX_QUADS 32 -> 128,
  *      SSX_MAX_TEXTURES and the struct sizes grew; ssx_set_jit takes a mode (default: background compilation); ssx_jit_status,
- *      ssx_jit_counters, ssx_sums_info, ssx_rccl_groups_made, ssx_done_tiles and ssx_render_params.tile_major (+ reserved: the
+ *      ssx_jit_counters, ssx_sums_info, ssx_rccl_groups_made, ssx_done_tiles and ssx_render_params.tile_major and tile_skew (the
  *      struct grew by 8 bytes) are new. */
 #define SSX_ABI_VERSION 2
 
@@ -173,7 +173,11 @@ typedef struct ssx_render_params {
 	                             others are returned as zeros -- ssx_done_tiles says how many of the device's tiles, in ascending tile order,
 	                             are finished, so that the host leaves its checkerboard where the reference does (src/renderer.cpp:388-394,
 	                             src/framebuffer.cpp:15-32).  Ignored by ssx_render_device (which cannot be stopped). */
-	uint32_t reserved;        /* 0 */
+	uint32_t tile_skew;       /* The list the devices share out (tile_first / tile_stride) is the row-major tile list with tile row ty rotated by
+	                             ty * tile_skew columns; 0 = the plain list.  With N devices and a tile row of a multiple of N tiles the plain list
+	                             gives every device vertical stripes of the image, whose cost differs (Cornell box at N = 8: the outer stripes are
+	                             7 % cheaper than the inner ones); tile_skew = 1 gives diagonals.  All devices of a render use the same value;
+	                             the image does not depend on it. */
 	uint64_t seed;            /* seeding contract below */
 } ssx_render_params;
 

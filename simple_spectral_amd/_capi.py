@@ -60,7 +60,7 @@ class SsxRenderParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32),
                 ("indirect_only", C.c_uint32), ("tile_first", C.c_uint32), ("tile_stride", C.c_uint32),
                 ("spp_per_launch", C.c_uint32), ("no_explicit_light_sampling", C.c_uint32), ("no_flat_field_correction", C.c_uint32),
-                ("tile_major", C.c_uint32), ("reserved", C.c_uint32), ("seed", C.c_uint64)]
+                ("tile_major", C.c_uint32), ("tile_skew", C.c_uint32), ("seed", C.c_uint64)]
 
 
 SSX_MODE_RGB, SSX_UPLIFT_OURS, SSX_UPLIFT_MENG, SSX_UPLIFT_JH = 0, 1, 2, 3

@@ -425,7 +425,7 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	a.width = p->width; a.height = p->height;
 	a.tiles_x = (p->width + 7u) / 8u;
 	a.n_tiles = a.tiles_x * ((p->height + 7u) / 8u);
-	a.tile_first = p->tile_first; a.tile_stride = p->tile_stride;
+	a.tile_first = p->tile_first; a.tile_stride = p->tile_stride; a.tile_skew = p->tile_skew;
 	a.indirect_only = p->indirect_only ? 1u : 0u;
 	a.no_els = p->no_explicit_light_sampling ? 1u : 0u;
 	a.no_flat_field = p->no_flat_field_correction ? 1u : 0u;
@@ -474,8 +474,14 @@ int ensure_logs(ssx_ctx* ctx, uint32_t unit_cohorts) {
 	const size_t need = (size_t)ctx->max_wave_slots * 2u * unit_cohorts * SSX_COHORT_RECORDS;
 	if (need * SSX_LOG_BYTES_PER_RECORD >= ((size_t)1 << 32)) return fail(ctx, SSX_ERR_DEVICE, "level logs beyond 4 GiB: the kernels address them with 32-bit offsets");
 	if (ctx->log_records < need) {
-		// normally sized once per scene (calibrate); growing later must not pull the logs from under a queued render
-		if (ctx->d_logs) { SSX_HIP(ctx, hipDeviceSynchronize()); (void)hipFree(ctx->d_logs); }
+		// Sized once per scene for the largest unit it renders with (calibrate), so this does not happen on the enqueue path of a
+		// render; should it (a debugging variable enlarging the units), the old logs may still serve a queued render of this
+		// context: wait for THAT -- the event of ssx_render_device and the context's own stream -- not for the whole device.
+		if (ctx->d_logs) {
+			if (ctx->device_pending) { SSX_HIP(ctx, hipEventSynchronize(ctx->ev_device_done)); ctx->device_pending = false; }
+			SSX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			(void)hipFree(ctx->d_logs);
+		}
 		ctx->d_logs = nullptr; ctx->log_records = 0;
 		hipError_t e = hipMalloc((void**)&ctx->d_logs, need * SSX_LOG_BYTES_PER_RECORD);
 		if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return fail(ctx, SSX_ERR_DEVICE, fmt("out of device memory for the level logs (%zu bytes)", need * (size_t)SSX_LOG_BYTES_PER_RECORD)); }
@@ -758,7 +764,7 @@ int launch_finalize(ssx_ctx* ctx, const ssx_render_params* p, uint32_t spp, floa
 	uint32_t pixels = p->width * p->height;
 	hipLaunchKernelGGL(ssx_finalize_kernel, dim3((pixels + 255u) / 256u), dim3(256), 0, stream,
 	                   (const double*)ctx->d_accum, (float4*)d_out, p->width, p->height, (p->width + 7u) / 8u,
-	                   p->tile_first, p->tile_stride, spp, ctx->rgb_mode ? 1u : 0u, done_tiles);
+	                   p->tile_first, p->tile_stride, spp, ctx->rgb_mode ? 1u : 0u, done_tiles, p->tile_skew);
 	SSX_HIP(ctx, hipGetLastError());
 	return SSX_OK;
 }

@@ -151,6 +151,7 @@ struct SsxKernelArgs {
 	uint32_t width, height;
 	uint32_t tiles_x, n_tiles;
 	uint32_t tile_first, tile_stride;
+	uint32_t tile_skew;     // the device's tile list runs over the row-major list with tile row ty rotated by ty * tile_skew columns (tile_of_slot)
 	uint32_t k0, k1;        // sample range of this launch
 	uint32_t indirect_only;
 	uint32_t no_els;        // 1: integrator without EXPLICIT_LIGHT_SAMPLING

@@ -1311,6 +1311,18 @@ __device__ __forceinline__ void resolve_records(const Lds& L, const SsxKernelArg
 // ray[] and st[] only, and the path loop traces a camera ray like any other ray (ssx_upload_scene decides: calibrate()).
 // Record order [tile slot][k-k0][pixel in tile]: a wave writes 64 consecutive records.  Persistent workgroups (they stage
 // the scene tables into LDS for trace()) striding over the record waves.
+// The device's tile list: slot -> tile.  The walk t' = tile_first + slot * tile_stride runs over the row-major tile list with tile row ty
+// rotated by ty * tile_skew columns (ssx_render_params::tile_skew; 0: the plain list): with N devices and a tile row of a multiple of N
+// tiles the plain list hands every device vertical stripes of the image -- the outer stripes of the Cornell box are 7 % cheaper than the
+// inner ones --, the rotated one diagonals.  Returns the tile's row-major index and its column / row.
+template <typename Args>
+__device__ __forceinline__ uint32_t tile_of_slot(const Args& a, uint32_t slot, uint32_t& tx, uint32_t& ty) {
+	const uint32_t t = a.tile_first + slot * a.tile_stride;
+	ty = t / a.tiles_x;
+	const uint32_t txr = t - ty * a.tiles_x, rot = (ty * a.tile_skew) % a.tiles_x;
+	tx = txr >= rot ? txr - rot : txr + a.tiles_x - rot;
+	return ty * a.tiles_x + tx;
+}
 __device__ __forceinline__ void generate_body(const SsxKernelArgs& a) {
 	Lds L; L.w = stage_lds(a);
 	const SsxBlobHeader& h = L.hdr();
@@ -1320,8 +1332,9 @@ __device__ __forceinline__ void generate_body(const SsxKernelArgs& a) {
 	const uint64_t n_waves = a.n_records >> 6;
 	for (uint64_t sk = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); sk < n_waves; sk += (uint64_t)gridDim.x * (blockDim.x >> 6)) {
 		const uint32_t slot = (uint32_t)(sk / n_k), kk = a.k0 + (uint32_t)(sk % n_k);
-		const uint32_t tile = a.tile_first + slot * a.tile_stride;
-		const uint32_t i = (tile % a.tiles_x) * 8u + (lane & 7u), j = (tile / a.tiles_x) * 8u + (lane >> 3);
+		uint32_t tx, ty;
+		(void)tile_of_slot(a, slot, tx, ty);
+		const uint32_t i = tx * 8u + (lane & 7u), j = ty * 8u + (lane >> 3);
 		const bool inside = i < a.width && j < a.height; // lanes outside a ragged image have no record
 		float4 ray = make_float4(0.0f, 0.0f, 1.0f, 0.0f); uint4 st = make_uint4(0u, 0u, 0u, 0u);
 		if (inside) generate_sample(h, a, i, j, kk, ray, st);
@@ -1361,8 +1374,9 @@ extern "C" __global__ void __launch_bounds__(256) ssx_tile_mask_kernel(SsxKernel
 	const SsxBlobHeader& h = *reinterpret_cast<const SsxBlobHeader*>(a.blob);
 	const uint32_t slot = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
 	if (slot >= a.my_tiles) return;
-	const uint32_t tile = a.tile_first + slot * a.tile_stride;
-	const double x0 = (double)((tile % a.tiles_x) * 8u), y0 = (double)((tile / a.tiles_x) * 8u);
+	uint32_t tx, ty;
+	(void)tile_of_slot(a, slot, tx, ty);
+	const double x0 = (double)(tx * 8u), y0 = (double)(ty * 8u);
 	// corner rays counter-clockwise (as seen along the viewing direction it does not matter: the planes are oriented by the centre ray)
 	double d[4][3], c[3];
 	camera_dir(h, a, x0, y0, d[0][0], d[0][1], d[0][2]);
@@ -1429,8 +1443,8 @@ __device__ __forceinline__ void unit_setup(const SsxKernelArgs& hot, uint32_t un
 	(void)hot;
 	const __attribute__((address_space(4))) SsxKernelArgs& a = cold_args();
 	const uint32_t slot = unit % a.my_tiles, grp = unit / a.my_tiles;
-	const uint32_t tile = a.tile_first + slot * a.tile_stride;
-	const uint32_t tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+	uint32_t tx, ty;
+	const uint32_t tile = tile_of_slot(a, slot, tx, ty);
 	const uint32_t ka = a.k0 + grp * a.group_spp;
 	const uint32_t kb = min(ka + a.group_spp, a.k1);
 	u.dims = min(8u, a.width - tx * 8u) | (min(8u, a.height - ty * 8u) << 4) | ((kb - ka) << 8);
@@ -1501,7 +1515,8 @@ __device__ __forceinline__ void sums_acquire(uint32_t* cnt) {
 // behind, and go on while that one is parked too.
 __device__ __forceinline__ void sums_chain(uint32_t slot, uint32_t grp, uint32_t lane, uint32_t* cnt) {
 	const __attribute__((address_space(4))) SsxKernelArgs& a = cold_args();
-	const uint32_t tile = a.tile_first + slot * a.tile_stride, tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+	uint32_t tx, ty;
+	const uint32_t tile = tile_of_slot(a, slot, tx, ty);
 	const bool has_px = (lane & 7u) < min(8u, a.width - tx * 8u) && (lane >> 3) < min(8u, a.height - ty * 8u);
 	double* const px = a.accum + (size_t)tile * 256u + lane;
 	uint32_t* state = a.unit_state + (slot * a.n_groups + grp);
@@ -1777,13 +1792,14 @@ extern "C" __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_pe
 // done_tiles: how many of the device's tiles (ascending tile order) hold a result -- all of them, except after a stopped tile-major
 // render (ssx_render_params::tile_major), whose unfinished tiles stay zero like foreign ones.
 extern "C" __global__ void __launch_bounds__(256) ssx_finalize_kernel(const double* accum, float4* out, uint32_t width, uint32_t height,
-                                                  uint32_t tiles_x, uint32_t tile_first, uint32_t tile_stride, uint32_t spp, uint32_t rgb_mode, uint32_t done_tiles) {
+                                                  uint32_t tiles_x, uint32_t tile_first, uint32_t tile_stride, uint32_t spp, uint32_t rgb_mode, uint32_t done_tiles, uint32_t tile_skew) {
 	uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
 	if (p >= width * height) return;
 	uint32_t i = p % width, j = p / width;
-	uint32_t tile = (j >> 3) * tiles_x + (i >> 3);
+	const uint32_t tile_rm = (j >> 3) * tiles_x + (i >> 3);                                      // row-major: the tile's block of the pixel sums
+	uint32_t tile = (j >> 3) * tiles_x + ((i >> 3) + ((j >> 3) * tile_skew) % tiles_x) % tiles_x;   // its place in the (rotated) list the devices share out: tile_of_slot
 	float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	const double* const px = accum + (size_t)tile * 256u + ((j & 7u) * 8u + (i & 7u)); // [tile][component][pixel of the tile] (unit_fold)
+	const double* const px = accum + (size_t)tile_rm * 256u + ((j & 7u) * 8u + (i & 7u)); // [tile][component][pixel of the tile] (unit_fold)
 	if (tile % tile_stride != tile_first || tile / tile_stride >= done_tiles) { out[p] = o; return; }
 	if (tile % tile_stride == tile_first && rgb_mode) { // renderer.cpp:304: avg /= double(spp)
 		const double n = (double)spp;

@@ -16,11 +16,12 @@ def tile_grid(width, height):
     return (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
 
 
-def tile_owner_mask(width, height, rank, world):
-    """Boolean [H, W] mask of the pixels whose 8x8 tile (row-major index) belongs to `rank`."""
+def tile_owner_mask(width, height, rank, world, skew=0):
+    """Boolean [H, W] mask of the pixels whose 8x8 tile belongs to `rank`: tile t' of the shared-out list with t' % world == rank,
+    the list being the row-major one with tile row ty rotated by ty * skew columns (ssx_render_params.tile_skew; 0: plain)."""
     tx, _ = tile_grid(width, height)
     jj, ii = np.meshgrid(np.arange(height), np.arange(width), indexing="ij")
-    tile = (jj // TILE) * tx + (ii // TILE)
+    tile = (jj // TILE) * tx + (ii // TILE + (jj // TILE) * skew) % tx
     return (tile % world) == rank
 
 

@@ -155,6 +155,7 @@ void Renderer::render_start() {
 		p.no_explicit_light_sampling = options.explicit_light_sampling ? 0u : 1u;
 		p.no_flat_field_correction = options.flat_field_correction ? 0u : 1u;
 		p.tile_first = static_cast<uint32_t>(d); p.tile_stride = static_cast<uint32_t>(ctxs_.size());
+		p.tile_skew = ctxs_.size() > 1 ? 1u : 0u; // several devices: diagonals instead of vertical stripes of the image (include/ssx.h)
 		p.spp_per_launch = 0;
 		p.tile_major = options.tile_major ? 1u : 0u;
 		p.seed = options.seed;
@@ -250,7 +251,8 @@ void Renderer::render_wait() {
 		std::vector<float> all(xyza.size());
 		color->xyza_to_srgba(xyza.data(), all.data(), options.res[0] * options.res[1]);
 		for (size_t j = 0; j < options.res[1]; ++j) for (size_t i = 0; i < options.res[0]; ++i) {
-			const size_t tile = (j / 8) * tiles_x + i / 8, d = tile % ctxs_.size();
+			const size_t skew = ctxs_.size() > 1 ? 1 : 0;
+			const size_t tile = (j / 8) * tiles_x + (i / 8 + (j / 8) * skew) % tiles_x, d = tile % ctxs_.size(); // its place in the shared-out list (tile_skew)
 			if (tile / ctxs_.size() < done_tiles[d]) std::memcpy(framebuffer(i, j), &all[4 * (j * options.res[0] + i)], 4 * sizeof(float));
 		}
 	}

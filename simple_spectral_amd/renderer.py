@@ -56,6 +56,7 @@ class Options:
     device: int = 0
     tile_first: int = 0
     tile_stride: int = 1
+    tile_skew: int = 0                   # ssx_render_params.tile_skew: rotate tile row ty of the shared-out list by ty * tile_skew columns (diagonal instead of vertical stripes)
     spp_per_launch: int = 0
     tile_major: bool = False             # ssx_render_params.tile_major: walk through the tiles like the reference (a stopped render keeps
     #                                       finished tiles at full sample count, the rest untouched) instead of through the samples
@@ -179,6 +180,7 @@ class Renderer:
         p.no_explicit_light_sampling = int(not o.explicit_light_sampling)
         p.no_flat_field_correction = int(not o.flat_field_correction)
         p.tile_first, p.tile_stride = o.tile_first, o.tile_stride
+        p.tile_skew = o.tile_skew
         p.spp_per_launch = o.spp_per_launch
         p.tile_major = int(o.tile_major)
         p.seed = o.seed

@@ -85,16 +85,20 @@ def test_launch_chunking_and_tile_partition_do_not_change_the_image():
     for chunk in (1, 5, 12, 100):
         got, _ = gpu_render(scene_name="cornell-srgb", res=(72, 40), spp=12, seed=21, texture="test-img.png", spp_per_launch=chunk)
         assert np.array_equal(bits(got), bits(base)), chunk
-    for world in (2, 3, 8):
+    # tile_skew: the shared-out list with tile row ty rotated by ty * skew columns (diagonal instead of vertical stripes where the tile
+    # row is a multiple of the device count: 72 / 8 = 9 tiles per row and world = 3; bench.py uses skew 1)
+    for world, skew in ((2, 0), (3, 0), (8, 0), (3, 1), (8, 1), (4, 5)):
         parts = []
         for rank in range(world):
             got, _ = gpu_render(scene_name="cornell-srgb", res=(72, 40), spp=12, seed=21, texture="test-img.png",
-                                tile_first=rank, tile_stride=world)
-            mask = sdist.tile_owner_mask(72, 40, rank, world)
-            assert not got[~mask].any()                       # foreign tiles are exactly zero
+                                tile_first=rank, tile_stride=world, tile_skew=skew)
+            mask = sdist.tile_owner_mask(72, 40, rank, world, skew)
+            assert mask.any() and not got[~mask].any()        # foreign tiles are exactly zero
             assert np.array_equal(bits(got[mask]), bits(base[mask]))
             parts.append(got)
         assert np.array_equal(bits(np.sum(parts, axis=0, dtype=np.float32)), bits(base))  # what the RCCL reduce computes
+    m0, m1 = sdist.tile_owner_mask(72, 40, 0, 3, 0), sdist.tile_owner_mask(72, 40, 0, 3, 1)
+    assert m0[:, :8].all() and not m1[:, :8].all()            # plain list: rank 0 owns the whole first tile column; rotated: a diagonal
 
 
 def test_device_buffer_entry_point_matches_host_path():

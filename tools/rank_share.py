@@ -6,8 +6,11 @@ samples per pixel on each (weak scaling: per-GPU work fixed).  A rank's share to
 rank until the final reduce, so it can be run alone: render_device(tile_first=r, tile_stride=N,
 spp=spp_per_gpu*N).  What changes with N is the SHAPE of the share -- N times fewer tiles, N times
 more samples per pixel -- and with it how many units of one tile are in flight at once (the
-ordered binary64 pixel sums, ssx_kernels.hip: unit_fold).  This prints ms per step of the shares
-r = 0 and r = N-1 for N = 1, 2, 4, 8 and the predicted weak-scaling efficiency t(1) / max_r t(N, r).
+ordered binary64 pixel sums, ssx_kernels.hip: unit_fold) -- and WHICH tiles a rank owns: with the
+plain round-robin a 64-tile row gives 8 ranks vertical stripes, the outer ones 7 % cheaper than the
+inner ones; bench.py rotates the tile rows (tile_skew 1).  This prints ms per step of the shares
+(--all-ranks: every r; else r = 0 and N-1) for N = 1, 2, 4, 8 and the predicted weak-scaling
+efficiency t(1) / max_r t(N, r).
 
     python tools/rank_share.py [--configs headline,plane,cie2006] [--steps 10] [--tag NAME]
 """
@@ -35,6 +38,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--tag", default="")
     ap.add_argument("--all-ranks", action="store_true", help="every r, not only 0 and N-1")
+    ap.add_argument("--skew", type=int, default=1, help="tile_skew of the shares (bench.py: 1); 0 = vertical stripes")
+    ap.add_argument("--only-n", type=int, default=0, help="one N only, rank 0 (for counter passes: tools/pmc_share.sh)")
     args = ap.parse_args()
 
     import torch
@@ -48,11 +53,13 @@ def main():
         out = torch.zeros((res, res, 4), dtype=torch.float32, device="cuda")
         t1 = None
         for n in ns:
-            ranks = range(n) if args.all_ranks else sorted({0, n - 1})
+            if args.only_n and n != args.only_n:
+                continue
+            ranks = [0] if args.only_n else (range(n) if args.all_ranks else sorted({0, n - 1}))
             worst = 0.0
             for r in ranks:
                 rd = Renderer(Options(scene_name=scene, res=(res, res), spp=spp * n, texture="crystal-lizard-512.png", device=0,
-                                      tile_first=r, tile_stride=n, seed=0, observer=observer))
+                                      tile_first=r, tile_stride=n, tile_skew=args.skew if n > 1 else 0, seed=0, observer=observer))
                 for _ in range(args.warmup):
                     rd.render_device(out.data_ptr(), stream.cuda_stream)
                 torch.cuda.synchronize()
@@ -77,7 +84,7 @@ def main():
                         "units_parked_frac": round(sums["units_parked"] / n_units, 4), "units_chained_frac": round(sums["units_chained"] / n_units, 4), "stage_ms": stages}
                 print(json.dumps(line), flush=True)
                 out_lines.append(line)
-            if n == 1:
+            if n == 1 or t1 is None:
                 t1 = worst
             print("# %s %s N=%d: worst share %.3f ms, predicted weak-scaling efficiency t(1)/max_r t(N,r) = %.3f"
                   % (args.tag, name, n, worst, t1 / worst), flush=True)
