@@ -272,8 +272,9 @@ int ssx_scratch_info(ssx_ctx* ctx, uint64_t* sample_bytes, uint64_t* log_bytes);
 /* How the ordered binary64 pixel sums (src/renderer.cpp:292-295: a pixel's samples are added in ascending k) went, counted since
  * ssx_create: work units of the path kernel (8x8 tile x 4 or 8 consecutive samples) that finished before their tile's turn had
  * reached them and parked their samples instead of waiting, and how many of those were then added by the wave in front of them
- * (the rest found, on a second look, that their turn had come).  No wave ever waits for another; a large count is normal for a
- * device that owns few tiles at many samples per pixel (a rank of a multi-GPU render).  Waits for a queued ssx_render_device. */
+ * (the rest had been given the turn before their mark was in place, and added themselves).  No wave ever waits for another; a
+ * large count is normal for a device that owns few tiles at many samples per pixel (a rank of a multi-GPU render: three quarters
+ * of the units at 512 tiles x 2048 samples).  Waits for a queued ssx_render_device. */
 int ssx_sums_info(ssx_ctx* ctx, uint64_t* units_parked, uint64_t* units_chained);
 /* Which path kernel the uploaded scene runs: 0 = the generic one (pass 1 of the intersection loops over the
  * quads), 1 / 2 = the kernel whose pass 1 is specialised to the mesh topology of the reference's Cornell box /

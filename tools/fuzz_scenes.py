@@ -27,6 +27,8 @@ def main():
         g = np.random.default_rng(77 + seed)                                   # image shape, samples and launch chunking vary too
         W, H, spp = int(g.integers(1, 71)), int(g.integers(1, 61)), int(g.integers(1, 10))
         r.options.spp_per_launch = int(g.integers(0, spp + 1))                  # 0: the library's choice
+        r.options.tile_major = bool(g.integers(0, 2))                           # the order of the work: through the samples / through the tiles
+        r.options.tile_skew = int(g.integers(0, 4))                             # ... and of the tile list (one device: the order of the units only)
         samples += W * H * spp
         r.options.res = (W, H); r.options.spp = spp; r.options.seed = seed
         r.options.indirect_only = o["indirect_only"]; r.options.explicit_light_sampling = o["els"]; r.options.flat_field_correction = o["flat_field"]

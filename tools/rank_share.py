@@ -63,12 +63,15 @@ def main():
                 for _ in range(args.warmup):
                     rd.render_device(out.data_ptr(), stream.cuda_stream)
                 torch.cuda.synchronize()
+                first = out.clone()  # every later step must reproduce it bit for bit: the hand-over of the pixel sums under real contention
                 t0 = time.perf_counter()
                 for _ in range(args.steps):
                     rd.render_device(out.data_ptr(), stream.cuda_stream)
                 torch.cuda.synchronize()
                 ms = (time.perf_counter() - t0) / args.steps * 1e3
                 worst = max(worst, ms)
+                if not torch.equal(out.view(torch.int32), first.view(torch.int32)):
+                    raise SystemExit("rank share N=%d r=%d: the image changed from one step to the next" % (n, r))
                 sums = rd.sums_info()
                 rd.set_timing(True)  # three more steps with HIP events around the kernels: which one carries a difference
                 for _ in range(3):
