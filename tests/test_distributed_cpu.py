@@ -24,7 +24,7 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     o = ol.Oracle("cornell-srgb", texture="test-img.png")
     full = o.render(W, H, SPP, seed=5, nthreads=1)
-    mine = np.where(sdist.tile_owner_mask(W, H, rank, world)[..., None], full, np.float32(0))
+    mine = np.where(sdist.tile_owner_mask(W, H, rank, world, skew=1)[..., None], full, np.float32(0))   # (bench.py's partition: tile rows rotated)
     t = torch.from_numpy(np.ascontiguousarray(mine))
     sdist.reduce_framebuffer(t, dst=0)
     if rank == 0:
@@ -34,12 +34,17 @@ def _worker(rank, world, port, q):
 
 
 def test_tile_partition_is_a_partition():
-    for world in (1, 2, 3, 4, 8):
-        masks = [sdist.tile_owner_mask(100, 61, r, world) for r in range(world)]
-        assert np.array_equal(np.sum(masks, axis=0), np.ones((61, 100)))
-        # 8x8 granularity
-        m = masks[0]
-        assert m[:8, :8].all() or not m[:8, :8].any()
+    for skew in (0, 1, 3):
+        for world in (1, 2, 3, 4, 8):
+            masks = [sdist.tile_owner_mask(100, 61, r, world, skew) for r in range(world)]
+            assert np.array_equal(np.sum(masks, axis=0), np.ones((61, 100)))
+            # 8x8 granularity
+            m = masks[0]
+            assert m[:8, :8].all() or not m[:8, :8].any()
+    # 64 tiles per row and 8 ranks: the plain list gives rank 0 whole tile columns, the rotated one a share of every column
+    plain, rotated = sdist.tile_owner_mask(512, 512, 0, 8, 0), sdist.tile_owner_mask(512, 512, 0, 8, 1)
+    assert set(plain.sum(axis=0)) == {0, 512} and set(rotated.sum(axis=0)) == {64}
+    assert plain.sum() == rotated.sum() == 512 * 512 // 8
 
 
 def test_two_rank_gloo_reduce_reassembles_the_image():
