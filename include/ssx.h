@@ -222,6 +222,13 @@ int ssx_render_wait(ssx_ctx* ctx, float* xyza_out);
  * width*height float4 (no host synchronisation; used when the framebuffer stays on the GPU, e.g.
  * for the RCCL reduce).  hip_stream is a hipStream_t (NULL = default stream). */
 int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* params, void* d_xyza_out, void* hip_stream);
+/* ssx_render_device only enqueues -- fills and kernels on hip_stream, no allocation and no synchronisation once the context's
+ * buffers have the size the render needs -- so it may be called on a stream that is being captured into a hipGraph (launch-bound
+ * small renders).  Then: run the same render once outside the capture first (sizes the buffers), let earlier renders of the context
+ * finish before the capture (ssx_render_device_wait), do not time it (ssx_set_timing), and order the graph's replays against every
+ * other use of the context yourself; otherwise SSX_ERR_STATE. */
+/* Waits on the host for the work ssx_render_device has queued for this context (the caller's streams are not touched otherwise). */
+int ssx_render_device_wait(ssx_ctx* ctx);
 
 /* ssx_render_start's result stays in a context-owned DEVICE buffer; these give the C++ host's multi-GPU
  * combine access to it (north_star: "final reduce over xGMI of the per-GPU framebuffer"; the reference

@@ -418,7 +418,7 @@ constexpr uint32_t kMinUnits = 3072;                   // one wave work unit per
 
 struct LaunchPlan { SsxKernelArgs args; size_t lds_bytes; uint32_t max_spp_per_launch; };
 
-LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
+LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p, bool ask_device = true) {
 	LaunchPlan pl{};
 	SsxKernelArgs& a = pl.args;
 	a.blob = ctx->d_blob; a.blob_words = ctx->path_blob_words;
@@ -438,7 +438,7 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p) {
 	size_t per_spp = (size_t)(a.my_tiles ? a.my_tiles : 1u) * 64u * kBytesPerSampleInFlight;
 	// the budget, or 80 % of what is free on the device right now (plus what this context already holds)
 	size_t budget = kSampleBufferBudget, free_b = 0, total_b = 0;
-	if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+	if (ask_device && hipMemGetInfo(&free_b, &total_b) == hipSuccess) { // (not while the stream is being captured: the buffers have their size then)
 		const size_t avail = (size_t)((double)(free_b + ctx->sample_slots * kBytesPerSampleInFlight) * 0.8);
 		if (avail < budget) budget = avail;
 	}
@@ -1076,19 +1076,28 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	// earlier call (possibly on another stream) has to finish first.  Stream-ordered, no host wait -- unless
 	// a buffer has to grow, which frees the old one.
 	if (!ctx->ev_device_done) SSX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_device_done, hipEventDisableTiming));
+	// The call may be recorded into a hipGraph (the stream is capturing): then nothing outside the capture can be waited for or
+	// signalled from here -- an earlier render of this context must have completed, the buffers must have their size (render once
+	// outside the capture first), and ordering the graph's replays against other uses of the context is the caller's business.
+	hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+	(void)hipStreamIsCapturing(stream, &capture);
+	const bool capturing = capture == hipStreamCaptureStatusActive;
+	if (ctx->device_pending && capturing) return fail(ctx, SSX_ERR_STATE, "a render of this context may still be queued: ssx_render_device_wait before capturing another into a graph");
 	if (ctx->device_pending) SSX_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_device_done, 0));
 	{
-		LaunchPlan probe = make_plan(ctx, p);
+		LaunchPlan probe = make_plan(ctx, p, !capturing);
 		const size_t need = (size_t)probe.args.my_tiles * 64u * (p->spp < probe.max_spp_per_launch ? p->spp : probe.max_spp_per_launch);
-		if (ctx->device_pending && (ctx->accum_pixels < accum_slots(p->width, p->height) || ctx->sample_slots < need)) {
+		const bool grow = ctx->accum_pixels < accum_slots(p->width, p->height) || ctx->sample_slots < need;
+		if (grow && capturing) return fail(ctx, SSX_ERR_STATE, "the context's buffers have to grow for this render: run it once outside the stream capture first");
+		if (ctx->device_pending && grow) {
 			SSX_HIP(ctx, hipEventSynchronize(ctx->ev_device_done));
 			ctx->device_pending = false;
 		}
 	}
 	if ((rc = ensure_buffers(ctx, p->width, p->height, false))) return rc;
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, accum_slots(p->width, p->height) * 4 * sizeof(double), stream));
-	maybe_swap_jit(ctx, (uint64_t)p->width * p->height * p->spp / p->tile_stride);
-	LaunchPlan pl = make_plan(ctx, p);
+	if (!capturing) maybe_swap_jit(ctx, (uint64_t)p->width * p->height * p->spp / p->tile_stride);
+	LaunchPlan pl = make_plan(ctx, p, !capturing);
 	// one batch when the whole render fits the buffer budget, else batches back to back
 	uint32_t batch = p->spp_per_launch ? p->spp_per_launch : p->spp;
 	if (batch > p->spp) batch = p->spp;
@@ -1096,8 +1105,20 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	if ((rc = ensure_samples(ctx, pl, batch))) return rc;
 	if ((rc = launch_batches(ctx, pl, p->spp, batch, stream))) return rc;
 	if ((rc = launch_finalize(ctx, p, p->spp, (float*)d_xyza_out, stream))) return rc;
-	SSX_HIP(ctx, hipEventRecord(ctx->ev_device_done, stream));
-	ctx->device_pending = true;
+	if (!capturing) {
+		SSX_HIP(ctx, hipEventRecord(ctx->ev_device_done, stream));
+		ctx->device_pending = true;
+	}
+	return SSX_OK;
+}
+
+int ssx_render_device_wait(ssx_ctx* ctx) {
+	if (!ctx) return SSX_ERR_ARG;
+	if (ctx->device_pending) {
+		SSX_HIP(ctx, hipSetDevice(ctx->device));
+		SSX_HIP(ctx, hipEventSynchronize(ctx->ev_device_done));
+		ctx->device_pending = false;
+	}
 	return SSX_OK;
 }
 

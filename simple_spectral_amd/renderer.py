@@ -220,6 +220,10 @@ class Renderer:
         p = self.params(**over)
         self._check(self._lib.ssx_render_device(self._ctx, C.byref(p), C.c_void_p(d_ptr), C.c_void_p(stream)))
 
+    def render_device_wait(self):
+        """ssx_render_device_wait: host wait for what render_device has queued for this context."""
+        self._check(self._lib.ssx_render_device_wait(self._ctx))
+
     def set_jit(self, mode=_capi.SSX_JIT_AT_UPLOAD):
         """ssx_set_jit: SSX_JIT_OFF / SSX_JIT_AT_UPLOAD / SSX_JIT_BACKGROUND (True / False: at upload / off)."""
         self._check(self._lib.ssx_set_jit(self._ctx, int(mode)))

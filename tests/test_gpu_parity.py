@@ -742,3 +742,30 @@ def test_rccl_communicators_are_kept_between_combines():
     assert lib.ssx_rccl_groups_made() == before + 2
     r2.close()                                      # releases its communicator; the first context's is untouched
     assert lib.ssx_reduce_rccl(ctxs, 1, 32, 24) == 0 and lib.ssx_rccl_groups_made() == before + 2
+
+
+def test_render_device_can_be_captured_in_a_hip_graph():
+    """ssx_render_device only enqueues (no allocation or device-wide synchronisation on its path once the buffers are
+    sized): a render can be captured into a hipGraph and replayed -- the launch-bound small renders (BASELINE configs[0]: five
+    kernels and three fills in 0.4 ms) are what that is for.  The replayed image is the oracle's, every time."""
+    import torch
+    W, H, spp = 128, 128, 16
+    r = Renderer(Options(scene_name="cornell-srgb", res=(W, H), spp=spp, seed=3, texture="test-img.png"))
+    ref = ol.Oracle("cornell-srgb", texture="test-img.png").render(W, H, spp, seed=3)
+    out = torch.zeros((H, W, 4), device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        r.render_device(out.data_ptr(), side.cuda_stream)          # sizes every buffer (and asks the occupancy calculator) outside the capture
+        r.render_device_wait()                                     # nothing of this context is queued any more
+        assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            r.render_device(out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
+    r.render_device(out.data_ptr(), torch.cuda.current_stream().cuda_stream)   # and the context still renders the plain way
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
