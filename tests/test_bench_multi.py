@@ -46,7 +46,7 @@ def test_bench_one_rank_through_rccl(tmp_path):
     """the RCCL branch executed for real on the 1-GPU box -- `--gpus 1` with
     SSX_BENCH_FORCE_DIST=1 initialises the nccl (= RCCL) process group with world size 1 on this device and
     runs the framebuffer reduce on the DEVICE buffer inside the timed loop, next to libssx_hip.so in one
-    process (torch's HIP runtime first, INTEGRATION.md).  The combined image equals the oracle's."""
+    process (one HIP runtime: simple_spectral_amd/_capi.py).  The combined image equals the oracle's."""
     dump = str(tmp_path / "img.npy")
     env = dict(os.environ, SSX_BENCH_FORCE_DIST="1", SSX_BENCH_DUMP=dump)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SSX_BENCH_TEST_ONE_GPU"):
