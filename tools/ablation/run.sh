@@ -1,6 +1,7 @@
 #!/bin/bash
 # Time budget of the path kernel by ablation / doubling (timing only: most variants render wrong images).
-#   git apply tools/ablation/time_budget.patch      # adds the ABL_* switches to csrc/ssx_kernels.hip (made against the commit that added this file)
+#   git apply tools/ablation/time_budget.patch      # adds the ABL_* switches to csrc/ssx_kernels.hip -- made against round 3's kernel (commit ad8295a: apply it in a
+#                                                   # worktree of that commit; it does not apply to the round-4 source, whose fold and hand-over were rewritten)
 #   tools/ablation/run.sh build                     # here: one library per switch
 #   gpurun -- 'tools/ablation/run.sh bench'         # on the GPU box: product and every variant, twice, on one box
 # A variant is only a measurement if it leaves the path structure alone (same rays, same shading decisions): removing code

@@ -1,9 +1,9 @@
 #!/bin/bash
-# round 4 closing run on the GPU box: whole GPU suite, bench line, rocprofv3 stats + counters, lane statistics, run-time specialisation
-O=gpurun_out/r04_final; mkdir -p $O
+# closing run of a round on the GPU box (tools/closing_run.sh <tag>): whole GPU suite, bench line, rocprofv3 stats + counters, lane statistics, run-time specialisation
+O=gpurun_out/${1:-closing}; mkdir -p $O
 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -E " passed| failed" $O/pytest_gpu.log | tail -1
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; python -c "
 import json; d=json.load(open('$O/bench.json')); print({k:d[k] for k in ('value','ms_per_step','value_device_resident')}, d['roofline']['frac'], d['roofline']['stage_ms'], d['cpu_baseline']['value'])"
-bash tools/profile_round.sh r04end > $O/profile_round.log 2>&1; tail -2 $O/profile_round.log | cut -c1-200
+bash tools/profile_round.sh ${1:-closing}_prof > $O/profile_round.log 2>&1; tail -2 $O/profile_round.log | cut -c1-200
 python tools/lanestat.py > $O/lanestat.log 2>&1; tail -22 $O/lanestat.log
 python tools/jit_rate.py > $O/jit_rate.log 2>&1; tail -3 $O/jit_rate.log | cut -c1-300
