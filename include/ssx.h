@@ -352,7 +352,8 @@ enum {
 	SSX_SWEEP_ACOS_SIN = 10,   /* |x| <= 1: fused {min(acos x, under_pi), its sine} vs ssx_acosf / ssx_sinf; result[1] = inputs sent to the fallback */
 	/* include/ssx_fmath.h against an INDEPENDENT evaluation (csrc/ssx_ddmath.h: double-double Taylor series, three-part pi/2, Newton on
 	 * the cosine -- nothing shared with the header), every float pattern: result[0] = inputs where ssx_*f is not the correctly rounded
-	 * value the independent evaluation decides on (or not NaN outside the domain), result[1] = inputs whose value lies within 2^-70 of a
+	 * value the independent evaluation decides on (or not NaN outside the domain; for sin and cos also: where ssx_sincosf returns another
+	 * float than ssx_sinf / ssx_cosf), result[1] = inputs whose value lies within 2^-70 of a
 	 * float rounding boundary, which it does not decide; examples (result[3..]): the input pattern, | 1 << 32 for an undecided one */
 	SSX_SWEEP_SIN_PROOF = 11, SSX_SWEEP_COS_PROOF = 12, SSX_SWEEP_ACOS_PROOF = 13
 };

@@ -76,6 +76,15 @@ extern "C" __global__ void __launch_bounds__(256) ssx_debug_sweep_kernel(SsxKern
 		case SSX_SWEEP_SIN_PROOF: case SSX_SWEEP_COS_PROOF: case SSX_SWEEP_ACOS_PROOF: { // ssx_fmath.h against csrc/ssx_ddmath.h
 			const bool arc = op == SSX_SWEEP_ACOS_PROOF;
 			const float got = op == SSX_SWEEP_SIN_PROOF ? ssx_sinf(x) : (arc ? ssx_acosf(x) : ssx_cosf(x));
+			if (!arc) { // ssx_sincosf (what the samplers call) returns the same two floats as ssx_sinf and ssx_cosf, for every input
+				float sc_s, sc_c;
+				ssx_sincosf(x, &sc_s, &sc_c);
+				if (!same_float(op == SSX_SWEEP_SIN_PROOF ? sc_s : sc_c, got)) {
+					atomicAdd(&res[0], 1ull);
+					const unsigned long long slot = atomicAdd(&res[2], 1ull);
+					if (slot < 8ull) res[3 + slot] = bits;
+				}
+			}
 			if (!(__builtin_fabsf(x) <= (arc ? 1.0f : 0x1p20f))) { ok = got != got; break; } // outside the domain (and NaN): NaN
 			int decided = 1;
 			const float want = op == SSX_SWEEP_SIN_PROOF ? ssx_dd::sin_f32(x, &decided) : (arc ? ssx_dd::acos_f32(x, acos((double)x), &decided) : ssx_dd::cos_f32(x, &decided));

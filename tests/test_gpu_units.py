@@ -207,7 +207,8 @@ def test_fmath_header_proved_against_an_independent_evaluation(cornell, op, name
     nothing about the header itself, and its only outside check was ~50 k mpmath inputs.  Here EVERY ONE of the 2^32 float
     patterns goes through ssx_sinf / ssx_cosf / ssx_acosf and through csrc/ssx_ddmath.h -- double-double Taylor series,
     three-part pi/2, Newton on the cosine: nothing shared with the header; pinned against mpmath by tests/test_fmath.py -- on the
-    device: the header returns the correctly rounded value (NaN outside its domain) for every input but the five listed below,
+    device: the header returns the correctly rounded value (NaN outside its domain) for every input but the five listed below (and
+    ssx_sincosf, which the samplers call, the same two floats as ssx_sinf and ssx_cosf for every input),
     and the inputs the independent evaluation cannot decide (within 2^-70 of a rounding boundary), if any, are settled with mpmath."""
     import mpmath as mp
     import oracle_lib as ol
