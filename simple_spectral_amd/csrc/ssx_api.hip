@@ -1071,7 +1071,6 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	if (ctx->rendering.load()) return fail(ctx, SSX_ERR_STATE, "asynchronous render in progress");
 	hipStream_t stream = (hipStream_t)hip_stream;
 	SSX_HIP(ctx, hipSetDevice(ctx->device));
-	size_t pixels = (size_t)p->width * p->height;
 	// the context's accumulators and per-sample arrays are shared by all renders: a render still queued by an
 	// earlier call (possibly on another stream) has to finish first.  Stream-ordered, no host wait -- unless
 	// a buffer has to grow, which frees the old one.
@@ -1344,7 +1343,6 @@ int ssx_debug_samples(ssx_ctx* ctx, const ssx_render_params* p, float* xyza, uin
 	if (p->tile_first != 0 || p->tile_stride != 1) return fail(ctx, SSX_ERR_ARG, "ssx_debug_samples renders the whole image");
 	SSX_HIP(ctx, hipSetDevice(ctx->device));
 	if (ctx->device_pending) { SSX_HIP(ctx, hipEventSynchronize(ctx->ev_device_done)); ctx->device_pending = false; }
-	const size_t pixels = (size_t)p->width * p->height;
 	if ((rc = ensure_buffers(ctx, p->width, p->height, false))) return rc;
 	LaunchPlan pl = make_plan(ctx, p);
 	if (p->spp > pl.max_spp_per_launch) return fail(ctx, SSX_ERR_ARG, "ssx_debug_samples: too many samples for one launch");
