@@ -235,6 +235,14 @@ def main():
     test_one_gpu = os.environ.get("SSX_BENCH_TEST_ONE_GPU") == "1"
     if test_one_gpu:
         local_rank = 0
+    # A launcher that gives every rank its own visible device (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per process) leaves each
+    # rank with ONE device, number 0, whatever its LOCAL_RANK: take the device that exists.  Fewer devices than ranks otherwise: say so.
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev:
+        if n_dev == 1 and world > 1:
+            local_rank = 0
+        else:
+            raise SystemExit("bench.py: LOCAL_RANK %d but %d visible device(s)" % (local_rank, n_dev))
     torch.cuda.set_device(local_rank)
     # SSX_BENCH_FORCE_DIST=1: with --gpus 1 still initialise RCCL (world size 1) and run the framebuffer reduce on
     # the device buffer inside the timed loop -- the N>1 code path (process group on this device, reduce on torch's
