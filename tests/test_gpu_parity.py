@@ -604,6 +604,47 @@ def test_pass1_compiled_at_upload_for_any_topology():
     assert rt.plan_info()["pass1"] == "generic"
 
 
+def test_two_threads_asking_for_the_same_pattern_compile_it_once(tmp_path):
+    """csrc/ssx_jit.h `get`: two contexts upload the same new mesh pattern at the same moment, both asking for the compilation on
+    the calling thread (ssx_set_jit mode 1); one of them compiles, the other waits for that code object."""
+    import threading
+    import custom_scene as cs
+    old = os.environ.get("SSX_CACHE_DIR")
+    os.environ["SSX_CACHE_DIR"] = str(tmp_path / "cache")
+    try:
+        lib = _capi.hip_lib()
+        counters = lambda: (lambda a, b: (lib.ssx_jit_counters(C.byref(a), C.byref(b)), (a.value, b.value))[1])(C.c_uint64(), C.c_uint64())
+        c = cs.CustomScene("cornell-srgb")
+        pos, st, m = c.quads[2]
+        pos = pos.copy(); pos[3, 1] += 0.25                 # a pattern of this test's own
+        c.quads[2] = (pos, st, m)
+        orc = c.oracle()
+        desc = c.desc(orc)
+        rs = [Renderer(Options(scene_name="cornell-srgb", res=(24, 16), spp=3, seed=8, texture="test-img.png", jit_pass1=True)) for _ in range(2)]
+        compiled0, hits0 = counters()
+        go = threading.Barrier(2)
+        errors = []
+        def upload(r):
+            try:
+                go.wait(); r.upload_scene_desc(desc)
+            except Exception as e:                          # noqa: BLE001 -- reported below
+                errors.append(e)
+        threads = [threading.Thread(target=upload, args=(r,)) for r in rs]
+        [t.start() for t in threads]; [t.join() for t in threads]
+        assert not errors, errors
+        assert counters() == (compiled0 + 1, hits0)
+        ref = orc.render(24, 16, 3, seed=8)
+        for r in rs:
+            assert r.jit_status() == (_capi.SSX_JIT_STATE_SPECIALISED, "") and r.plan_info()["kernel"] == "ssx_render_kernel_jit"
+            r.render_start(); r.render_wait()
+            assert np.array_equal(bits(r.xyza), bits(ref))
+    finally:
+        if old is None:
+            os.environ.pop("SSX_CACHE_DIR", None)
+        else:
+            os.environ["SSX_CACHE_DIR"] = old
+
+
 _JIT_CHILD = r"""
 import os, sys, time, json
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
