@@ -14,8 +14,9 @@ renders its tiles at spp = 256*N (per-GPU work fixed -> weak scaling) into a zer
 full-size float4 XYZA buffer on its GPU, and one RCCL reduce(sum) to rank 0 combines them (x+0
 is exact, so the sum is the image).  Inputs (scene tables, texture) are resident in HBM before the
 timed region; the timed region is K x (render [+ reduce] + copy of the combined XYZA image into pinned host memory on
-rank 0): the metric as SURVEY.md section 8(d) defines it ("framebuffer reduce + D2H of XYZA included").  The same K steps
-without the copy are timed afterwards and reported as value_device_resident.
+rank 0): the metric as SURVEY.md section 8(d) defines it ("framebuffer reduce + D2H of XYZA included").  The copies run on their
+own stream between two device and two host images, so step k's image travels while step k+1 renders; all K images are in host
+memory when the timed region ends.  The same K steps without the copy are timed afterwards and reported as value_device_resident.
 
 Prints ONE JSON line on rank 0.
 """
@@ -269,46 +270,61 @@ def main():
     out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
 
-    def reduce_to_rank0():
+    def reduce_to_rank0(img):
         # the one exchange step of the path: sum of the per-rank framebuffers (RCCL over xGMI)
         if test_one_gpu:
-            h = out.cpu()
+            h = img.cpu()
             dist.reduce(h, dst=0, op=dist.ReduceOp.SUM)
-            out.copy_(h)
+            img.copy_(h)
         else:
-            dist.reduce(out, dst=0, op=dist.ReduceOp.SUM)
+            dist.reduce(img, dst=0, op=dist.ReduceOp.SUM)
 
     def step():
         r.render_device(out.data_ptr(), stream.cuda_stream)
         if use_dist:
-            reduce_to_rank0()
+            reduce_to_rank0(out)
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # rank 0's copy of the combined image in pinned host memory: part of every timed step
-    host_img = torch.empty((H, W, 4), dtype=torch.float32, pin_memory=True) if rank == 0 else None
+    # rank 0's copy of the combined image in pinned host memory: part of every timed step.  Two device images and two
+    # host images, the copies on a stream of their own: step k's image travels while step k+1 renders (the render stream waits for
+    # the copy that last read the image it is about to overwrite); the closing fence waits for the last copy.
+    outs = [out, torch.zeros_like(out)]
+    host_imgs = [torch.empty((H, W, 4), dtype=torch.float32, pin_memory=True) for _ in range(2)] if rank == 0 else None
+    copy_stream = torch.cuda.Stream() if rank == 0 else None
+    img_ready = [torch.cuda.Event() for _ in range(2)]
+    img_copied = [None, None]
 
-    for _ in range(args.warmup):
-        step()
+    def host_step(k):
+        # one step of the metric: render [+ reduce] into image k & 1, then its copy to the host behind it on the copy stream
+        img = outs[k & 1]
+        if img_copied[k & 1] is not None:
+            stream.wait_event(img_copied[k & 1])
+        r.render_device(img.data_ptr(), stream.cuda_stream)
+        if use_dist:
+            reduce_to_rank0(img)
+        if rank == 0:
+            img_ready[k & 1].record(stream)
+            copy_stream.wait_event(img_ready[k & 1])
+            with torch.cuda.stream(copy_stream):
+                host_imgs[k & 1].copy_(img, non_blocking=True)
+                img_copied[k & 1] = torch.cuda.Event()
+                img_copied[k & 1].record(copy_stream)
+
+    for k in range(args.warmup):  # the same step as the timed ones (the first copy on a new stream sets up its queue)
+        host_step(k)
     fence()
     r.set_timing(True)  # HIP events on the launch stream around each kernel of the pipeline
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record(stream)
-        r.render_device(out.data_ptr(), stream.cuda_stream)
-        ev[k][1].record(stream)
-        if use_dist:
-            reduce_to_rank0()
-        if rank == 0:
-            host_img.copy_(out, non_blocking=True)
+        host_step(k)
     fence()
     elapsed = time.perf_counter() - t0
-    pipeline_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
     stage_ms = {k: v / max(args.steps, 1) for k, v in r.get_timing().items()}
+    pipeline_ms = sum(stage_ms.values())  # the kernels of a step, first to last (events without a system fence: csrc/ssx_api.hip timing_events)
     r.set_timing(False)
     # The same K steps without the copy to the host (rounds 1-3 reported this figure as `value`): value_device_resident.
     fence()

@@ -520,7 +520,8 @@ int timing_events(ssx_ctx* ctx, hipEvent_t** out) {
 	if (ctx->ev_used + 6 > 6 * 64) { int r = collect_timing(ctx); if (r) return r; }
 	while (ctx->ev_pool.size() < ctx->ev_used + 6) {
 		hipEvent_t e;
-		SSX_HIP(ctx, hipEventCreate(&e));
+		// timing only: without the system-scope fence (cache write-back + invalidation) a default event puts between two kernels
+		SSX_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableSystemFence));
 		ctx->ev_pool.push_back(e);
 	}
 	*out = &ctx->ev_pool[ctx->ev_used];
