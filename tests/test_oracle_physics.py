@@ -39,8 +39,8 @@ def _box(c, m, lo=-100.0, hi=100.0):
     c.add_quad((h, l, h), (l, l, h), (l, h, h), (h, h, h), m)
 
 
-def _furnace(rho):
-    c = cs.CustomScene("cornell", keep_quads=False)
+def _furnace(rho, observer=1931):
+    c = cs.CustomScene("cornell", observer=observer, keep_quads=False)
     _box(c, _flat_materials(c, rho, 1.0))
     c.set_camera((30.0, -20.0, 10.0), (-100.0, 40.0, 90.0), up=(0, 1, 0), vfov_deg=70.0)
     return c.oracle()
@@ -240,3 +240,46 @@ def test_light_sampling_is_uniform_in_solid_angle_with_the_stated_pdf():
         for l in lights:
             n0, n1 = total[2 * l], total[2 * l + 1]
             assert abs(n0 - n1) < 4.5 * np.sqrt(n0 + n1)
+
+
+def test_flat_radiance_gives_the_integrals_of_the_colour_matching_functions():
+    """Hero-wavelength sampling (src/renderer.cpp:138), the table lookups (src/spectrum.cpp:39-67) and flux -> XYZ (src/renderer.cpp:266-273
+    with the 0.001 / 1000 scaling of :292-298): for radiance 1 at every wavelength the expected pixel is (int xbar, int ybar, int zbar) d lambda
+    -- the trapezoid sums of the observer's table, computed here from the data file, not through the oracle."""
+    import os
+    data = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+    for observer, name, step in ((1931, "cie1931-xyzbar-380+5+780.csv", 5.0), (2006, "cie2006-xyzbar-390+1+830.csv", 1.0)):
+        tab = np.loadtxt(os.path.join(data, name), delimiter=",")
+        want = step * (tab.sum(axis=0) - 0.5 * (tab[0] + tab[-1]))
+        img = _furnace(0.0, observer).render(64, 64, 64, seed=5).astype(np.float64)
+        px = img[..., :3].reshape(-1, 3)
+        mean, se = px.mean(axis=0), px.std(axis=0, ddof=1) / np.sqrt(len(px))
+        assert (se < 2e-3 * want).all(), (observer, se)
+        assert (np.abs(mean - want) < 4.0 * se + 1e-5 * want).all(), (observer, mean, want, se)
+
+
+def test_cosine_hemisphere_sampler_and_the_local_frame():
+    """rand_coshemi (src/util/random.cpp:33-41, :128-151) and get_rotated_to (src/util/math-helpers.hpp): unit vectors in the upper hemisphere,
+    pdf = cos(theta) / pi, moments of the cosine density about the local y axis -- the reference's 'up' -- (E[y] = 2/3, E[y^2] = 1/2, E[x] = E[z] = 0,
+    E[x^2] = E[z^2] = 1/4), and the rotation takes the local y axis onto the normal keeping lengths and the angle to it."""
+    import ctypes as C
+    import oracle_lib as ol
+    lib = ol.load()
+    rng = ol.Rng(); lib.orc_seed_sample(3, 1, 4, C.byref(rng))
+    N = 40000
+    w = np.zeros((N, 3)); pdf = np.zeros(N)
+    g = np.random.default_rng(2)
+    for i in range(N):
+        p = C.c_float()
+        v = lib.orc_rand_coshemi(C.byref(rng), C.byref(p))
+        w[i] = (v.x, v.y, v.z); pdf[i] = p.value
+        if i < 2000:
+            n = g.normal(size=3); n = (n / np.linalg.norm(n)).astype(np.float32)
+            r = lib.orc_get_rotated_to(v, ol.V3(*map(float, n)))
+            R = np.array((r.x, r.y, r.z))
+            assert abs(np.linalg.norm(R) - 1.0) < 1e-5 and abs(R @ n.astype(np.float64) - v.y) < 1e-5, (n, w[i], R)
+    assert np.abs(np.linalg.norm(w, axis=1) - 1.0).max() < 1e-5 and (w[:, 1] >= 0).all()
+    assert np.abs(pdf - w[:, 1] / np.pi).max() < 1e-6
+    for got, want, sd in ((w[:, 1].mean(), 2 / 3, np.sqrt(1 / 18)), ((w[:, 1] ** 2).mean(), 0.5, np.sqrt(1 / 12)),
+                          (w[:, 0].mean(), 0.0, 0.5), (w[:, 2].mean(), 0.0, 0.5), ((w[:, 0] ** 2).mean(), 0.25, 0.25), ((w[:, 2] ** 2).mean(), 0.25, 0.25)):
+        assert abs(got - want) < 4.5 * sd / np.sqrt(N), (got, want)
