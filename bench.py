@@ -18,7 +18,11 @@ rank 0): the metric as SURVEY.md section 8(d) defines it ("framebuffer reduce + 
 own stream between two device and two host images, so step k's image travels while step k+1 renders; all K images are in host
 memory when the timed region ends.  The same K steps without the copy are timed afterwards and reported as value_device_resident.
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0 -- and only for an image that passed: the last timed step's image (from pinned host memory) is compared
+with the CPU oracle on six 8x8 tiles at full spp ("check"), every rank's record is gathered ("ranks": device uuid / bus id, hostname, ms per
+step, path kernel ms, share of parked units), two ranks on one device or overlapping rank images end the run without a line ("distributed"),
+and at N = 1 the HBM traffic of the path and generate kernels is measured in the run by two rocprofv3 --pmc passes over a child run of the
+same workload (roofline.traffic; replayed from profiles/traffic.json with a staleness stamp when counters are unavailable).
 """
 import argparse
 import json
@@ -145,25 +149,168 @@ def cpu_baseline(scene, W, H, texture, target_seconds=10.0):
                      "box": pr["host"], "source": "tools/port_vs_reference_probe.py in the build container; reference side: survey probe of the reference binary there (BASELINE.md section 2)"}
     except Exception:
         pass
-    return {"value": round(rate, 4), "unit": "Msamples/s", "cores": cores, "kind": "port", "vs_reference_probe": probe,
+    # The number BASELINE.md section 4 wants next to the GPU figure is the REFERENCE's rate on these cores: the port's measured rate divided
+    # by the port/reference ratio of the probe (multi-thread figure, taken at the probe's thread count: the ratio is flat from 1 to 8 threads)
+    ref_equiv = None
+    if probe:
+        ref_equiv = {"value": round(rate / probe["port_over_ref_eight_threads"], 4), "unit": "Msamples/s", "cores": cores,
+                     "port_over_ref": probe["port_over_ref_eight_threads"], "probe_threads": 8, "probe_box": probe["box"],
+                     "how": "cpu_baseline.value / port_over_ref (the reference binary itself cannot run on the GPU box: it needs GLM and /root/reference)"}
+    return {"value": round(rate, 4), "unit": "Msamples/s", "cores": cores, "kind": "port", "reference_equivalent": ref_equiv, "vs_reference_probe": probe,
             "one_thread": round(rate1, 4), "scaling_efficiency": round(rate / (rate1 * cores), 3),
             "efficiency_vs_physical_cores": round(rate / (rate1 * min(cores, phys)), 3), "host": info,
             "sample": "%s %dx%d spp=%d (%.1f s, oracle/libssx_oracle.so, %d threads, 8x8 tile queue); one thread: %d px x spp=%d (%.1f s); port, ~%sx the reference binary's rate (vs_reference_probe)"
                       % (scene, W, H, spp, dt, cores, npx, spp1, dt1, ("%.1f" % probe["port_over_ref_one_thread"]) if probe else "2")}
 
 
+def oracle_check(img, scene, W, H, spp_total, observer, texture, n_tiles=6):
+    """The checker of the cpu_baseline leg, applied to the image the timed region produced: `n_tiles` 8x8 tiles of the LAST timed step's
+    combined image (as it arrived in pinned host memory) against the CPU oracle at full spp, bit for bit.  The oracle is only ever the
+    checker here -- never the thing measured.  A bench line is printed only for an image that passes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as ol
+
+    o = ol.Oracle(scene, observer=observer, texture=texture)
+    tx, ty = (W + 7) // 8, (H + 7) // 8
+    # corners, centre and two tiles at fixed fractions of the image (the red textured wall, a block face): spread over the tile list
+    picks = [(0, 0), (tx // 2, ty // 2), (tx - 1, ty - 1), ((15 * tx) // 64, (50 * ty) // 64), ((55 * tx) // 64, (20 * ty) // 64), ((5 * tx) // 64, (30 * ty) // 64)][:n_tiles]
+    t = time.time()
+    differing = 0
+    checked = []
+    for (a, b) in picks:
+        i0, j0 = a * 8, b * 8
+        i1, j1 = min(i0 + 8, W), min(j0 + 8, H)
+        ref = o.render(W, H, spp_total, rect=(i0, j0, i1, j1), nthreads=1)
+        got = np.ascontiguousarray(img[j0:j1, i0:i1], dtype=np.float32).view(np.uint32)
+        differing += int((got != np.ascontiguousarray(ref[j0:j1, i0:i1], dtype=np.float32).view(np.uint32)).sum())
+        checked.append([i0, j0])
+    alpha = float(img[..., 3].mean())
+    return {"tiles": len(checked), "tile_origins": checked, "spp": spp_total, "differing_floats": differing, "image": "last timed step, from pinned host memory",
+            "against": "oracle/libssx_oracle.so (CPU restatement), uint32 compare of float4 XYZA", "mean_alpha": round(alpha, 5), "seconds": round(time.time() - t, 2)}
+
+
+def n1_reference():
+    """The N = 1 figure the efficiency field is quoted against: the driver's own last N = 1 record in the tree (BENCH_rNN.json), else round 4's."""
+    best = {"value": 3149.36, "source": "BENCH_r04.json (driver's N=1 run, round 4)"}
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json"))):
+            d = json.load(open(f)).get("parsed") or {}
+            if d.get("n_gpus") == 1 and d.get("value"):
+                best = {"value": float(d["value"]), "source": "%s (driver's N=1 run)" % os.path.basename(f)}
+    except Exception:
+        pass
+    return best
+
+
+def sha256_of(*paths):
+    import hashlib
+    h = hashlib.sha256()
+    for p in paths:
+        try:
+            h.update(open(p, "rb").read())
+        except OSError:
+            h.update(b"<missing>")
+    return h.hexdigest()[:16]
+
+
+def kernel_source_id():
+    """Identifies the device code the traffic belongs to: hash of the kernel sources (not of the .so, whose bytes differ per build host)."""
+    c = os.path.join(ROOT, "simple_spectral_amd", "csrc")
+    return sha256_of(*[os.path.join(c, f) for f in ("ssx_kernels.hip", "ssx_api.hip", "ssx_blob.h", "ssx_exact.h", "ssx_pass1_gen.h")] + [os.path.join(ROOT, "include", "ssx_fmath.h")])
+
+
+PMC_KERNELS = (("path", "ssx_render_kernel"), ("generate", "ssx_generate_kernel"))
+
+
+def pmc_passes(args):
+    """HBM traffic of THIS run's workload, measured now: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: no trace flags next to
+    them, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over a short child run of this script (--pmc-child: same scene, same launches,
+    prints nothing).  Corrections of that guide: both counters are KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced read
+    streams (what this pipeline's reads are: calibrated on known byte counts, tools/ubench/traffic_calib) -> doubled; WRITE_SIZE as is.
+    Returns ({kernel: bytes per launch}, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    out_root = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else tempfile.gettempdir()
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "2", "--warmup", "1", "--scene", args.scene, "--res", str(args.res), "--spp", str(args.spp),
+             "--observer", str(args.observer), "--uplift", args.uplift, "--texture", args.texture, "--batch", str(args.batch)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    got = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ssx_pmc_%s_" % counter.lower(), dir=out_root)
+        try:
+            subprocess.run([prof, "--pmc", counter, "--output-format", "csv", "-d", d, "--"] + child, cwd="/tmp", env=env, timeout=240,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, "rocprofv3 wrote no counter file for %s" % counter
+            per = {k: [] for k, _ in PMC_KERNELS}
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") != counter:
+                    continue
+                for k, pat in PMC_KERNELS:
+                    if pat in row.get("Kernel_Name", ""):
+                        per[k].append(float(row["Counter_Value"]))
+            # (the child's first launches are its warm-up: same size, so every launch counts)
+            got[counter] = {k: (sum(v) / len(v) if v else None) for k, v in per.items()}
+            got[counter + "_launches"] = {k: len(v) for k, v in per.items()}
+        except Exception as e:  # a pool without counter access, a timeout: say so, the line then replays the stamped file
+            return None, "%s pass failed: %s" % (counter, str(e)[:200])
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    by_kernel = {}
+    for k, _ in PMC_KERNELS:
+        f, w = got["FETCH_SIZE"][k], got["WRITE_SIZE"][k]
+        if f is None or w is None:
+            return None, "no %s launches in the counter files" % k
+        by_kernel[k] = int(2.0 * f * 1024 + w * 1024)
+    detail = {"FETCH_SIZE_KiB": got["FETCH_SIZE"], "WRITE_SIZE_KiB": got["WRITE_SIZE"], "fetch_correction": 2.0, "launches": got["FETCH_SIZE_launches"],
+              "bytes_per_launch": by_kernel}
+    return by_kernel, detail
+
+
 def measured_traffic(args, world):
-    """HBM bytes per launch of the pipeline's dominant kernel as recorded from rocprofv3 --pmc passes of
-    THIS workload (separate FETCH_SIZE / WRITE_SIZE passes, corrected with the factors calibrated on known
-    byte counts in the same access patterns: tools/profile_round.sh, tools/collect_traffic.py ->
-    profiles/traffic.json).  Replayed from that file: counters cannot be read from inside this process."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+    """HBM bytes per launch of the path kernel (roofline.traffic) and of the generate kernel.  N = 1: measured in this run by two
+    rocprofv3 --pmc passes (pmc_passes) unless --no-pmc / SSX_BENCH_NO_PMC=1 or the passes fail; the result also refreshes
+    profiles/traffic.json.  Otherwise replayed from that file -- stamped with the hash of the kernel sources it was taken on and of
+    the counter summary it agrees with, and marked stale when the sources have changed since, so that it cannot go stale silently."""
+    path = os.environ.get("SSX_BENCH_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "traffic.json")   # (tests point it elsewhere)
+    key = "%s %d spp%d obs%d gpus%d" % (args.scene, args.res, args.spp, args.observer, world)
+    src_id = kernel_source_id()
+    if world == 1 and not args.no_pmc and os.environ.get("SSX_BENCH_NO_PMC") != "1":
+        by_kernel, detail = pmc_passes(args)
+        if by_kernel:
+            detail["kernel_source_id"] = src_id
+            try:
+                t = json.load(open(path)) if os.path.exists(path) else {}
+                t[key] = by_kernel["path"]
+                t[key + " detail"] = detail
+                json.dump(t, open(path, "w"), indent=1, sort_keys=True)
+            except Exception:
+                pass
+            return by_kernel["path"], detail, "measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over a child run of the same workload; FETCH_SIZE x 2 (gfx950 wide-read correction), KiB -> bytes; path kernel (traffic) and generate kernel (traffic_detail.bytes_per_launch)"
+        why = detail
+    else:
+        why = "--no-pmc" if world == 1 else "N > 1: counters are collected at N = 1"
     try:
         t = json.load(open(path))
-        key = "%s %d spp%d obs%d gpus%d" % (args.scene, args.res, args.spp, args.observer, world)
-        return t.get(key), t.get(key + " detail")
+        detail = dict(t.get(key + " detail") or {})
+        taken_on = detail.get("kernel_source_id")
+        detail["replayed"] = {"file": "profiles/traffic.json", "file_sha256_16": sha256_of(path), "why_not_measured": why,
+                              "agrees_with": "profiles/r04/pmc_summary.csv", "pmc_summary_sha256_16": sha256_of(os.path.join(ROOT, "profiles", "r04", "pmc_summary.csv")),
+                              "taken_on_kernel_source_id": taken_on, "this_build_kernel_source_id": src_id,
+                              "stale": (taken_on != src_id) if taken_on else "unknown (taken before round 5 stamped the sources)"}
+        return t.get(key), detail, "REPLAYED from profiles/traffic.json (not measured in this run: %s); see traffic_detail.replayed for the stamp" % why
     except Exception:
-        return None, None
+        return None, None, None
+
+
 
 
 def spawn_ranks(args):
@@ -214,7 +361,13 @@ def main():
     ap.add_argument("--texture", default="crystal-lizard-512.png", help="PNG under data/scenes, or procedural:N[:SEED]")
     ap.add_argument("--batch", type=int, default=0, help="spp per pipelined batch (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the timed image (A/B scripts; the driver's command never passes it)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure HBM traffic with rocprofv3 --pmc passes in this run (replay profiles/traffic.json, stamped)")
+    ap.add_argument("--quick", action="store_true", help="= --no-cpu-baseline --no-check --no-pmc (A/B and profiling scripts)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the run under rocprofv3 --pmc: renders, prints nothing
     args = ap.parse_args()
+    if args.pmc_child or args.quick:
+        args.no_check = args.no_cpu_baseline = args.no_pmc = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)
@@ -318,11 +471,15 @@ def main():
         host_step(k)
     fence()
     r.set_timing(True)  # HIP events on the launch stream around each kernel of the pipeline
+    sums0 = r.sums_info()
     t0 = time.perf_counter()
     for k in range(args.steps):
         host_step(k)
     fence()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
+    sums1 = r.sums_info()
+    last_host_img = host_imgs[(args.steps - 1) & 1].numpy().copy() if rank == 0 and args.steps > 0 else None  # what the last timed step delivered
     stage_ms = {k: v / max(args.steps, 1) for k, v in r.get_timing().items()}
     pipeline_ms = sum(stage_ms.values())  # the kernels of a step, first to last (events without a system fence: csrc/ssx_api.hip timing_events)
     r.set_timing(False)
@@ -342,12 +499,56 @@ def main():
         tt = torch.tensor([elapsed, kernel_ms, elapsed_resident, path_ms], dtype=torch.float64, device="cpu" if test_one_gpu else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms, elapsed_resident, path_ms = float(tt[0]), float(tt[1]), float(tt[2]), float(tt[3])
+    # ---- who took part: one record per rank, gathered on rank 0; a run in which two ranks share a device, or in which
+    # two ranks' images overlap (a pixel nonzero on both: the partition is wrong), does not print a bench line.
+    my_ms, my_path_ms = elapsed_local / args.steps * 1e3, stage_ms["path"]
+    n_tiles_img = ((W + 7) // 8) * ((H + 7) // 8)
+    my_tiles = (n_tiles_img - rank + world - 1) // world
+    unit_spp = 4 if r.plan_info()["frames_per_sample"] >= 2.0 else 8                    # make_batch: units of 4 samples per pixel for long paths, else 8
+    n_units = max(1, my_tiles * ((spp_total + unit_spp - 1) // unit_spp) * args.steps)    # work units of the timed steps
+    sums = {k: sums1[k] - sums0[k] for k in sums0}
+    props = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "local_rank": local_rank, "hostname": socket.gethostname(), "pid": os.getpid(),
+          "device": props.name, "device_uuid": str(getattr(props, "uuid", "")), "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+          "ms_per_step": round(my_ms, 3), "path_ms": round(my_path_ms, 3), "generate_ms": round(stage_ms["generate"], 3),
+          "tiles_owned": my_tiles, "units_parked_frac": round(sums["units_parked"] / float(n_units), 4)}
+    ranks = [me]
+    overlap = None
+    if use_dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, me)
+        ranks = gathered
+        # the un-reduced image of every rank on three sampled rows: nonzero sets must be pairwise disjoint
+        own = torch.zeros_like(out)
+        r.render_device(own.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        rows = sorted({0, H // 2, H - 1})
+        nz = (own[rows] != 0).any(dim=-1).to(torch.int32)                        # [rows, W]
+        tot = nz.clone() if not test_one_gpu else nz.cpu()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        overlap = {"rows": rows, "pixels_nonzero_on_more_than_one_rank": int((tot > 1).sum()), "pixels_nonzero_on_some_rank": int((tot > 0).sum()), "row_pixels": len(rows) * W}
     if os.environ.get("SSX_BENCH_DUMP"):  # tests: rank 0's combined image
         if rank == 0:
             import numpy as np
             np.save(os.environ["SSX_BENCH_DUMP"], out.cpu().numpy())
 
+    if args.pmc_child:
+        if use_dist:
+            dist.barrier(); dist.destroy_process_group()
+        return
     if rank == 0:
+        # ---- the timed image is a checked image: no line for an image that differs from the oracle
+        check = None
+        if not args.no_check:
+            from simple_spectral_amd import textures as _tx
+            check = oracle_check(last_host_img, args.scene, W, H, spp_total, args.observer, _tx.resolve(texture)) if args.uplift == "ours" else {"skipped": "uplift %s: the check needs the model the renderer fitted" % args.uplift}
+            if check.get("differing_floats"):
+                raise SystemExit("bench.py: the timed image differs from the CPU oracle (%d floats on %d tiles): no bench line" % (check["differing_floats"], check["tiles"]))
+        devs = [(x["hostname"], x["device_uuid"] or x["pci_bus_id"]) for x in ranks]
+        if len(set(devs)) != len(devs) and not test_one_gpu:
+            raise SystemExit("bench.py: two ranks report the same device: %s" % devs)
+        if overlap and overlap["pixels_nonzero_on_more_than_one_rank"]:
+            raise SystemExit("bench.py: rank images overlap on %d sampled pixels: the tile partition is wrong" % overlap["pixels_nonzero_on_more_than_one_rank"])
         samples_per_step = W * H * spp_total
         value = samples_per_step * args.steps / elapsed / 1e6
         per_gpu_samples = W * H * args.spp
@@ -356,8 +557,9 @@ def main():
         plan = r.plan_info()
         L = plan["frames_per_sample"]  # continued levels per sample, measured on this scene at upload
         hbm_bytes = per_gpu_samples * design_bytes_per_sample(args.scene, levels=L)
-        traffic, traffic_detail = measured_traffic(args, world)
+        traffic, traffic_detail, traffic_source = measured_traffic(args, world)
         info = r.kernel_info()
+        n1 = n1_reference()
         line = {
             "metric": "Msamples/s (w*h*spp/s) %s %dx%d" % (args.scene, W, H),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -375,7 +577,7 @@ def main():
             "roofline": {"bound": "valu", "achieved": round(achieved_tflops, 3), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved_tflops / PEAK_VALU_TFLOPS, 4),
                          "traffic": traffic,
-                         "traffic_source": "replayed from profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, corrected by factors calibrated on known byte counts in the same access patterns; NOT measured in this run" if traffic else None,
+                         "traffic_source": traffic_source,
                          "traffic_detail": traffic_detail,
                          "kernel": "ssx_generate_kernel + %s" % (plan.get("kernel") or "ssx_render_kernel"),
                          "kernel_ms": round(kernel_ms, 3), "path_kernel_ms": round(path_ms, 3),
@@ -399,6 +601,13 @@ def main():
                          "vgprs": info["vgprs"], "scratch_bytes": info["scratch_bytes"], "lds_bytes": info["lds_bytes"],
                          "plan": plan},
         }
+        line["check"] = check
+        line["ranks"] = ranks
+        line["distributed"] = {"backend": dist.get_backend() if use_dist else None, "world_size": dist.get_world_size() if use_dist else 1,
+                               "devices_distinct": len(set(devs)) == len(devs), "overlap": overlap,
+                               "slowest_rank_ms": max(x["ms_per_step"] for x in ranks), "fastest_rank_ms": min(x["ms_per_step"] for x in ranks)}
+        # weak-scaling efficiency against a stated N = 1 figure (the driver computes its own from its per-N runs; this one names what it used)
+        line["efficiency_vs_n1_reference"] = {"value": round(value / (world * n1["value"]), 4), "n1_value": n1["value"], "n1_source": n1["source"]}
         if world == 1 and not args.no_cpu_baseline:
             from simple_spectral_amd import textures
             line["cpu_baseline"] = cpu_baseline(args.scene, W, H, textures.resolve(texture))  # "procedural:N[:SEED]" -> the same texels the GPU run used

@@ -10,6 +10,11 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 HIP_LIB = os.path.join(PKG, "libssx_hip.so")
+# The same library with the inter-wave hand-over of the pixel sums stated in the HIP memory model (csrc/ssx_kernels.hip unit_fold:
+# acquire / release agent-scope read-modify-writes instead of relaxed atomics + s_waitcnt; 25 % slower).  Not what runs by default:
+# tests/test_gpu_variants.py runs it next to the default build on every `pytest -m gpu`, which is what validates the default build's
+# below-the-model ordering on the box and toolchain at hand.
+HIP_LIB_FORMAL = os.path.join(PKG, "libssx_hip_formal.so")
 HOST_LIB = os.path.join(PKG, "libssx_host.so")
 
 HIP_SRC = [os.path.join(PKG, "csrc", f) for f in ("ssx_api.hip",)]
@@ -92,6 +97,11 @@ def build_hip(force=False, verbose=False):
         check_toolchain()
         embed_sources()
         cmd = [hipcc()] + HIP_FLAGS + HIP_SRC + ["-o", HIP_LIB, "-lpthread", "-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    if force or _stale(HIP_LIB_FORMAL, HIP_DEPS):
+        cmd = [hipcc()] + HIP_FLAGS + ["-DSSX_ACCUM_FORMAL"] + HIP_SRC + ["-o", HIP_LIB_FORMAL, "-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -36,9 +36,36 @@ def test_bench_two_ranks_json_line_and_image(tmp_path, launcher):
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["unit"] == "Msamples/s" and line["value"] > 0
     assert line["steps"] == 2 and line["warmup"] == 1 and "roofline" in line and "cpu_baseline" not in line
     assert line["config"]["workload"].startswith("cornell-srgb 64x64 spp=4/GPU (total spp 8)")
+    # the line ties its value to a checked image and says who took part
+    assert line["check"]["differing_floats"] == 0 and line["check"]["tiles"] >= 4 and line["check"]["spp"] == 8
+    assert [x["rank"] for x in line["ranks"]] == [0, 1] and all(x["ms_per_step"] > 0 and x["path_ms"] > 0 and x["tiles_owned"] == 32 for x in line["ranks"])
+    assert len({x["pid"] for x in line["ranks"]}) == 2 and all(0.0 <= x["units_parked_frac"] <= 1.0 for x in line["ranks"])
+    d = line["distributed"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["overlap"]["pixels_nonzero_on_more_than_one_rank"] == 0 and d["overlap"]["pixels_nonzero_on_some_rank"] > 0
+    assert d["devices_distinct"] is False            # both ranks on device 0 here (SSX_BENCH_TEST_ONE_GPU): the driver's 8-GPU run must say True, or bench.py refuses
+    e = line["efficiency_vs_n1_reference"]
+    assert e["n1_value"] > 0 and abs(e["value"] - line["value"] / (2 * e["n1_value"])) < 1e-3 and "BENCH_r" in e["n1_source"]
+    assert "REPLAYED" in (line["roofline"]["traffic_source"] or "REPLAYED") or line["roofline"]["traffic"] is None
     img = np.load(dump)
     ref = ol.Oracle("cornell-srgb", texture="test-img.png").render(64, 64, 8)   # total spp = 4 per GPU x 2
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_bench_refuses_a_line_when_two_ranks_share_a_device(tmp_path):
+    """Without SSX_BENCH_TEST_ONE_GPU a 2-rank run on a 1-GPU box puts both ranks on device 0 over RCCL: either RCCL refuses (duplicate
+    device) or bench.py's own device check does -- in no case is a bench line printed."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SSX_BENCH_TEST_ONE_GPU", "SSX_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    env["NCCL_DEBUG"] = "WARN"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--res", "64", "--spp", "4", "--texture", "test-img.png", "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.skip("RCCL hung on the duplicate device instead of refusing it")
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 @pytest.mark.gpu
@@ -53,14 +80,44 @@ def test_bench_one_rank_through_rccl(tmp_path):
         env.pop(k, None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--res", "64", "--spp", "8",
-           "--texture", "test-img.png", "--no-cpu-baseline"]
+           "--texture", "test-img.png", "--no-cpu-baseline", "--no-pmc"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
+    assert line["check"]["differing_floats"] == 0 and line["distributed"]["backend"] == "nccl" and line["distributed"]["world_size"] == 1
+    assert len(line["ranks"]) == 1 and line["ranks"][0]["device_uuid"] != "" and line["distributed"]["devices_distinct"] is True
     assert line["n_gpus"] == 1 and "RCCL reduce (world size 1" in line["config"]["parallelism"]
     assert line["value"] > 0 and line["value_device_resident"] > 0 and line["ms_per_step_device_resident"] > 0 and line["value_host_inclusive"] == line["value"]
     img = np.load(dump)
     ref = ol.Oracle("cornell-srgb", texture="test-img.png").render(64, 64, 8)
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_bench_measures_its_hbm_traffic_in_the_run(tmp_path):
+    """with rocprofv3 on the box the default N = 1 run measures roofline.traffic itself (two --pmc passes over a child
+    run) instead of replaying a file; the line says which, and carries the generate kernel's bytes too."""
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("no rocprofv3")
+    tj = str(tmp_path / "traffic.json")
+    env = dict(os.environ, SSX_BENCH_TRAFFIC_JSON=tj)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SSX_BENCH_TEST_ONE_GPU", "SSX_BENCH_FORCE_DIST", "SSX_BENCH_NO_PMC"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--res", "256", "--spp", "32", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    rf = line["roofline"]
+    if "REPLAYED" in (rf["traffic_source"] or "REPLAYED"):
+        pytest.skip("counter passes unavailable on this box: %s" % ((rf.get("traffic_detail") or {}).get("replayed") or {}).get("why_not_measured"))
+    assert rf["traffic_source"].startswith("measured in this run")
+    samples = 256 * 256 * 32
+    per_sample = rf["traffic"] / samples
+    assert 300.0 < per_sample < 900.0, per_sample                 # the design's own bytes are ~425 B per sample (DESIGN.md section 3): counters within 2x of them
+    d = rf["traffic_detail"]
+    assert d["bytes_per_launch"]["generate"] > 48 * samples * 0.8 and d["launches"]["path"] >= 3 and d["kernel_source_id"]
+    assert json.load(open(tj))["cornell-srgb 256 spp32 obs1931 gpus1"] == rf["traffic"]
+    assert line["check"]["differing_floats"] == 0

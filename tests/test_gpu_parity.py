@@ -135,6 +135,17 @@ def test_full_size_properties_config2():
     assert np.array_equal(bits(h0 + h1), bits(a))
 
 
+def test_headline_config_whole_image_against_the_oracle():
+    """BASELINE.json configs[1] -- the bench's workload: cornell-srgb 512x512 spp=256, CIE 1931, lizard texture, seed 0 -- the WHOLE image
+    against the CPU oracle, all 1 048 576 floats bit for bit (67 M samples on the host's cores: ~20 s on 16).  bench.py checks tiles of the
+    image it timed; this is the same image in full (reference: src/renderer.cpp:278-299, every pixel's ordered binary64 mean)."""
+    got, _ = gpu_render(scene_name="cornell-srgb", res=(512, 512), spp=256, texture="crystal-lizard-512.png")
+    ref = ol.Oracle("cornell-srgb", texture="crystal-lizard-512.png").render(512, 512, 256, nthreads=0)
+    assert np.array_equal(bits(got), bits(ref)), "floats differing: %d" % int((bits(got) != bits(ref)).sum())
+    rel = np.abs(got[..., :3] - ref[..., :3]) / np.maximum(np.abs(ref[..., :3]), 1e-6)   # the north-star form of the same statement
+    assert rel.max() <= 1e-4
+
+
 def test_async_interface_progress_and_stop():
     r = Renderer(Options(scene_name="cornell-srgb", res=(256, 256), spp=4096, spp_per_launch=8, texture="test-img.png"))
     r.render_start()

@@ -1,0 +1,67 @@
+"""Every kernel variant the library can run -- the default build, the build whose inter-wave hand-over of the pixel sums is stated
+in the HIP memory model (-DSSX_ACCUM_FORMAL, libssx_hip_formal.so: csrc/ssx_kernels.hip unit_fold), the generic pass 1 forced on
+the built-in scenes, the narrow shadow-queue entries -- through the hand-over stress cases and 500 fuzzed scenes each, against the
+CPU oracle, bit for bit (the guard of the default build's below-the-model ordering runs with `pytest -m gpu`).
+One worker process per variant (tests/variant_worker.py), all four side by side on the one GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+FUZZ_FIRST, FUZZ_COUNT = 90000, 500        # seeds no earlier run used (tools/fuzz_scenes.py logs: up to 71799)
+
+VARIANTS = {
+    "default": {},
+    "formal": {"SSX_DEBUG_ENV": "1", "SSX_HIP_LIB_OVERRIDE": os.path.join(ROOT, "simple_spectral_amd", "libssx_hip_formal.so")},
+    "generic": {"SSX_DEBUG_ENV": "1", "SSX_GENERIC_KERNEL": "1"},
+    "narrow-queue": {"SSX_DEBUG_ENV": "1", "SSX_NARROW_QUEUE": "1"},
+}
+
+
+@pytest.fixture(scope="module")
+def workers():
+    procs = {}
+    for name, extra in VARIANTS.items():
+        env = dict(os.environ, **extra)
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        procs[name] = subprocess.Popen([sys.executable, os.path.join(HERE, "variant_worker.py"), str(FUZZ_FIRST), str(FUZZ_COUNT)], cwd=ROOT, env=env,
+                                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    yield procs
+    for p in procs.values():
+        if p.poll() is None:
+            p.kill()
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_variant_stress_and_fuzz_bit_exact(workers, variant):
+    if variant == "formal":
+        assert os.path.exists(VARIANTS["formal"]["SSX_HIP_LIB_OVERRIDE"]), "libssx_hip_formal.so missing: simple_spectral_amd/build.py builds it"
+    p = workers[variant]
+    try:
+        out, err = p.communicate(timeout=900)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        pytest.fail("variant %s: worker timed out" % variant)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert lines, (p.returncode, err[-2000:])
+    rep = json.loads(lines[-1])
+    assert rep["stress_failures"] == [] and rep["fuzz_mismatching_seeds"] == [] and p.returncode == 0, rep
+    assert rep["fuzz_scenes"] == FUZZ_COUNT
+    assert rep["n8_share_parked_frac"] > 0.3, rep          # the N = 8 share really went through the parked branch
+    assert min(rep["units_parked"]) > 10, rep
+    if variant == "formal":
+        assert rep["library"] == "libssx_hip_formal.so"
+    else:
+        assert rep["library"] == "libssx_hip.so"
+    if variant == "generic":
+        assert rep["kernel"] in ("ssx_render_kernel", "ssx_render_kernel_nq"), rep["kernel"]
+    elif variant == "narrow-queue":
+        assert rep["kernel"].endswith("_nq"), rep["kernel"]
+    else:
+        assert rep["kernel"] == "ssx_render_kernel_cornell", rep["kernel"]

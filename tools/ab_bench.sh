@@ -6,8 +6,8 @@ export SSX_DEBUG_ENV=1 # the master switch of the A/B environment variables (REA
 R=$(pwd)
 P='import json,sys; d=json.loads(sys.stdin.read()); print(sys.argv[1], d["value"], d["ms_per_step"], d["roofline"]["kernel_ms"], d["roofline"]["stage_ms"], d["roofline"]["scratch_bytes"])'
 for round in 1 2 3; do
-	python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline $BENCH_ARGS 2>/dev/null | python -c "$P" product
+	python $R/bench.py --steps 10 --warmup 2 --quick $BENCH_ARGS 2>/dev/null | python -c "$P" product
 	for V in "$@"; do
-		SSX_HIP_LIB_OVERRIDE=$R/$V python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline $BENCH_ARGS 2>/dev/null | python -c "$P" $V
+		SSX_HIP_LIB_OVERRIDE=$R/$V python $R/bench.py --steps 10 --warmup 2 --quick $BENCH_ARGS 2>/dev/null | python -c "$P" $V
 	done
 done

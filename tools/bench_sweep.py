@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for extra in sys.argv[1:]:
     args = extra.split()
     base = [] if "--steps" in args else ["--steps", "5", "--warmup", "2"]
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"] + base + args
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--quick"] + base + args
     out = subprocess.run(cmd, capture_output=True, text=True).stdout
     line = [l for l in out.splitlines() if l.startswith("{")]
     if not line:

@@ -7,7 +7,7 @@ rocprofv3 -L 2>/dev/null | grep -o -i "SQC_[A-Z_0-9]*\|SQ_IFETCH[A-Z_0-9]*\|SQ_I
 for SET in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQ_IFETCH SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
 D=$R/gpurun_out/pmc_ic_$(echo $SET | cut -c1-12 | tr ' ' _)
 rm -rf $D
-timeout 180 rocprofv3 --pmc $SET --output-format csv -d $D -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 180 rocprofv3 --pmc $SET --output-format csv -d $D -- python $R/bench.py --steps 2 --warmup 1 --quick > /dev/null 2>&1
 python3 - $D <<'PY'
 import csv, glob, sys, collections
 rows = collections.defaultdict(list)

@@ -8,7 +8,7 @@ for V in product "$@"; do
 	D=$R/gpurun_out/pmcq_$(basename $V .so)
 	rm -rf $D
 	if [ "$V" = product ]; then unset SSX_HIP_LIB_OVERRIDE; else export SSX_HIP_LIB_OVERRIDE=$R/$V; fi
-	rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d $D -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline $ARGS > /dev/null 2>&1
+	rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d $D -- python $R/bench.py --steps 2 --warmup 1 --quick $ARGS > /dev/null 2>&1
 	python3 - $D $V <<'PY'
 import csv, glob, sys, collections
 rows = collections.defaultdict(list)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Samples rocm-smi power / clocks while bench.py runs (GPU box): is the path kernel running at its power cap?
 R=$(pwd)
-python $R/bench.py --steps 60 --warmup 5 --no-cpu-baseline > $R/gpurun_out/power_bench.json 2>/dev/null &
+python $R/bench.py --steps 60 --warmup 5 --quick > $R/gpurun_out/power_bench.json 2>/dev/null &
 B=$!
 sleep 6
 for i in $(seq 1 12); do

@@ -123,6 +123,58 @@ KERNEL(k_cmp_sel2x, F8, OPCS2X(a0, a1, a2) OPCS2X(a3, a4, a5) OPCS2X(a6, a7, a0)
 #define OPCS2N(A, B) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\ts_nop 0\n\tv_cndmask_b32_e32 %1, %1, %2, vcc" : "+v"(A), "+v"(B) : "v"(b) : "vcc");
 KERNEL(k_cmp_sel2n, F8, OPCS2N(a0, a1) OPCS2N(a2, a3) OPCS2N(a4, a5) OPCS2N(a6, a7) OPCS2N(a0, a1) OPCS2N(a2, a3) OPCS2N(a4, a5) OPCS2N(a6, a7), SINKF)
 
+
+#define OPCW2(txt) asm volatile(txt : "+v"(a0) : "v"(e0)); asm volatile(txt : "+v"(a1) : "v"(e0)); asm volatile(txt : "+v"(a2) : "v"(e0)); asm volatile(txt : "+v"(a3) : "v"(e0)); asm volatile(txt : "+v"(a4) : "v"(e0)); asm volatile(txt : "+v"(a5) : "v"(e0)); asm volatile(txt : "+v"(a6) : "v"(e0)); asm volatile(txt : "+v"(a7) : "v"(e0));
+#define OPMAD(txt) asm volatile(txt : "+v"(a0) : "v"(u0) : "s20", "s21"); asm volatile(txt : "+v"(a1) : "v"(u0) : "s20", "s21"); asm volatile(txt : "+v"(a2) : "v"(u0) : "s20", "s21"); asm volatile(txt : "+v"(a3) : "v"(u0) : "s20", "s21"); asm volatile(txt : "+v"(a4) : "v"(u0) : "s20", "s21"); asm volatile(txt : "+v"(a5) : "v"(u0) : "s20", "s21"); asm volatile(txt : "+v"(a6) : "v"(u0) : "s20", "s21"); asm volatile(txt : "+v"(a7) : "v"(u0) : "s20", "s21");
+
+// round 5 additions (tools/isa_census.py prices): forms the path kernel uses that had no measured rate yet
+KERNEL(k_ashr_c, F8, OPA("v_ashrrev_i32 %0, 3, %0"), SINKF)
+KERNEL(k_lshl_c, F8, OPA("v_lshlrev_b32 %0, 3, %0"), SINKF)
+KERNEL(k_not, F8, OPA("v_not_b32 %0, %0"), SINKF)
+KERNEL(k_ffbl, F8, OPA("v_ffbl_b32 %0, %0"), SINKF)
+KERNEL(k_min_u32, F8, OPA("v_min_u32 %0, %0, %1"), SINKF)
+KERNEL(k_max_i32, F8, OPA("v_max_i32 %0, %0, %1"), SINKF)
+KERNEL(k_bfi, F8, OPA("v_bfi_b32 %0, %0, %1, %1"), SINKF)
+KERNEL(k_add_e64_neg, F8, OPA("v_add_f32_e64 %0, %0, -%1"), SINKF)
+KERNEL(k_mul_e64_abs, F8, OPA("v_mul_f32_e64 %0, |%0|, %1"), SINKF)
+KERNEL(k_fma_neg, F8, OPA("v_fma_f32 %0, -%0, %1, 1.0"), SINKF)
+KERNEL(k_cmp_class, F8, OPA("v_cmp_class_f32_e64 s[20:21], %0, %1") , SINKF)
+KERNEL(k_div_scale, F8, OPA("v_div_scale_f32 %0, vcc, %0, %1, %0"), SINKF)
+KERNEL(k_readlane, F8, asm volatile("v_readlane_b32 s20, %0, 3" :: "v"(a0) : "s20"); asm volatile("v_readlane_b32 s21, %0, 3" :: "v"(a1) : "s21"); asm volatile("v_readlane_b32 s22, %0, 3" :: "v"(a2) : "s22"); asm volatile("v_readlane_b32 s23, %0, 3" :: "v"(a3) : "s23"); asm volatile("v_readlane_b32 s20, %0, 3" :: "v"(a4) : "s20"); asm volatile("v_readlane_b32 s21, %0, 3" :: "v"(a5) : "s21"); asm volatile("v_readlane_b32 s22, %0, 3" :: "v"(a6) : "s22"); asm volatile("v_readlane_b32 s23, %0, 3" :: "v"(a7) : "s23");, SINKF)
+KERNEL(k_mbcnt, F8, OPA("v_mbcnt_lo_u32_b32 %0, -1, %0"), SINKF)
+KERNEL(k_mov_b64, D8, OPA("v_mov_b64 %0, %1"), SINKD)
+KERNEL(k_lshl_add_u64, D8, OPA("v_lshl_add_u64 %0, %0, 0, %1"), SINKD)
+KERNEL(k_min_f64, D8, OPA("v_min_f64 %0, %0, %1"), SINKD)
+KERNEL(k_ldexp_f64, D8; int e0 = threadIdx.x & 1, OPCW2("v_ldexp_f64 %0, %0, %1"), SINKD)
+KERNEL(k_cmp_f64, D8, OPA("v_cmp_lt_f64_e64 s[20:21], %0, %1"), SINKD)
+KERNEL(k_mad_u64_u32, D8; unsigned u0 = threadIdx.x, OPMAD("v_mad_u64_u32 %0, s[20:21], %1, %1, %0"), SINKD)
+// a compare and its VOP2 select with independent arithmetic in between (what the scheduler can do for ray_setup)
+#define OPCSI(A, B) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %2\n\tv_add_f32 %1, %1, %2\n\tv_cndmask_b32_e32 %0, %0, %2, vcc\n\tv_mul_f32 %1, %1, %2" : "+v"(A), "+v"(B) : "v"(b) : "vcc");
+KERNEL(k_cmp_add_sel_mul, F8, OPCSI(a0, a1) OPCSI(a2, a3) OPCSI(a4, a5) OPCSI(a6, a7) OPCSI(a0, a1) OPCSI(a2, a3) OPCSI(a4, a5) OPCSI(a6, a7), SINKF)
+// one compare, then selects alternating with arithmetic: cmp, (sel, add) x 4
+#define OPCS4I(A, B, C, D, E) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %5\n\tv_cndmask_b32_e32 %0, %0, %5, vcc\n\tv_add_f32 %4, %4, %5\n\tv_cndmask_b32_e32 %1, %1, %5, vcc\n\tv_add_f32 %4, %4, %5\n\tv_cndmask_b32_e32 %2, %2, %5, vcc\n\tv_add_f32 %4, %4, %5\n\tv_cndmask_b32_e32 %3, %3, %5, vcc" : "+v"(A), "+v"(B), "+v"(C), "+v"(D), "+v"(E) : "v"(b) : "vcc");
+KERNEL(k_cmp_4sel_interleaved, F8, OPCS4I(a0, a1, a2, a3, a7) OPCS4I(a4, a5, a6, a0, a7) OPCS4I(a1, a2, a3, a4, a7) OPCS4I(a5, a6, a0, a1, a7) OPCS4I(a2, a3, a4, a5, a7) OPCS4I(a6, a0, a1, a2, a7) OPCS4I(a3, a4, a5, a6, a7) OPCS4I(a0, a1, a2, a3, a7), SINKF)
+// a fast-class and a slow-class instruction alternating: do their costs simply add?
+#define OPMIX(A) asm volatile("v_mul_f32 %0, %0, %1\n\tv_med3_f32 %0, %0, %1, %1" : "+v"(A) : "v"(b));
+KERNEL(k_mul_med3, F8, OPMIX(a0) OPMIX(a1) OPMIX(a2) OPMIX(a3) OPMIX(a4) OPMIX(a5) OPMIX(a6) OPMIX(a7), SINKF)
+// VALU next to LDS reads issued by the same waves: does a ds_read take a VALU issue slot?
+__global__ void __launch_bounds__(256) k_mul_with_ds(float* out, float seed) {
+	__shared__ float buf[2048];
+	for (int i = threadIdx.x; i < 2048; i += 256) buf[i] = seed + i;
+	__syncthreads();
+	F8;
+	const float* p = buf + threadIdx.x;
+	for (int it = 0; it < N_ITER; ++it) {
+		REP8(
+			asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a0) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a1) : "v"(b));
+			asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a2) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a3) : "v"(b));
+			asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a4) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a5) : "v"(b));
+			asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a6) : "v"(b)); { float t; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"((unsigned)(size_t)p)); a7 += t; }
+		)
+	}
+	SINKF;
+}
+
 // LDS read rates with a per-lane address pattern like the permuted-vertex table
 __global__ void __launch_bounds__(256) k_ds_read_b128(float* out, float seed) {
 	__shared__ float4 buf[1024];
@@ -164,6 +216,12 @@ int main() {
 		{"cmp + 2 cndmask_e32 (16+8 instr -> per 8 groups)", k_cmp_sel2}, {"cmp + 4 cndmask_e32 (8 groups)", k_cmp_sel4}, {"cmp_e64 + 4 cndmask_e64 sgpr (8 groups)", k_cmp_sel4s},
 		{"cmp + 4 cndmask_e64 on vcc (8 groups)", k_cmp_sel4e}, {"cmp, sel, v_add, sel (8 groups of 4)", k_cmp_sel2x}, {"cmp, sel, s_nop, sel (8 groups)", k_cmp_sel2n},
 		{"v_fma_f64 v,v,1.0", k_fma_f64_inl}, {"v_cvt_f32_f64", k_cvt_f32_f64}, {"v_cvt_f64_f32", k_cvt_f64_f32},
+		{"v_ashrrev_i32 const", k_ashr_c}, {"v_lshlrev_b32 const", k_lshl_c}, {"v_not_b32", k_not}, {"v_ffbl_b32", k_ffbl}, {"v_min_u32", k_min_u32}, {"v_max_i32", k_max_i32},
+		{"v_bfi_b32", k_bfi}, {"v_add_f32_e64 v,-v", k_add_e64_neg}, {"v_mul_f32_e64 |v|,v", k_mul_e64_abs}, {"v_fma_f32 -v,v,1.0", k_fma_neg}, {"v_cmp_class_f32_e64", k_cmp_class},
+		{"v_div_scale_f32", k_div_scale}, {"v_readlane_b32", k_readlane}, {"v_mbcnt_lo", k_mbcnt}, {"v_mov_b64", k_mov_b64}, {"v_lshl_add_u64", k_lshl_add_u64},
+		{"v_min_f64", k_min_f64}, {"v_ldexp_f64", k_ldexp_f64}, {"v_cmp_lt_f64_e64", k_cmp_f64}, {"v_mad_u64_u32", k_mad_u64_u32},
+		{"cmp, add, sel, mul (8 groups of 4)", k_cmp_add_sel_mul}, {"cmp + 4 x (sel, add) interleaved (8 groups of 8)", k_cmp_4sel_interleaved},
+		{"v_mul_f32 + v_med3_f32 (per pair)", k_mul_med3}, {"7 v_mul_f32 + 1 ds_read_b32 (per 8)", k_mul_with_ds},
 	};
 	float* d; hipMalloc(&d, 4096);
 	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
