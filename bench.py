@@ -504,7 +504,9 @@ def main():
     my_ms, my_path_ms = elapsed_local / args.steps * 1e3, stage_ms["path"]
     n_tiles_img = ((W + 7) // 8) * ((H + 7) // 8)
     my_tiles = (n_tiles_img - rank + world - 1) // world
-    unit_spp = 4 if r.plan_info()["frames_per_sample"] >= 2.0 else 8                    # make_batch: units of 4 samples per pixel for long paths, else 8
+    unit_spp = 4 if r.plan_info()["frames_per_sample"] >= 2.0 else 8                    # make_batch (csrc/ssx_api.hip): units of 4 samples per pixel for long paths, else 8,
+    while unit_spp > 1 and ((spp_total + unit_spp - 1) // unit_spp) * my_tiles < 3072:    # halved while a launch would leave SIMDs without a wave (kMinUnits)
+        unit_spp //= 2
     n_units = max(1, my_tiles * ((spp_total + unit_spp - 1) // unit_spp) * args.steps)    # work units of the timed steps
     sums = {k: sums1[k] - sums0[k] for k in sums0}
     props = torch.cuda.get_device_properties(local_rank)

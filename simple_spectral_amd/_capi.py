@@ -127,31 +127,65 @@ def mapped_hip_runtimes():
     return sorted(out)
 
 
-def _one_hip_runtime_before_load():
+def _elf_dynamic(path):
+    """(SONAME, [NEEDED ...]) of a 64-bit little-endian ELF file, from its dynamic section; (None, []) if it cannot be read."""
+    import struct
+    try:
+        with open(path, "rb") as f:
+            eh = f.read(64)
+            if eh[:6] != b"\x7fELF\x02\x01":
+                return None, []
+            shoff, = struct.unpack_from("<Q", eh, 0x28)
+            shentsize, shnum = struct.unpack_from("<HH", eh, 0x3A)
+            f.seek(shoff)
+            sh = [struct.unpack_from("<IIQQQQIIQQ", f.read(shentsize)) for _ in range(shnum)]
+            dyn = next((x for x in sh if x[1] == 6), None)           # SHT_DYNAMIC
+            if dyn is None:
+                return None, []
+            strtab = sh[dyn[6]]                                      # sh_link: its string table
+            f.seek(strtab[4]); names = f.read(strtab[5])
+            f.seek(dyn[4]); raw = f.read(dyn[5])
+        soname, needed = None, []
+        for k in range(0, len(raw) - 15, 16):
+            tag, val = struct.unpack_from("<qQ", raw, k)
+            if tag in (1, 14):                                       # DT_NEEDED, DT_SONAME
+                name = names[val:names.index(b"\0", val)].decode()
+                if tag == 14:
+                    soname = name
+                else:
+                    needed.append(name)
+        return soname, needed
+    except Exception:
+        return None, []
+
+
+def _one_hip_runtime_before_load(path):
     """ONE HIP runtime per process, whatever the import order (this used to be a usage rule).
-    libssx_hip.so needs "libamdhip64.so.7"; torch bundles its own copy under that soname.  Streams, events and device pointers
-    are handed between torch and this library (bench.py, dist.py), which only works inside one runtime.  So:
+    libssx_hip.so needs a libamdhip64 by soname ("libamdhip64.so.7" with ROCm 7); torch bundles its own copy.  Streams, events and
+    device pointers are handed between torch and this library (bench.py, dist.py), which only works inside one runtime.  So:
       * a runtime is already mapped (torch was imported first, or the host linked one): the loader binds libssx_hip.so to it
         by soname -- nothing to do;
-      * none is mapped and torch is installed: its bundled copy is mapped NOW (RTLD_GLOBAL), so that libssx_hip.so binds to it
-        and a later `import torch` finds its own runtime already in place;
-      * no torch: libssx_hip.so brings /opt/rocm's through its RUNPATH.
+      * none is mapped, torch is installed AND its bundled copy carries the soname libssx_hip.so asks for: that copy is mapped NOW
+        (RTLD_GLOBAL), so that libssx_hip.so binds to it and a later `import torch` finds its own runtime already in place;
+      * no torch, or a torch built against another ROCm generation (another soname: preloading it would not satisfy the library's
+        NEEDED entry and only put a second runtime into a renderer-only process): libssx_hip.so brings /opt/rocm's through its RUNPATH.
     _one_hip_runtime_after_load checks the outcome instead of trusting it."""
     if mapped_hip_runtimes():
         return
     try:
         import importlib.util
+        wanted = [n for n in _elf_dynamic(path)[1] if n.startswith("libamdhip64.so")]
         spec = importlib.util.find_spec("torch")
-        if spec and spec.submodule_search_locations:
+        if wanted and spec and spec.submodule_search_locations:
             cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-            if os.path.exists(cand):
+            if os.path.exists(cand) and _elf_dynamic(cand)[0] == wanted[0]:
                 C.CDLL(cand, mode=C.RTLD_GLOBAL)
     except Exception:
         pass  # (then the library's own RUNPATH decides; the check below still holds)
 
 
 def _one_hip_runtime_after_load(path):
-    rts = mapped_hip_runtimes()
+    rts = mapped_hip_runtimes()                                      # (/proc/self/maps: read here, once per process -- hip_lib() caches the library)
     if len(rts) > 1:
         raise RuntimeError("two HIP runtimes are mapped into this process (%s) after loading %s: streams and device pointers cannot be "
                            "handed between them.  Import simple_spectral_amd (or torch) before whatever loaded the other one, or "
@@ -168,7 +202,7 @@ def hip_lib():
         if not os.path.exists(path):
             raise RuntimeError("%s is missing: run `python -m simple_spectral_amd.build` (needs hipcc). "
                                "simple_spectral_amd has no CPU or PyTorch fallback path." % path)
-        _one_hip_runtime_before_load()
+        _one_hip_runtime_before_load(path)
         lib = C.CDLL(path)
         _one_hip_runtime_after_load(path)
         override = path != _build.HIP_LIB

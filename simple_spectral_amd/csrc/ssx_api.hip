@@ -28,7 +28,7 @@ namespace {
 
 thread_local std::string g_create_error;
 
-// Environment switches of the A/B runs and tests (SSX_GENERIC_KERNEL, SSX_JIT_PASS1, SSX_UNIT_SPP, SSX_NARROW_QUEUE, SSX_PRE_HITS).
+// Environment switches of the A/B runs and tests (SSX_GENERIC_KERNEL, SSX_JIT_PASS1, SSX_NARROW_QUEUE, SSX_PRE_HITS).
 // None changes a result bit, all change the kernel plan -- so none is looked at unless the master switch SSX_DEBUG_ENV=1 is set:
 // a variable inherited from somebody's shell cannot silently change what a production process launches.
 const char* debug_env(const char* name) {
@@ -91,6 +91,7 @@ struct ssx_ctx {
 	std::atomic<int> rendering{0};
 	std::atomic<int> stop_flag{0};
 	std::atomic<uint32_t> done_spp{0};
+	uint32_t device_spp_cap = 0;         // ssx_render_device: max_spp_per_launch of the last render outside a stream capture (what a captured one is held to)
 	std::atomic<uint32_t> done_tiles{0}; // tile_major renders: the device's tiles finished so far (ssx_done_tiles)
 	uint32_t total_spp = 0;
 	int worker_rc = 0;
@@ -278,8 +279,10 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	}
 	if (h.topology) { // distinct-vertex table per axis permutation + vertex ids per quad
 		h.vtab_stride = (3u * h.n_verts + 1u) & ~1u; // even: the {x,y} pairs stay 8-byte aligned
-		h.off_vtab = off;  off = align4(off + 6u * h.vtab_stride);
+		h.off_vtab = off;  off = align4(off + SSX_PERM_COUNT * h.vtab_stride);
 		h.off_vid = off;   off = align4(off + s->n_quads);
+		h.off_vtab4 = off; off = align4(off + SSX_PERM_COUNT * 4u * h.n_verts);   // 16-byte aligned (align4)
+		h.off_triofs = off; off = align4(off + 4u * s->n_quads);                    // 8-byte aligned entries
 	}
 	h.words_without_perm = off;
 	h.off_perm = off;      off = align4(off + s->n_quads * SSX_PERM_WORDS_PER_QUAD); // last: not staged by the specialised kernels
@@ -302,10 +305,11 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	for (uint32_t q = 0; q < s->n_quads; ++q) {
 		const ssx_quad& Q = s->quads[q];
 		const ssx_vertex* vs[4] = { &Q.v00, &Q.v10, &Q.v11, (Q.flags & SSX_PRIM_TRI) ? &Q.v00 : &Q.v01 }; // a triangle's v01 is not part of the scene
-		for (uint32_t p = 0; p < 6; ++p) {
-			// (kx,ky,kz) of geometry.cpp:19-32: kz=0 -> (1,2,0); kz=1 -> (2,0,1); kz=2 -> (0,1,2); odd p swaps kx,ky
-			uint32_t kz = p >> 1, kx = (kz + 1) % 3, ky = (kz + 2) % 3;
-			if (p & 1u) { uint32_t t = kx; kx = ky; ky = t; }
+		for (uint32_t p = 0; p < SSX_PERM_COUNT; ++p) {
+			// p = kz of geometry.cpp:19-24; (kx, ky) = the other two axes in the table's fixed order (ssx_blob.h: the reference's two
+			// orders per kz give the same hits)
+			static const uint32_t axes[3][2] = SSX_PERM_AXES;
+			const uint32_t kz = p, kx = axes[p][0], ky = axes[p][1];
 			float* dst = perm + q * SSX_PERM_WORDS_PER_QUAD + p * 12u;
 			for (int v = 0; v < 4; ++v) { dst[2 * v + 0] = vs[v]->pos[kx]; dst[2 * v + 1] = vs[v]->pos[ky]; dst[8 + v] = vs[v]->pos[kz]; } // x0 y0 .. x3 y3 | z0..z3
 		}
@@ -333,14 +337,24 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	}
 	if (h.topology) {
 		float* vt = reinterpret_cast<float*>(blob.data() + h.off_vtab);
-		for (uint32_t p = 0; p < 6; ++p) {
-			uint32_t kz = p >> 1, kx = (kz + 1) % 3, ky = (kz + 2) % 3;
-			if (p & 1u) { uint32_t t = kx; kx = ky; ky = t; }
+		float* vt4 = reinterpret_cast<float*>(blob.data() + h.off_vtab4);
+		for (uint32_t p = 0; p < SSX_PERM_COUNT; ++p) {
+			static const uint32_t axes[3][2] = SSX_PERM_AXES;
+			const uint32_t kz = p, kx = axes[p][0], ky = axes[p][1];
 			float* dst = vt + p * h.vtab_stride;
 			for (uint32_t k = 0; k < h.n_verts; ++k) { dst[2 * k] = distinct[k][kx]; dst[2 * k + 1] = distinct[k][ky]; dst[2 * h.n_verts + k] = distinct[k][kz]; }
+			float* d4 = vt4 + p * 4u * h.n_verts;
+			for (uint32_t k = 0; k < h.n_verts; ++k) { d4[4 * k] = distinct[k][kx]; d4[4 * k + 1] = distinct[k][ky]; d4[4 * k + 2] = distinct[k][kz]; d4[4 * k + 3] = 0.0f; }
 		}
-		for (uint32_t q = 0; q < s->n_quads; ++q)
+		for (uint32_t q = 0; q < s->n_quads; ++q) {
 			blob[h.off_vid + q] = (uint32_t)vid[q][0] | ((uint32_t)vid[q][1] << 8) | ((uint32_t)vid[q][2] << 16) | ((uint32_t)vid[q][3] << 24);
+			// triangle `which` of quad q = vertices (v00, v10 | v11, v11 | v01): byte offsets of their 16-byte records (n_verts <= 128: below 2^16)
+			for (uint32_t which = 0; which < 2u; ++which) {
+				const uint32_t a = 16u * vid[q][0], b = 16u * vid[q][1 + which], c = 16u * vid[q][2 + which];
+				blob[h.off_triofs + 2u * (2u * q + which)] = a | (b << 16);
+				blob[h.off_triofs + 2u * (2u * q + which) + 1u] = c;
+			}
+		}
 	}
 	memcpy(blob.data() + h.off_lights, s->lights, 4 * s->n_lights);
 	SsxBlobSpectrum* bs = reinterpret_cast<SsxBlobSpectrum*>(blob.data() + h.off_spectra);
@@ -425,7 +439,9 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p, bool ask_device =
 	a.width = p->width; a.height = p->height;
 	a.tiles_x = (p->width + 7u) / 8u;
 	a.n_tiles = a.tiles_x * ((p->height + 7u) / 8u);
-	a.tile_first = p->tile_first; a.tile_stride = p->tile_stride; a.tile_skew = p->tile_skew;
+	// tile_skew only ever enters as (ty * tile_skew) % tiles_x: reduced here, so that the kernels' 32-bit product cannot wrap where the
+	// hosts' wider arithmetic (host/renderer.cpp, simple_spectral_amd/dist.py) does not -- any skew names the same tile list everywhere
+	a.tile_first = p->tile_first; a.tile_stride = p->tile_stride; a.tile_skew = p->tile_skew % a.tiles_x;
 	a.indirect_only = p->indirect_only ? 1u : 0u;
 	a.no_els = p->no_explicit_light_sampling ? 1u : 0u;
 	a.no_flat_field = p->no_flat_field_correction ? 1u : 0u;
@@ -536,7 +552,6 @@ struct Batch { SsxKernelArgs a; uint32_t units; uint64_t n_rec; hipEvent_t* tev;
 // samples per pixel of a work unit for the uploaded scene (before make_batch halves it for small launches)
 uint32_t unit_spp_of(const ssx_ctx* ctx) {
 	uint32_t g = ctx->calib_frames >= 2.0f ? SSX_MAX_UNIT_KS / 2u : SSX_MAX_UNIT_KS;
-	if (const char* e = debug_env("SSX_UNIT_SPP")) { const int v = atoi(e); if (v >= 1 && v <= (int)SSX_MAX_UNIT_KS) g = (uint32_t)v; } // A/B runs
 	return g;
 }
 
@@ -573,7 +588,11 @@ Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1) {
 
 // dynamic LDS of a path-kernel workgroup: coefficient table + staged blob + 4 waves' shadow-ray queues and log counters
 size_t path_lds_bytes(uint32_t blob_words, uint32_t queue_words) {
-	return ((size_t)blob_words + SSX_LDS_PREFIX_WORDS) * 4 + 4u * ((size_t)SSX_QUEUE_ENTRIES * queue_words + SSX_WAVE_COUNTER_WORDS) * 4u;
+	size_t n = ((size_t)blob_words + SSX_LDS_PREFIX_WORDS) * 4 + 4u * ((size_t)SSX_QUEUE_ENTRIES * queue_words + SSX_WAVE_COUNTER_WORDS) * 4u;
+#ifdef SSX_REGTIME // profiling build: the waves' region timers (ssx_lanestat.h SSX_TIME)
+	n += 4u * SSX_NTIME * 8u;
+#endif
+	return n;
 }
 // the path megakernel for a pass-1 variant (0 generic, 1 Cornell topology, 2 plane topology) and queue entry size
 typedef void (*path_kernel_t)(SsxKernelArgs);
@@ -765,7 +784,7 @@ int launch_finalize(ssx_ctx* ctx, const ssx_render_params* p, uint32_t spp, floa
 	uint32_t pixels = p->width * p->height;
 	hipLaunchKernelGGL(ssx_finalize_kernel, dim3((pixels + 255u) / 256u), dim3(256), 0, stream,
 	                   (const double*)ctx->d_accum, (float4*)d_out, p->width, p->height, (p->width + 7u) / 8u,
-	                   p->tile_first, p->tile_stride, spp, ctx->rgb_mode ? 1u : 0u, done_tiles, p->tile_skew);
+	                   p->tile_first, p->tile_stride, spp, ctx->rgb_mode ? 1u : 0u, done_tiles, p->tile_skew % ((p->width + 7u) / 8u));
 	SSX_HIP(ctx, hipGetLastError());
 	return SSX_OK;
 }
@@ -1086,7 +1105,13 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	if (ctx->device_pending) SSX_HIP(ctx, hipStreamWaitEvent(stream, ctx->ev_device_done, 0));
 	{
 		LaunchPlan probe = make_plan(ctx, p, !capturing);
-		const size_t need = (size_t)probe.args.my_tiles * 64u * (p->spp < probe.max_spp_per_launch ? p->spp : probe.max_spp_per_launch);
+		// the batch ensure_samples below will size the arrays for -- the same expression.  While capturing the device cannot be asked
+		// for its free memory: the cap the warm-up render outside the capture worked with is the one that holds (device_spp_cap).
+		if (capturing && ctx->device_spp_cap && probe.max_spp_per_launch > ctx->device_spp_cap) probe.max_spp_per_launch = ctx->device_spp_cap;
+		uint32_t probe_batch = p->spp_per_launch ? p->spp_per_launch : p->spp;
+		if (probe_batch > p->spp) probe_batch = p->spp;
+		if (probe_batch > probe.max_spp_per_launch) probe_batch = probe.max_spp_per_launch;
+		const size_t need = (size_t)probe.args.my_tiles * 64u * probe_batch;
 		const bool grow = ctx->accum_pixels < accum_slots(p->width, p->height) || ctx->sample_slots < need;
 		if (grow && capturing) return fail(ctx, SSX_ERR_STATE, "the context's buffers have to grow for this render: run it once outside the stream capture first");
 		if (ctx->device_pending && grow) {
@@ -1098,6 +1123,8 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, accum_slots(p->width, p->height) * 4 * sizeof(double), stream));
 	if (!capturing) maybe_swap_jit(ctx, (uint64_t)p->width * p->height * p->spp / p->tile_stride);
 	LaunchPlan pl = make_plan(ctx, p, !capturing);
+	if (!capturing) ctx->device_spp_cap = pl.max_spp_per_launch;
+	else if (ctx->device_spp_cap && pl.max_spp_per_launch > ctx->device_spp_cap) pl.max_spp_per_launch = ctx->device_spp_cap;
 	// one batch when the whole render fits the buffer budget, else batches back to back
 	uint32_t batch = p->spp_per_launch ? p->spp_per_launch : p->spp;
 	if (batch > p->spp) batch = p->spp;
@@ -1375,6 +1402,13 @@ int ssx_lanestat(unsigned long long* out, int reset) {
 	if (reset) { unsigned long long z[2 * SSX_NSTAT] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_lanestat), z, sizeof z); }
 	(void)hipDeviceSynchronize();
 	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lanestat), 2 * SSX_NSTAT * sizeof(unsigned long long));
+}
+#endif
+#ifdef SSX_REGTIME // profiling build only (tools/regtime.py)
+int ssx_regtime(unsigned long long* out, int reset) { // SSX_NTIME shader-clock sums, one per region (ssx_lanestat.h SSX_TIME)
+	if (reset) { unsigned long long z[SSX_NTIME] = {}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_regtime), z, sizeof z); }
+	(void)hipDeviceSynchronize();
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_regtime), SSX_NTIME * sizeof(unsigned long long));
 }
 #endif
 

@@ -21,14 +21,22 @@
 // prefix + blob + 4 (narrow) queues + 4 x 16 counters must fit the 64 KiB a workgroup may allocate: 65536 - 320 - 16384 - 256 = 48576
 #define SSX_BLOB_MAX_BYTES 48576u
 
-// Permuted vertex table: for quad q and axis permutation p (0..5) the 12 floats
+// Permuted vertex table: for quad q and axis permutation p (0..2) the 12 floats
 //   v00[kx] v00[ky]  v10[kx] v10[ky]  v11[kx] v11[ky]  v01[kx] v01[ky] | v00[kz] v10[kz] v11[kz] v01[kz]
-// ((x,y) pairs land in aligned register pairs for the packed-f32 pass-1 arithmetic)
 // so a lane reads its ray's shear-space ordering with three 16-byte LDS loads instead of
-// selecting components per vertex.  p = 2*kz_case + swapped, with (kx,ky,kz) as chosen by the
-// reference's axis rule (src/geometry.cpp:17-32).  The six 48-byte copies of one quad sit in
-// distinct 16-byte bank slots, so lanes with different p do not conflict.
-#define SSX_PERM_WORDS_PER_QUAD (6u * 12u)
+// selecting components per vertex.  p = kz, the ray's dominant axis by the reference's rule (src/geometry.cpp:17-24), and
+// (kx, ky) = SSX_PERM_AXES[p]: the two other axes in ONE fixed order per p.  The reference orders them by (kz+1)%3, (kz+2)%3 and
+// exchanges them where dir[kz] < 0 (:26-32, to keep the winding for a back-face test it does not make); exchanging kx and ky
+// exchanges x' and y' of every sheared vertex, which negates every edge function U = B.y*C.x - B.x*C.y EXACTLY (a*b - c*d against
+// c*d - a*b in round-to-nearest), and with U, V, W negated det, T and 1/det are negated exactly, the mixed-sign test, |det| > EPS
+// and sign(T) == sign(det) read the same, and dist = T/det and the barycentrics U/det are the same floats -- also through the
+// binary64 fallback.  So three tables do where the reference's rule names six orders, and the ray set-up selects half as much
+// (rounds 1-4 kept all six; profiles/r05/isa_census.md).  The order per p is chosen so that each of the two slots is one select:
+// slot A = x unless x is dominant (then y), slot B = z unless z is dominant (then y).
+#define SSX_PERM_COUNT 3u
+#define SSX_PERM_WORDS_PER_QUAD (SSX_PERM_COUNT * 12u)
+// (kx, ky) per p = kz
+#define SSX_PERM_AXES { { 1u, 2u }, { 0u, 2u }, { 0u, 1u } }
 
 struct SsxBlobSpectrum { // 4 words
 	uint32_t offset; // word offset of the first sample from the blob start; the words at offset-2, offset-1, offset+n, offset+n+1 are 0
@@ -70,10 +78,15 @@ struct SsxBlobHeader {
 	// (word offset of element 0, 16-byte aligned; valid when the *_one_grid flag is set)
 	uint32_t off_basis4, off_observer4;
 	// Topology-specialised kernels (csrc/ssx_pass1_gen.h): topology = 0 (none) or the id of the built-in mesh topology the
-	// scene's corners coincide like; off_vtab: for each of the 6 axis permutations vtab_stride words: {v[kx], v[ky]} of the
-	// n_verts distinct vertices, then their v[kz]; off_vid: per quad 4 x u8 distinct-vertex ids of v00, v10, v11, v01.
+	// scene's corners coincide like; off_vtab: for each of the 3 axis permutations vtab_stride words: {v[kx], v[ky]} of the
+	// n_verts distinct vertices, then their v[kz] (pass 1 reads it with compile-time offsets); off_vid: per quad 4 x u8
+	// distinct-vertex ids of v00, v10, v11, v01.  Pass 2 fetches the three vertices of ONE candidate triangle per trip, by run-time
+	// index: for that the same vertices once more as 16-byte records {v[kx], v[ky], v[kz], 0} per permutation (off_vtab4, stride
+	// 4 * n_verts words) and per triangle t = 2 * quad + which the byte offsets of its A, B, C records within a permutation's
+	// table, off_triofs + 2 t: { A | B << 16, C } -- one 8-byte and three 12-byte LDS reads behind 6 integer instructions where the
+	// {x,y} / z tables and the vertex ids took 17 (profiles/r05/isa_census.md).
 	// The per-quad permuted table (off_perm) is the LAST section of the blob: the specialised kernels do not stage it.
-	uint32_t topology, n_verts, off_vtab, vtab_stride, off_vid, words_without_perm, pad3_[2];
+	uint32_t topology, n_verts, off_vtab, vtab_stride, off_vid, words_without_perm, off_vtab4, off_triofs;
 	// Intersection candidates are kept as 64-bit masks of 32 primitives (two triangle bits each); scenes with more primitives are
 	// worked through in groups of 32 in list order (ssx_kernels.hip: trace).  tri_valid[g]: the triangle bits of group g that
 	// exist (a PrimTri primitive has no second triangle).

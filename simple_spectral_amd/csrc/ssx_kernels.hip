@@ -135,6 +135,10 @@ struct Lds {
 		return reinterpret_cast<const float*>(w + hdr().off_vtab) + p * hdr().vtab_stride;
 	}
 	__device__ __forceinline__ uint32_t vid(uint32_t q) const { return w[hdr().off_vid + q]; } // 4 x u8: distinct-vertex ids of v00, v10, v11, v01
+	// pass 2 of the topology-specialised kernels: the distinct vertices as 16-byte records {x, y, z, 0} of axis permutation p (byte
+	// address), and per triangle the byte offsets of its three records within such a table { A | B << 16, C }
+	__device__ __forceinline__ const char* vtab4(uint32_t p) const { return reinterpret_cast<const char*>(w + hdr().off_vtab4) + p * (16u * hdr().n_verts); }
+	__device__ __forceinline__ uint2 triofs(uint32_t t) const { return reinterpret_cast<const uint2*>(w + hdr().off_triofs)[t]; }
 	__device__ __forceinline__ const SsxBlobQuad& quad(uint32_t q) const {
 		return reinterpret_cast<const SsxBlobQuad*>(w + hdr().off_quads)[q];
 	}
@@ -435,29 +439,31 @@ __device__ __forceinline__ void flux_to_xyz(const Lds& L, const Hero& flux, floa
 struct RaySetup { // per-ray constants of the watertight test (geometry.cpp:17-37), hoisted
 	float okx, oky, okz; // ray origin in (kx,ky,kz) order
 	float Sx, Sy, Sz;
-	uint32_t perm;       // 2*kz + swapped
+	uint32_t perm;       // kz: which of the three axis-permuted vertex tables the ray reads (ssx_blob.h)
 };
 
 __device__ __forceinline__ RaySetup ray_setup(V3 orig, V3 dir) {
-	// geometry.cpp:19-32 as selects on three compare masks (a select costs what an FMA costs: the nested-if form of the
-	// reference compiles to 23 of them; this to 17)
+	// geometry.cpp:19-24: kz = the axis of the direction's largest magnitude (the reference's comparisons, ties included).  The two
+	// other axes go to the slots (kx, ky) in the table's fixed order per kz (ssx_blob.h SSX_PERM_AXES: slot A = x unless x is
+	// dominant, then y; slot B = z unless z is dominant, then y) -- the reference's own order and its exchange for dir[kz] < 0
+	// (:25-32) give exactly negated edge functions, hence the same hits, distances and barycentrics (argument in ssx_blob.h) --
+	// so the set-up is 12 selects where the reference's nested ifs compile to 23 and rounds 1-4 had 17.
 	const float ax = __builtin_fabsf(dir.x), ay = __builtin_fabsf(dir.y), az = __builtin_fabsf(dir.z);
 	const bool xy = ax > ay;
-	const bool k0 = xy && ax > az;       // kz = 0, (kx, ky) = (1, 2)
-	const bool k1 = !xy && ay > az;      // kz = 1, (kx, ky) = (2, 0); otherwise kz = 2, (kx, ky) = (0, 1)
+	const bool k0 = xy && ax > az;       // kz = 0
+	const bool k1 = !xy && ay > az;      // kz = 1; otherwise kz = 2
+	// (slot B through the two conditions at hand: a third one, "not kz = 2", costs the compiler five instructions to materialise)
 	const float dkz = k0 ? dir.x : (k1 ? dir.y : dir.z);
-	const float da = k0 ? dir.y : (k1 ? dir.z : dir.x), db = k0 ? dir.z : (k1 ? dir.x : dir.y);
-	const float oa = k0 ? orig.y : (k1 ? orig.z : orig.x), ob = k0 ? orig.z : (k1 ? orig.x : orig.y);
-	const bool swapped = dkz < 0; // :32: kx and ky trade places
+	const float da = k0 ? dir.y : dir.x, db = k0 ? dir.z : (k1 ? dir.z : dir.y);
 	RaySetup rs;
 	// three IEEE divisions by one divisor: one binary64 reciprocal, one multiply each (exact: ssx_exact.h)
 	const double dkz_recip = ssx_exact::div64_rcp_any(dkz);
-	rs.Sx = ssx_exact::div64_by(swapped ? db : da, dkz_recip);
-	rs.Sy = ssx_exact::div64_by(swapped ? da : db, dkz_recip);
+	rs.Sx = ssx_exact::div64_by(da, dkz_recip);
+	rs.Sy = ssx_exact::div64_by(db, dkz_recip);
 	rs.Sz = ssx_exact::div64_by(1.0f, dkz_recip);
-	rs.okx = swapped ? ob : oa; rs.oky = swapped ? oa : ob;
+	rs.okx = k0 ? orig.y : orig.x; rs.oky = k0 ? orig.z : (k1 ? orig.z : orig.y);
 	rs.okz = k0 ? orig.x : (k1 ? orig.y : orig.z);
-	rs.perm = (k0 ? 0u : (k1 ? 2u : 4u)) + (swapped ? 1u : 0u); // 2*kz + swapped
+	rs.perm = k0 ? 0u : (k1 ? 1u : 2u); // = kz
 	return rs;
 }
 
@@ -521,7 +527,7 @@ namespace {
 // quad_mask (TOPO 0 only): wave-uniform bit per primitive, or nullptr; primitives whose bit is clear are known not to be
 // hit by any ray of the wave (ssx_tile_mask_kernel: the camera rays of a pixel tile) and are left out of pass 1.
 template <int TOPO>
-__device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_quad, bool has_ray, HitInfo& hit, int stat_base = 0, const uint32_t* quad_mask = nullptr) {
+__device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_quad, bool has_ray, HitInfo& hit, int stat_base = 0, const uint32_t* quad_mask = nullptr, SsxTimer* tm = nullptr) {
 	const RaySetup rs = ray_setup(orig, dir);
 	const SsxBlobHeader& hd = L.hdr();
 	const uint32_t nq = hd.n_quads;
@@ -597,6 +603,7 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		const uint32_t ign = (uint32_t)ignore_quad - base; // (a negative ignore_quad, or one of another group, falls outside 0..31)
 		if (ign < 32u) cand &= ~(3ull << (2u * ign));
 		if (!has_ray) cand = 0ull;
+		if (tm) SSX_TIME(*tm, stat_base == 0 ? 7 : 12); // (profiling build: ray set-up + pass 1 end here)
 		while (cand) {
 			SSX_STAT(stat_base + 1); // pass-2 trips x lanes with a candidate
 			uint32_t bit = (uint32_t)__builtin_ctzll(cand);
@@ -606,12 +613,12 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 			// { x0 y0 x1 y1 x2 y2 x3 y3 | z0 z1 z2 z3 }
 			float pv3[9];
 			if constexpr (TOPO != 0) {
-				const uint32_t ids = L.vid(q);
-				const uint32_t ia = ids & 0xFFu, ib = (ids >> (8u + 8u * which)) & 0xFFu, ic = (ids >> (16u + 8u * which)) & 0xFFu;
-				const float* vt = L.vtab(rs.perm);
-				const float* vz = vt + 2u * L.hdr().n_verts;
-				const float2 Axy = *reinterpret_cast<const float2*>(vt + 2u * ia), Bxy = *reinterpret_cast<const float2*>(vt + 2u * ib), Cxy = *reinterpret_cast<const float2*>(vt + 2u * ic);
-				pv3[0] = Axy.x; pv3[1] = Axy.y; pv3[2] = vz[ia]; pv3[3] = Bxy.x; pv3[4] = Bxy.y; pv3[5] = vz[ib]; pv3[6] = Cxy.x; pv3[7] = Cxy.y; pv3[8] = vz[ic];
+				// one 8-byte read names the triangle's three vertex records, three 12-byte reads fetch them (ssx_blob.h: off_triofs, off_vtab4)
+				struct alignas(16) V3a { float x, y, z; };
+				const uint2 to = L.triofs(bit);
+				const char* vt = L.vtab4(rs.perm);
+				const V3a A3 = *reinterpret_cast<const V3a*>(vt + (to.x & 0xFFFFu)), B3 = *reinterpret_cast<const V3a*>(vt + (to.x >> 16)), C3 = *reinterpret_cast<const V3a*>(vt + to.y);
+				pv3[0] = A3.x; pv3[1] = A3.y; pv3[2] = A3.z; pv3[3] = B3.x; pv3[4] = B3.y; pv3[5] = B3.z; pv3[6] = C3.x; pv3[7] = C3.y; pv3[8] = C3.z;
 			} else {
 				float2 Axy, Bxy, Cxy; float Az_, Bz_, Cz_;
 				if (perm_hbm) { // (loads from HBM; the two address spaces do not share a pointer)
@@ -633,7 +640,8 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 			// has tested exactly that on these same floats (same operands, same operations; a shared edge evaluated the other
 			// way round is the exact negative) and a candidate is a triangle that passed, so nothing is left to test here.
 			// With a zero among them the reference decides on the binary64 values (:57-67), which pass 1 does not look at:
-			if (U == 0.0f || V == 0.0f || W == 0.0f) {
+			// (one three-way minimum of the magnitudes and one compare: a NaN among them does not hide a zero, and none is zero if all are NaN)
+			if (__builtin_fminf(__builtin_fminf(__builtin_fabsf(U), __builtin_fabsf(V)), __builtin_fabsf(W)) == 0.0f) {
 				double Ud = (double)B.y * (double)C.x - (double)B.x * (double)C.y;
 				double Vd = (double)C.y * (double)A.x - (double)C.x * (double)A.y;
 				double Wd = (double)A.y * (double)B.x - (double)A.x * (double)B.y;
@@ -653,6 +661,7 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 				if (which == 0u) cand &= ~(1ull << (bit + 1u)); // PrimQuad::intersect: tri0 hit -> tri1 not tested
 			}
 		}
+		if (tm) SSX_TIME(*tm, stat_base == 0 ? 8 : 13); // (profiling build: pass 2)
 	}
 }
 
@@ -1115,7 +1124,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 // (vis[index]; narrow entries, the contribution went to nee[index] when the ray was parked) or the finished next-event
 // term (nee[index] = visible ? contribution : 0; wide entries).  Called in uniform control flow.
 template <int TOPO, bool NARROW>
-__device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& a, const ShadowQ& q, uint32_t first, uint32_t n) {
+__device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& a, const ShadowQ& q, uint32_t first, uint32_t n, SsxTimer& tm) {
 	const uint32_t lane = threadIdx.x & 63u;
 	const bool have = lane < n;
 	const bool narrow = NARROW;
@@ -1126,7 +1135,7 @@ __device__ __forceinline__ void shadow_flush(const Lds& L, const SsxKernelArgs& 
 	}
 	const uint32_t tag = __float_as_uint(e2.z);
 	HitInfo sh;
-	trace<TOPO>(L, mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y), (int)(tag & 0xFFu), have, sh, 2);
+	trace<TOPO>(L, mk(e0.x, e0.y, e0.z), mk(e0.w, e1.x, e1.y), (int)(tag & 0xFFu), have, sh, 2, nullptr, &tm);
 	if (have) {
 		const bool visible = sh.tri >= 0 && ((uint32_t)sh.tri >> 1) == (tag >> 8);
 		if (narrow) log_vis(a, __float_as_uint(e2.w)) = visible ? (uint8_t)1 : (uint8_t)0;
@@ -1614,6 +1623,12 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	                    // cohort | unit tag << 2 | (unit tag * unit_cohorts + cohort) << 3 | (sample's position in the cohort) << 8
 	constexpr uint32_t queue_words = SSX_QUEUE_ENTRIES * (NARROW ? SSX_QUEUE_WORDS_NARROW : SSX_QUEUE_WORDS_WIDE); // per wave (ssx_blob.h)
 	uint32_t* const log_cnt = lds_words + a.blob_words + 4u * queue_words + wave * SSX_WAVE_COUNTER_WORDS; // see LogRef
+	SsxTimer tm;
+#ifdef SSX_REGTIME // the wave's region timers (ssx_lanestat.h): behind the four waves' log counters
+	tm.acc = reinterpret_cast<unsigned long long*>(lds_words + a.blob_words + 4u * queue_words + 4u * SSX_WAVE_COUNTER_WORDS) + wave * SSX_NTIME;
+	if (lane < (uint32_t)SSX_NTIME) tm.acc[lane] = 0ull;
+	tm.last = __builtin_amdgcn_s_memtime();
+#endif
 	ShadowQ sq; // this wave's queue behind the blob (16-byte aligned: blob_words is a multiple of 4)
 	sq.e = reinterpret_cast<float4*>(lds_words + a.blob_words + wave * queue_words);
 	sq.count = 0; sq.cnt = log_cnt;
@@ -1683,11 +1698,13 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		while (sq.count >= SSX_SQ_FLUSH_AT || (drain && sq.count)) {
 			const uint32_t take = min(sq.count, 64u);
 			sq.count -= take;
-			shadow_flush<TOPO, NARROW>(L, a, sq, sq.count, take);
+			shadow_flush<TOPO, NARROW>(L, a, sq, sq.count, take, tm);
+			SSX_TIME(tm, 5); // (shadow flush: queue read, result store; its trace is timed inside)
 		}
 		if (fold_old) {
 			if (a.fuse_resolve) unit_fold<NARROW>(L, a, old, wave_slot, old_tag, log_cnt);
 			old_pending = false;
+			SSX_TIME(tm, 6); // (fold)
 		}
 	};
 	// rotate: the current unit has no items left and the previous one is folded; then fetch the next unit
@@ -1734,13 +1751,16 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			}
 			sq.count += (uint32_t)__popcll(__ballot(pushed));
 		}
+		SSX_TIME(tm, 3); // (profiling build: the shading of the iteration -- path_step, end_path -- ends here; SSX_TIME only ever stands in wave-uniform control flow)
 		rotate_fetch(); // (3)
 		if (!a.pre_hits) refill(false); // the new samples' camera rays ride in the trace (4): their loads are in flight during (2)
+		SSX_TIME(tm, 4); // (rotate / unit fetch)
 		flush_fold(); // (2)
+		SSX_TIME(tm, 14); // (flush_fold's own tests)
 		// (4)
 		if (__any(active)) {
 			HitInfo hit;
-			trace<TOPO>(L, p.orig, p.dir, p.ignore, active, hit, 0);
+			trace<TOPO>(L, p.orig, p.dir, p.ignore, active, hit, 0, nullptr, &tm);
 			// (unconditional assignments: nothing of the previous hit stays live across the trace)
 			p.hit_tri = hit.tri; p.hit_dist = hit.dist;
 			float st_x = 0.0f, st_y = 0.0f;
@@ -1754,10 +1774,15 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			}
 			p.hit_st_x = st_x; p.hit_st_y = st_y;
 		}
+		SSX_TIME(tm, 9); // (hit -> path state, hitrec.st)
 		if (a.pre_hits) refill(true); // (5)
+		SSX_TIME(tm, 10); // (refill)
 		// nothing runs, nothing is left to hand out, nothing waits for its flush or fold
 		if (!__any(active) && !cur_valid && !more && !old_pending && sq.count == 0u) break;
 	}
+#ifdef SSX_REGTIME
+	if (lane < (uint32_t)SSX_NTIME) atomicAdd(&g_regtime[lane], tm.acc[lane]);
+#endif
 }
 
 #ifndef SSX_WAVES_PER_EU

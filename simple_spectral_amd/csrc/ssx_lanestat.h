@@ -12,6 +12,23 @@ __device__ unsigned long long g_lanestat[2 * SSX_NSTAT];
 #define SSX_STAT(r) do {} while (0)
 #endif
 
+// Profiling build of its own (-DSSX_REGTIME, tools/regtime.py; NOT together with SSX_LANESTAT, whose global atomics slow the kernel 40-fold).
+// SSX_TIME(tm, r): where the waves' TIME goes, measured (tools/regtime.py; VERDICT r04 item 1 asked for a cycle-weighted view and
+// the static census of tools/isa_census.py prices issue slots only): the shader clock (s_memtime) since the wave's previous mark is
+// added to region r -- the region that ends here -- in the wave's own LDS accumulators (behind the log counters: 16 x 8 bytes per wave),
+// flushed to g_regtime when the wave leaves the kernel.  A wave's time in a region includes the cycles it waited for the SIMD's other
+// three waves, for LDS / HBM round trips and for the instruction cache: regions whose share of the time exceeds their share of the
+// issue cycles are the latency-bound ones.
+#ifdef SSX_REGTIME
+#define SSX_NTIME 16
+__device__ unsigned long long g_regtime[SSX_NTIME];
+struct SsxTimer { unsigned long long last; unsigned long long* acc; };
+#define SSX_TIME(tm, r) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63u) == 0u) atomicAdd((tm).acc + (r), t_ - (tm).last); (tm).last = t_; } while (0)
+#else
+struct SsxTimer {};
+#define SSX_TIME(tm, r) do { (void)(tm); } while (0)
+#endif
+
 
 
 

@@ -138,7 +138,7 @@ def source_ranges():
         cold.append((func, a, block_end(a) if block else a))
     one("normalize3_any", "if (d < 0x1p-100f) s = 1.0f / __builtin_sqrtf(d);")
     one("func_bar", "if (lensq < 0x1p-100f) is = 1.0f / __builtin_sqrtf(lensq);")
-    one("trace", "if (U == 0.0f || V == 0.0f || W == 0.0f) {", True)                      # the binary64 edge fallback (its three compares are priced below)
+    one("trace", "__builtin_fabsf(W)) == 0.0f) {", True)                      # the binary64 edge fallback (its three compares are priced below)
     one("operator()", "else { const uint32_t r = item % npx;")                          # ragged tiles
     one("render_body", "else { const uint32_t r = item % npx;")
     one("resolve_records", "if ((K[s] >> 26) & 1u) {", True)

@@ -175,6 +175,40 @@ __global__ void __launch_bounds__(256) k_mul_with_ds(float* out, float seed) {
 	SINKF;
 }
 
+
+// round 5: do two kinds of instruction in one stream cost the sum of their single costs, or do they overlap (separate pipes)?
+// 8 groups of {A on accumulator i, B on accumulator j} per REP8; the printed figure is cycles per PAIR.
+#define OPPAIR(TA, TB, X, Y) asm volatile(TA "\n\t" TB : "+v"(X), "+v"(Y) : "v"(b));
+#define PAIRK(name, TA, TB) KERNEL(name, F8, OPPAIR(TA, TB, a0, a1) OPPAIR(TA, TB, a2, a3) OPPAIR(TA, TB, a4, a5) OPPAIR(TA, TB, a6, a7) OPPAIR(TA, TB, a1, a0) OPPAIR(TA, TB, a3, a2) OPPAIR(TA, TB, a5, a4) OPPAIR(TA, TB, a7, a6), SINKF)
+PAIRK(k_p_mul_lshladd, "v_mul_f32 %0, %0, %2", "v_lshl_add_u32 %1, %1, 2, %2")
+PAIRK(k_p_mul_bfe, "v_mul_f32 %0, %0, %2", "v_bfe_u32 %1, %1, 3, 8")
+PAIRK(k_p_mul_and, "v_mul_f32 %0, %0, %2", "v_and_b32 %1, %1, %2")
+PAIRK(k_p_mul_sel64, "v_mul_f32 %0, %0, %2", "v_cndmask_b32_e64 %1, %1, %2, s[20:21]")
+PAIRK(k_p_mul_cmp, "v_mul_f32 %0, %0, %2", "v_cmp_lt_f32_e64 s[22:23], %1, %2")
+PAIRK(k_p_mul_min3, "v_mul_f32 %0, %0, %2", "v_min3_f32 %1, %1, %2, %2")
+PAIRK(k_p_mul_alignbit, "v_mul_f32 %0, %0, %2", "v_alignbit_b32 %1, %1, %2, 31")
+PAIRK(k_p_mul_cvt, "v_mul_f32 %0, %0, %2", "v_cvt_i32_f32 %1, %1")
+PAIRK(k_p_mul_fma, "v_mul_f32 %0, %0, %2", "v_fma_f32 %1, %1, %2, %2")
+PAIRK(k_p_mul_add, "v_mul_f32 %0, %0, %2", "v_add_f32 %1, %1, %2")
+PAIRK(k_p_mul_rcp, "v_mul_f32 %0, %0, %2", "v_rcp_f32 %1, %1")
+PAIRK(k_p_lshladd_bfe, "v_lshl_add_u32 %0, %0, 2, %2", "v_bfe_u32 %1, %1, 3, 8")
+PAIRK(k_p_med3_min3, "v_med3_f32 %0, %0, %2, %2", "v_min3_f32 %1, %1, %2, %2")
+__global__ void __launch_bounds__(256) k_p_mul_fma64(float* out, float seed) {
+	F8; double d0 = seed, d1 = seed + 1, d2 = seed + 2, d3 = seed + 3, e = seed * 0.5 + threadIdx.x;
+	for (int it = 0; it < N_ITER; ++it) {
+		REP8(
+			asm volatile("v_mul_f32 %0, %0, %2\n\tv_fma_f64 %1, %1, %3, %3" : "+v"(a0), "+v"(d0) : "v"(b), "v"(e)); asm volatile("v_mul_f32 %0, %0, %2\n\tv_fma_f64 %1, %1, %3, %3" : "+v"(a1), "+v"(d1) : "v"(b), "v"(e));
+			asm volatile("v_mul_f32 %0, %0, %2\n\tv_fma_f64 %1, %1, %3, %3" : "+v"(a2), "+v"(d2) : "v"(b), "v"(e)); asm volatile("v_mul_f32 %0, %0, %2\n\tv_fma_f64 %1, %1, %3, %3" : "+v"(a3), "+v"(d3) : "v"(b), "v"(e));
+			asm volatile("v_mul_f32 %0, %0, %2\n\tv_fma_f64 %1, %1, %3, %3" : "+v"(a4), "+v"(d0) : "v"(b), "v"(e)); asm volatile("v_mul_f32 %0, %0, %2\n\tv_fma_f64 %1, %1, %3, %3" : "+v"(a5), "+v"(d1) : "v"(b), "v"(e));
+			asm volatile("v_mul_f32 %0, %0, %2\n\tv_fma_f64 %1, %1, %3, %3" : "+v"(a6), "+v"(d2) : "v"(b), "v"(e)); asm volatile("v_mul_f32 %0, %0, %2\n\tv_fma_f64 %1, %1, %3, %3" : "+v"(a7), "+v"(d3) : "v"(b), "v"(e));
+		)
+	}
+	if (d0 + d1 + d2 + d3 == 12345.678) out[0] = 1.0f;
+	SINKF;
+}
+// a VALU stream next to SALU work of the same wave (s_and / s_or on masks, as the path loop's control code)
+KERNEL(k_p_mul_salu, F8, asm volatile("v_mul_f32 %0, %0, %1\n\ts_and_b64 s[20:21], s[20:21], s[22:23]" : "+v"(a0) : "v"(b) : "s20", "s21"); asm volatile("v_mul_f32 %0, %0, %1\n\ts_or_b64 s[22:23], s[20:21], s[22:23]" : "+v"(a1) : "v"(b) : "s22", "s23"); asm volatile("v_mul_f32 %0, %0, %1\n\ts_and_b64 s[20:21], s[20:21], s[22:23]" : "+v"(a2) : "v"(b) : "s20", "s21"); asm volatile("v_mul_f32 %0, %0, %1\n\ts_or_b64 s[22:23], s[20:21], s[22:23]" : "+v"(a3) : "v"(b) : "s22", "s23"); asm volatile("v_mul_f32 %0, %0, %1\n\ts_and_b64 s[20:21], s[20:21], s[22:23]" : "+v"(a4) : "v"(b) : "s20", "s21"); asm volatile("v_mul_f32 %0, %0, %1\n\ts_or_b64 s[22:23], s[20:21], s[22:23]" : "+v"(a5) : "v"(b) : "s22", "s23"); asm volatile("v_mul_f32 %0, %0, %1\n\ts_and_b64 s[20:21], s[20:21], s[22:23]" : "+v"(a6) : "v"(b) : "s20", "s21"); asm volatile("v_mul_f32 %0, %0, %1\n\ts_or_b64 s[22:23], s[20:21], s[22:23]" : "+v"(a7) : "v"(b) : "s22", "s23");, SINKF)
+
 // LDS read rates with a per-lane address pattern like the permuted-vertex table
 __global__ void __launch_bounds__(256) k_ds_read_b128(float* out, float seed) {
 	__shared__ float4 buf[1024];
@@ -222,6 +256,10 @@ int main() {
 		{"v_min_f64", k_min_f64}, {"v_ldexp_f64", k_ldexp_f64}, {"v_cmp_lt_f64_e64", k_cmp_f64}, {"v_mad_u64_u32", k_mad_u64_u32},
 		{"cmp, add, sel, mul (8 groups of 4)", k_cmp_add_sel_mul}, {"cmp + 4 x (sel, add) interleaved (8 groups of 8)", k_cmp_4sel_interleaved},
 		{"v_mul_f32 + v_med3_f32 (per pair)", k_mul_med3}, {"7 v_mul_f32 + 1 ds_read_b32 (per 8)", k_mul_with_ds},
+		{"pair v_mul_f32 | v_lshl_add_u32", k_p_mul_lshladd}, {"pair v_mul_f32 | v_bfe_u32", k_p_mul_bfe}, {"pair v_mul_f32 | v_and_b32", k_p_mul_and}, {"pair v_mul_f32 | v_cndmask_e64", k_p_mul_sel64},
+		{"pair v_mul_f32 | v_cmp_lt_f32_e64", k_p_mul_cmp}, {"pair v_mul_f32 | v_min3_f32", k_p_mul_min3}, {"pair v_mul_f32 | v_alignbit", k_p_mul_alignbit}, {"pair v_mul_f32 | v_cvt_i32_f32", k_p_mul_cvt},
+		{"pair v_mul_f32 | v_fma_f32 (3 vgpr)", k_p_mul_fma}, {"pair v_mul_f32 | v_add_f32", k_p_mul_add}, {"pair v_mul_f32 | v_rcp_f32", k_p_mul_rcp}, {"pair v_lshl_add_u32 | v_bfe_u32", k_p_lshladd_bfe},
+		{"pair v_med3_f32 | v_min3_f32", k_p_med3_min3}, {"pair v_mul_f32 | v_fma_f64", k_p_mul_fma64}, {"pair v_mul_f32 | s_and/s_or_b64", k_p_mul_salu},
 	};
 	float* d; hipMalloc(&d, 4096);
 	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
