@@ -1,5 +1,6 @@
 #!/bin/bash
-# closing run of a round on the GPU box (tools/closing_run.sh <tag>): whole GPU suite, bench line, rocprofv3 stats + counters, lane statistics, run-time specialisation
+# closing run of a round on the GPU box (tools/closing_run.sh <tag>): whole GPU suite, bench line, rocprofv3 stats + counters, lane statistics, region times, run-time specialisation,
+# the GPU half of the sanitizer pass
 O=gpurun_out/${1:-closing}; mkdir -p $O
 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -E " passed| failed" $O/pytest_gpu.log | tail -1
 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; python -c "
@@ -7,3 +8,5 @@ import json; d=json.load(open('$O/bench.json')); print({k:d[k] for k in ('value'
 bash tools/profile_round.sh ${1:-closing}_prof > $O/profile_round.log 2>&1; tail -2 $O/profile_round.log | cut -c1-200
 python tools/lanestat.py > $O/lanestat.log 2>&1; tail -22 $O/lanestat.log
 python tools/jit_rate.py > $O/jit_rate.log 2>&1; tail -3 $O/jit_rate.log | cut -c1-300
+python tools/regtime.py --census profiles/r05/isa_census.csv > $O/regtime.log 2>&1; tail -13 $O/regtime.log
+bash tools/sanitize.sh --gpu-only $O/sanitize_gpu.log > /dev/null 2>&1; echo "sanitize rc=$?"; tail -12 $O/sanitize_gpu.log

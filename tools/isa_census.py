@@ -33,7 +33,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "simple_spectral_amd", "csrc", "ssx_kernels.hip")
+SRC = os.environ.get("SSX_CENSUS_SRC") or os.path.join(ROOT, "simple_spectral_amd", "csrc", "ssx_kernels.hip")   # (another revision's source: a worktree)
 LLVM = "/opt/rocm/lib/llvm/bin"
 RARE = 0.002  # weight of code behind a branch that the counters do not see and the design calls rare
 
@@ -138,7 +138,10 @@ def source_ranges():
         cold.append((func, a, block_end(a) if block else a))
     one("normalize3_any", "if (d < 0x1p-100f) s = 1.0f / __builtin_sqrtf(d);")
     one("func_bar", "if (lensq < 0x1p-100f) is = 1.0f / __builtin_sqrtf(lensq);")
-    one("trace", "__builtin_fabsf(W)) == 0.0f) {", True)                      # the binary64 edge fallback (its three compares are priced below)
+    try:
+        one("trace", "__builtin_fabsf(W)) == 0.0f) {", True)
+    except KeyError:
+        one("trace", "if (U == 0.0f || V == 0.0f || W == 0.0f) {", True)     # (round 4's source)                      # the binary64 edge fallback (its three compares are priced below)
     one("operator()", "else { const uint32_t r = item % npx;")                          # ragged tiles
     one("render_body", "else { const uint32_t r = item % npx;")
     one("resolve_records", "if ((K[s] >> 26) & 1u) {", True)
@@ -375,6 +378,10 @@ def main():
     rates = load_rates(args.rates)
     W, OCC, iters_ls = weights(args.lanestat)
 
+    # The pair-aware model (profiles/r05/valu_rates.log, "pair" rows): an instruction of the 4.3-cycle kind next to one of the 2.5-cycle
+    # kind costs the pair ~4.7 cycles, two of the slow kind 8.5, a binary64 operation does not overlap with anything (mul | fma_f64 6.9):
+    # per region  max(2.35 x (fast + slow), 4.2 x slow) + 4.3 x binary64 + 8.8 x transcendental f32 + 16.3 x transcendental f64.
+    pair = collections.defaultdict(lambda: [0.0, 0.0, 0.0, 0.0, 0.0])   # region -> dynamic [fast, slow, f64, trans32, trans64]
     table = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0, 0.0]))   # region -> class -> [static, dyn, cycles]
     opsum = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0, 0.0]))   # region -> opcode form -> ...
     key_of = {}
@@ -388,6 +395,7 @@ def main():
         key_of[region] = key
         cyc, cls = price(op, operands, rates)
         w = W[key]
+        pair[region][4 if cls == "trans f64" else 3 if cls == "trans f32" else 2 if cls in ("binary64 arith",) or (cls == "convert" and "f64" in op) else 1 if cyc > 3.5 else 0] += w
         for t, k in ((table[region], cls), (opsum[region], op + (" [sgpr src]" if "SGPR" in cls else ""))):
             t[k][0] += 1; t[k][1] += w; t[k][2] += w * cyc
 
@@ -399,6 +407,11 @@ def main():
     print("model: %.0f VALU wave-instructions and %.0f issue cycles per loop iteration (%.2f cycles each);" % (tot_dyn, tot_cyc, tot_cyc / tot_dyn))
     print("measured: %.2f ms x %.0f MHz x 1024 SIMDs / %.3g iterations = %.0f SIMD cycles per iteration -> the model's VALU issue time is %.0f %% of the kernel's time"
           % (args.kernel_ms, args.clock_mhz, iters, meas_cyc, 100.0 * tot_cyc / meas_cyc))
+    def pair_cycles(v):
+        return max(2.35 * (v[0] + v[1]), 4.2 * v[1]) + 4.3 * v[2] + 8.8 * v[3] + 16.3 * v[4]
+    tot_pair = sum(pair_cycles(v) for v in pair.values())
+    print("pair-aware model (an instruction of the 4.3-cycle kind overlaps with one of the 2.5-cycle kind; binary64 and transcendentals do not): %.0f cycles per iteration = %.0f %% of the kernel's time"
+          % (tot_pair, 100.0 * tot_pair / meas_cyc))
     print()
     classes = sorted({c for r in table.values() for c in r}, key=lambda c: -sum(table[r][c][2] for r in table if c in table[r]))
     print("== by class (all regions)")
@@ -409,13 +422,13 @@ def main():
     print("%-34s %7d %9.1f %9.1f %6.1f%%" % ("TOTAL", n_valu, tot_dyn, tot_cyc, 100.0))
     print()
     print("== by region")
-    print("%-46s %7s %7s %9s %9s %7s %6s  %s" % ("region", "w/iter", "static", "dyn/iter", "cyc/iter", "share", "lanes", "cycles by class"))
+    print("%-46s %7s %7s %9s %9s %7s %9s %6s  %s" % ("region", "w/iter", "static", "dyn/iter", "cyc/iter", "share", "pair-cyc", "lanes", "cycles by class"))
     regions = sorted(table, key=lambda r: -sum(v[2] for v in table[r].values()))
     rows = []
     for r in regions:
         s = sum(v[0] for v in table[r].values()); d = sum(v[1] for v in table[r].values()); y = sum(v[2] for v in table[r].values())
         top = sorted(table[r].items(), key=lambda kv: -kv[1][2])[:4]
-        print("%-46s %7.3f %7d %9.1f %9.1f %6.1f%% %6.1f  %s" % (r, W[key_of[r]], s, d, y, 100 * y / tot_cyc, OCC[key_of[r]], ", ".join("%s %.0f" % (k, v[2]) for k, v in top)))
+        print("%-46s %7.3f %7d %9.1f %9.1f %6.1f%% %9.1f %6.1f  %s" % (r, W[key_of[r]], s, d, y, 100 * y / tot_cyc, pair_cycles(pair[r]), OCC[key_of[r]], ", ".join("%s %.0f" % (k, v[2]) for k, v in top)))
         for c, v in table[r].items():
             rows.append((r, c, W[key_of[r]], v[0], v[1], v[2], 100 * v[2] / tot_cyc, OCC[key_of[r]]))
     print()
