@@ -747,6 +747,17 @@ def test_pass1_compiled_in_the_background_and_kept_on_disk(tmp_path):
         # no cache directory at all: the code lives in the process only
         nocache = run(SSX_CACHE_DIR="")
         assert nocache["state"] == _capi.SSX_JIT_STATE_GENERIC_MEANWHILE and not list(cache.glob("pass1-*"))
+        # a cache directory that group or others can write to is not trusted with code that runs on the GPU: neither read nor written
+        # (ADVICE r04); the same directory closed to them (0700) is used
+        shared = tmp_path / "shared"
+        shared.mkdir()
+        (shared / files[0].name).write_bytes(data)
+        os.chmod(shared, 0o777)
+        loose = run(SSX_CACHE_DIR=str(shared))
+        assert loose["state"] == _capi.SSX_JIT_STATE_GENERIC_MEANWHILE and loose["disk_hits"] == 0 and loose["same"], loose
+        os.chmod(shared, 0o700)
+        tight = run(SSX_CACHE_DIR=str(shared))
+        assert tight["state"] == _capi.SSX_JIT_STATE_SPECIALISED and tight["disk_hits"] == 1 and tight["compiled"] == 0 and tight["same"], tight
     finally:
         if old is None:
             os.environ.pop("SSX_CACHE_DIR", None)
