@@ -16,38 +16,40 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("launcher", ["self-spawn", "torch.distributed.run"])
-def test_bench_two_ranks_json_line_and_image(tmp_path, launcher):
+@pytest.mark.parametrize("launcher,world", [("self-spawn", 2), ("torch.distributed.run", 2), ("self-spawn", 8)])
+def test_bench_two_ranks_json_line_and_image(tmp_path, launcher, world):
+    """(world 8: the driver's largest run in miniature -- eight ranks, tile rows rotated, every rank's record in the line)"""
     dump = str(tmp_path / "img.npy")
     env = dict(os.environ, SSX_BENCH_TEST_ONE_GPU="1", SSX_BENCH_DUMP=dump)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--res", "64", "--spp", "4", "--texture", "test-img.png", "--no-cpu-baseline"]
+    args = ["--gpus", str(world), "--steps", "2", "--warmup", "1", "--res", "64", "--spp", "4", "--texture", "test-img.png", "--no-cpu-baseline"]
     if launcher == "self-spawn":
         cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
     else:
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29653",
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", "29653",
                os.path.join(ROOT, "bench.py")] + args
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["unit"] == "Msamples/s" and line["value"] > 0
+    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["unit"] == "Msamples/s" and line["value"] > 0
     assert line["steps"] == 2 and line["warmup"] == 1 and "roofline" in line and "cpu_baseline" not in line
-    assert line["config"]["workload"].startswith("cornell-srgb 64x64 spp=4/GPU (total spp 8)")
+    assert line["config"]["workload"].startswith("cornell-srgb 64x64 spp=4/GPU (total spp %d)" % (4 * world))
     # the line ties its value to a checked image and says who took part (VERDICT r04 items 2 and 4)
-    assert line["check"]["differing_floats"] == 0 and line["check"]["tiles"] >= 4 and line["check"]["spp"] == 8
-    assert [x["rank"] for x in line["ranks"]] == [0, 1] and all(x["ms_per_step"] > 0 and x["path_ms"] > 0 and x["tiles_owned"] == 32 for x in line["ranks"])
-    assert len({x["pid"] for x in line["ranks"]}) == 2 and all(0.0 <= x["units_parked_frac"] <= 1.0 for x in line["ranks"])
+    assert line["check"]["differing_floats"] == 0 and line["check"]["tiles"] >= 4 and line["check"]["spp"] == 4 * world
+    assert [x["rank"] for x in line["ranks"]] == list(range(world)) and all(x["ms_per_step"] > 0 and x["path_ms"] > 0 and x["tiles_owned"] == 64 // world for x in line["ranks"])
+    assert len({x["pid"] for x in line["ranks"]}) == world and all(0.0 <= x["units_parked_frac"] <= 1.0 for x in line["ranks"])
     d = line["distributed"]
-    assert d["backend"] == "gloo" and d["world_size"] == 2 and d["overlap"]["pixels_nonzero_on_more_than_one_rank"] == 0 and d["overlap"]["pixels_nonzero_on_some_rank"] > 0
+    assert d["evidence_error"] is None
+    assert d["backend"] == "gloo" and d["world_size"] == world and d["overlap"]["pixels_nonzero_on_more_than_one_rank"] == 0 and d["overlap"]["pixels_nonzero_on_some_rank"] > 0
     assert d["devices_distinct"] is False            # both ranks on device 0 here (SSX_BENCH_TEST_ONE_GPU): the driver's 8-GPU run must say True, or bench.py refuses
     e = line["efficiency_vs_n1_reference"]
-    assert e["n1_value"] > 0 and abs(e["value"] - line["value"] / (2 * e["n1_value"])) < 1e-3 and "BENCH_r" in e["n1_source"]
+    assert e["n1_value"] > 0 and abs(e["value"] - line["value"] / (world * e["n1_value"])) < 1e-3 and "BENCH_r" in e["n1_source"]
     assert "REPLAYED" in (line["roofline"]["traffic_source"] or "REPLAYED") or line["roofline"]["traffic"] is None
     img = np.load(dump)
-    ref = ol.Oracle("cornell-srgb", texture="test-img.png").render(64, 64, 8)   # total spp = 4 per GPU x 2
+    ref = ol.Oracle("cornell-srgb", texture="test-img.png").render(64, 64, 4 * world)   # total spp = 4 per GPU x world
     assert np.array_equal(img.view(np.uint32), ref.view(np.uint32))
 
 

@@ -209,6 +209,31 @@ __global__ void __launch_bounds__(256) k_p_mul_fma64(float* out, float seed) {
 // a VALU stream next to SALU work of the same wave (s_and / s_or on masks, as the path loop's control code)
 KERNEL(k_p_mul_salu, F8, asm volatile("v_mul_f32 %0, %0, %1\n\ts_and_b64 s[20:21], s[20:21], s[22:23]" : "+v"(a0) : "v"(b) : "s20", "s21"); asm volatile("v_mul_f32 %0, %0, %1\n\ts_or_b64 s[22:23], s[20:21], s[22:23]" : "+v"(a1) : "v"(b) : "s22", "s23"); asm volatile("v_mul_f32 %0, %0, %1\n\ts_and_b64 s[20:21], s[20:21], s[22:23]" : "+v"(a2) : "v"(b) : "s20", "s21"); asm volatile("v_mul_f32 %0, %0, %1\n\ts_or_b64 s[22:23], s[20:21], s[22:23]" : "+v"(a3) : "v"(b) : "s22", "s23"); asm volatile("v_mul_f32 %0, %0, %1\n\ts_and_b64 s[20:21], s[20:21], s[22:23]" : "+v"(a4) : "v"(b) : "s20", "s21"); asm volatile("v_mul_f32 %0, %0, %1\n\ts_or_b64 s[22:23], s[20:21], s[22:23]" : "+v"(a5) : "v"(b) : "s22", "s23"); asm volatile("v_mul_f32 %0, %0, %1\n\ts_and_b64 s[20:21], s[20:21], s[22:23]" : "+v"(a6) : "v"(b) : "s20", "s21"); asm volatile("v_mul_f32 %0, %0, %1\n\ts_or_b64 s[22:23], s[20:21], s[22:23]" : "+v"(a7) : "v"(b) : "s22", "s23");, SINKF)
 
+
+// round 5: a vector-memory instruction per 64 v_mul_f32; random = every lane its own 64-byte line of a 4 MB (L2-resident) array,
+// coalesced = 64 consecutive 16-byte records.  A load is waited for at the end of its group, so with four waves per SIMD the load rows show
+// the L2 round trip (~490 cycles over the 154 of the group), not an issue cost; the store rows show the device-wide rate at which the L2
+// takes 16-byte partial-line writes from all 4096 waves at once (every 64-lane random store ~1600 cycles): bounds, not prices of the path
+// loop's ~19 memory instructions per iteration, which are spread over ~9600 cycles.
+#define MUL7 asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a0) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a1) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a2) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a3) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a4) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a5) : "v"(b)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a6) : "v"(b));
+#define MEMK(name, IDX, OP)                                                                              \
+__global__ void __launch_bounds__(256) name(float* out, float seed) {                                    \
+	F8; float4* arr = reinterpret_cast<float4*>(out + 4096);                                             \
+	unsigned idx = IDX; float4 acc = make_float4(0, 0, 0, 0);                                            \
+	for (int it = 0; it < N_ITER; ++it) {                                                                \
+		REP8(MUL7 asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a7) : "v"(b));)                             \
+		OP                                                                                               \
+		idx = (idx * 1664525u + 1013904223u) & 0x3FFFFu;                                                 \
+	}                                                                                                    \
+	if (acc.x + acc.y == 12345.678f) out[threadIdx.x] = acc.x;                                           \
+	SINKF;                                                                                               \
+}
+MEMK(k_mem_none, threadIdx.x, ;)
+MEMK(k_mem_ld_random, (threadIdx.x * 2654435761u + blockIdx.x * 97u) & 0x3FFFFu, { const float4 v = arr[(idx & ~3u)]; acc.x += v.x; acc.y += v.w; })
+MEMK(k_mem_ld_coalesced, threadIdx.x, { const float4 v = arr[(idx & 0x3FF00u) + threadIdx.x]; acc.x += v.x; acc.y += v.w; })
+MEMK(k_mem_st_random, (threadIdx.x * 2654435761u + blockIdx.x * 97u) & 0x3FFFFu, { arr[(idx & ~3u)] = make_float4(a0, a1, a2, a3); })
+MEMK(k_mem_st_coalesced, threadIdx.x, { arr[(idx & 0x3FF00u) + threadIdx.x] = make_float4(a0, a1, a2, a3); })
+
 // LDS read rates with a per-lane address pattern like the permuted-vertex table
 __global__ void __launch_bounds__(256) k_ds_read_b128(float* out, float seed) {
 	__shared__ float4 buf[1024];
@@ -260,8 +285,10 @@ int main() {
 		{"pair v_mul_f32 | v_cmp_lt_f32_e64", k_p_mul_cmp}, {"pair v_mul_f32 | v_min3_f32", k_p_mul_min3}, {"pair v_mul_f32 | v_alignbit", k_p_mul_alignbit}, {"pair v_mul_f32 | v_cvt_i32_f32", k_p_mul_cvt},
 		{"pair v_mul_f32 | v_fma_f32 (3 vgpr)", k_p_mul_fma}, {"pair v_mul_f32 | v_add_f32", k_p_mul_add}, {"pair v_mul_f32 | v_rcp_f32", k_p_mul_rcp}, {"pair v_lshl_add_u32 | v_bfe_u32", k_p_lshladd_bfe},
 		{"pair v_med3_f32 | v_min3_f32", k_p_med3_min3}, {"pair v_mul_f32 | v_fma_f64", k_p_mul_fma64}, {"pair v_mul_f32 | s_and/s_or_b64", k_p_mul_salu},
+		{"64 v_mul_f32, no memory op (per instr)", k_mem_none}, {"64 v_mul_f32 + 1 random 16-byte load, waited for (per instr)", k_mem_ld_random}, {"64 v_mul_f32 + 1 coalesced 16-byte load, waited for (per instr)", k_mem_ld_coalesced},
+		{"64 v_mul_f32 + 1 random 16-byte store (per instr)", k_mem_st_random}, {"64 v_mul_f32 + 1 coalesced 16-byte store (per instr)", k_mem_st_coalesced},
 	};
-	float* d; hipMalloc(&d, 4096);
+	float* d; hipMalloc(&d, 4096 * 4 + (4u << 20) + 4096);   // (+ the 4 MB array of the memory kernels)
 	hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
 	double clk = prop.clockRate * 1e3; // Hz
 	int cus = prop.multiProcessorCount;
