@@ -18,6 +18,11 @@ total = int(2 * fetch_kib * 1024 + write_kib * 1024)
 path = os.path.join(ROOT, "profiles", "traffic.json")
 t = json.load(open(path)) if os.path.exists(path) else {}
 t[sys.argv[3]] = total
-t[sys.argv[3] + " detail"] = {"FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib, "fetch_correction": 2.0}
+sys.path.insert(0, ROOT)
+import bench  # kernel_source_id(): the hash of the kernel sources these counters belong to (bench.py marks a replayed figure stale when they change)
+gen_f, gen_w = mean_counter(sys.argv[1], "FETCH_SIZE", "ssx_generate_kernel"), mean_counter(sys.argv[2], "WRITE_SIZE", "ssx_generate_kernel")
+t[sys.argv[3] + " detail"] = {"FETCH_SIZE_KiB": {"path": fetch_kib, "generate": gen_f}, "WRITE_SIZE_KiB": {"path": write_kib, "generate": gen_w}, "fetch_correction": 2.0,
+                              "bytes_per_launch": {"path": total, "generate": int(2 * gen_f * 1024 + gen_w * 1024)}, "kernel_source_id": bench.kernel_source_id(),
+                              "taken_by": "tools/profile_round.sh + tools/collect_traffic.py (rocprofv3 --pmc, separate passes)"}
 json.dump(t, open(path, "w"), indent=1, sort_keys=True)
 print(sys.argv[3], "->", total, "bytes per launch")
