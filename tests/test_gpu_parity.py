@@ -727,7 +727,7 @@ def test_pass1_compiled_in_the_background_and_kept_on_disk(tmp_path):
         run = lambda **env: json.loads(subprocess.run([sys.executable, "-c", child], env=dict(os.environ, **env), capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
         second = run()
         assert second["state"] == _capi.SSX_JIT_STATE_SPECIALISED and second["compiled"] == 0 and second["disk_hits"] == 1 and second["same"] and second["kernel"] == "ssx_render_kernel_jit", second
-        assert second["upload_s"] < upload + 0.25, (second, upload)         # (both uploads include the calibration render; tools/jit_rate.py has the numbers)
+        assert second["upload_s"] < upload + 1.0, (second, upload)          # (both uploads include the calibration render; "compiled == 0" above is the statement, this only says the upload did not sit through a compilation: ~1.5 s; tools/jit_rate.py has the numbers)
         # a damaged file is not trusted
         data = files[0].read_bytes()
         files[0].write_bytes(data[:len(data) // 2])
