@@ -177,7 +177,8 @@ typedef struct ssx_render_params {
 	                             ty * tile_skew columns; 0 = the plain list.  With N devices and a tile row of a multiple of N tiles the plain list
 	                             gives every device vertical stripes of the image, whose cost differs (Cornell box at N = 8: the outer stripes are
 	                             7 % cheaper than the inner ones); tile_skew = 1 gives diagonals.  All devices of a render use the same value;
-	                             the image does not depend on it. */
+	                             the image does not depend on it.  Any value is accepted and taken modulo the number of tile columns (the
+	                             rotation (ty * tile_skew) % tiles_x is what enters: kernels, C++ host and Python mask agree for every value). */
 	uint64_t seed;            /* seeding contract below */
 } ssx_render_params;
 

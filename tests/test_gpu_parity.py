@@ -87,7 +87,7 @@ def test_launch_chunking_and_tile_partition_do_not_change_the_image():
         assert np.array_equal(bits(got), bits(base)), chunk
     # tile_skew: the shared-out list with tile row ty rotated by ty * skew columns (diagonal instead of vertical stripes where the tile
     # row is a multiple of the device count: 72 / 8 = 9 tiles per row and world = 3; bench.py uses skew 1)
-    for world, skew in ((2, 0), (3, 0), (8, 0), (3, 1), (8, 1), (4, 5)):
+    for world, skew in ((2, 0), (3, 0), (8, 0), (3, 1), (8, 1), (4, 5), (3, 2 ** 31 + 5)):   # (the last: a skew whose 32-bit product with the tile row would wrap -- it is taken modulo the tile columns)
         parts = []
         for rank in range(world):
             got, _ = gpu_render(scene_name="cornell-srgb", res=(72, 40), spp=12, seed=21, texture="test-img.png",
