@@ -80,7 +80,7 @@ struct SsxBlobHeader {
 	// Topology-specialised kernels (csrc/ssx_pass1_gen.h): topology = 0 (none) or the id of the built-in mesh topology the
 	// scene's corners coincide like; off_vtab: for each of the 3 axis permutations vtab_stride words: {v[kx], v[ky]} of the
 	// n_verts distinct vertices, then their v[kz] (pass 1 reads it with compile-time offsets); off_vid: per quad 4 x u8
-	// distinct-vertex ids of v00, v10, v11, v01.  Pass 2 fetches the three vertices of ONE candidate triangle per trip, by run-time
+	// distinct-vertex ids of v00, v10, v11, v01 (what the offset records below are made from; the kernels no longer read it).  Pass 2 fetches the three vertices of ONE candidate triangle per trip, by run-time
 	// index: for that the same vertices once more as 16-byte records {v[kx], v[ky], v[kz], 0} per permutation (off_vtab4, stride
 	// 4 * n_verts words) and per triangle t = 2 * quad + which the byte offsets of its A, B, C records within a permutation's
 	// table, off_triofs + 2 t: { A | B << 16, C } -- one 8-byte and three 12-byte LDS reads behind 6 integer instructions where the

@@ -134,7 +134,6 @@ struct Lds {
 	__device__ __forceinline__ const float* vtab(uint32_t p) const {
 		return reinterpret_cast<const float*>(w + hdr().off_vtab) + p * hdr().vtab_stride;
 	}
-	__device__ __forceinline__ uint32_t vid(uint32_t q) const { return w[hdr().off_vid + q]; } // 4 x u8: distinct-vertex ids of v00, v10, v11, v01
 	// pass 2 of the topology-specialised kernels: the distinct vertices as 16-byte records {x, y, z, 0} of axis permutation p (byte
 	// address), and per triangle the byte offsets of its three records within such a table { A | B << 16, C }
 	__device__ __forceinline__ const char* vtab4(uint32_t p) const { return reinterpret_cast<const char*>(w + hdr().off_vtab4) + p * (16u * hdr().n_verts); }
