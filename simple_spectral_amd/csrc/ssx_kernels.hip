@@ -602,7 +602,7 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 		const uint32_t ign = (uint32_t)ignore_quad - base; // (a negative ignore_quad, or one of another group, falls outside 0..31)
 		if (ign < 32u) cand &= ~(3ull << (2u * ign));
 		if (!has_ray) cand = 0ull;
-		if (tm) SSX_TIME(*tm, stat_base == 0 ? 7 : 12); // (profiling build: ray set-up + pass 1 end here)
+		if (tm) SSX_TIME_AFTER(*tm, stat_base == 0 ? 7 : 12, (uint32_t)cand ^ (uint32_t)(cand >> 32)); // (profiling build: ray set-up + pass 1 end here, behind the candidate mask)
 		while (cand) {
 			SSX_STAT(stat_base + 1); // pass-2 trips x lanes with a candidate
 			uint32_t bit = (uint32_t)__builtin_ctzll(cand);
@@ -660,7 +660,7 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 				if (which == 0u) cand &= ~(1ull << (bit + 1u)); // PrimQuad::intersect: tri0 hit -> tri1 not tested
 			}
 		}
-		if (tm) SSX_TIME(*tm, stat_base == 0 ? 8 : 13); // (profiling build: pass 2)
+		if (tm) SSX_TIME_AFTER(*tm, stat_base == 0 ? 8 : 13, hit.dist); // (profiling build: pass 2)
 	}
 }
 

@@ -24,9 +24,14 @@ __device__ unsigned long long g_lanestat[2 * SSX_NSTAT];
 __device__ unsigned long long g_regtime[SSX_NTIME];
 struct SsxTimer { unsigned long long last; unsigned long long* acc; };
 #define SSX_TIME(tm, r) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63u) == 0u) atomicAdd((tm).acc + (r), t_ - (tm).last); (tm).last = t_; } while (0)
+// the same, with the clock read pinned BEHIND the computation of `dep` (a VGPR value the region produces): the scheduler otherwise moves
+// a clock read over pure arithmetic (pass 1 of the intersection is nothing else)
+#define SSX_TIME_AFTER(tm, r, dep) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory"); \
+	if ((threadIdx.x & 63u) == 0u) atomicAdd((tm).acc + (r), t_ - (tm).last); (tm).last = t_; } while (0)
 #else
 struct SsxTimer {};
 #define SSX_TIME(tm, r) do { (void)(tm); } while (0)
+#define SSX_TIME_AFTER(tm, r, dep) do { (void)(tm); } while (0)
 #endif
 
 
