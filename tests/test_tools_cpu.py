@@ -35,3 +35,51 @@ def test_isa_census_prices_the_path_kernel_and_agrees_with_the_counters():
     assert 0.7 * single < pair < single                   # the pair-aware price is below the sum of the single prices, and not by an order of magnitude
     for region in ("trace primary: pass 1", "trace primary: pass 2 trip", "light: sphtri_make acos/sin (binary64)", "fold: level step (2 ways)", "loop: refill"):
         assert region in out.stdout, region
+
+
+def test_bench_helpers_replay_stamp_and_n1_reference(tmp_path, monkeypatch):
+    """bench.py's bookkeeping that needs no GPU: a replayed traffic figure carries the hash of the kernel sources it was taken on and is
+    marked stale when they differ from the tree's; the N = 1 reference of the efficiency field names its source."""
+    import json
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    src_id = bench.kernel_source_id()
+    assert len(src_id) == 16 and src_id == bench.kernel_source_id()
+    key = "cornell-srgb 512 spp256 obs1931 gpus2"
+    tj = tmp_path / "traffic.json"
+    args = types.SimpleNamespace(scene="cornell-srgb", res=512, spp=256, observer=1931, no_pmc=False)
+    monkeypatch.setenv("SSX_BENCH_TRAFFIC_JSON", str(tj))
+    # nothing recorded for this key: no figure, but still a stamp saying why nothing was measured
+    tj.write_text(json.dumps({}))
+    traffic, detail, source = bench.measured_traffic(args, 2)
+    assert traffic is None and "REPLAYED" in source and detail["replayed"]["why_not_measured"].startswith("N > 1")
+    # recorded on these sources: not stale; recorded on others: stale
+    tj.write_text(json.dumps({key: 123, key + " detail": {"kernel_source_id": src_id}}))
+    traffic, detail, source = bench.measured_traffic(args, 2)
+    assert traffic == 123 and detail["replayed"]["stale"] is False and detail["replayed"]["this_build_kernel_source_id"] == src_id
+    tj.write_text(json.dumps({key: 123, key + " detail": {"kernel_source_id": "0" * 16}}))
+    assert bench.measured_traffic(args, 2)[1]["replayed"]["stale"] is True
+    tj.write_text(json.dumps({key: 123, key + " detail": {}}))
+    assert "unknown" in str(bench.measured_traffic(args, 2)[1]["replayed"]["stale"])
+    n1 = bench.n1_reference()
+    assert n1["value"] > 1000 and "BENCH_r" in n1["source"]
+    # the design's byte model the line quotes next to the counters (DESIGN.md section 3)
+    assert 440 < bench.design_bytes_per_sample("cornell-srgb", levels=4.07) < 500      # 470.8: the counters read 1.23 x the path kernel's share of it
+    assert abs(bench.algorithmic_bytes_per_sample_8d("cornell-srgb", 256) - (16.0 / 256 + 3.8)) < 1e-9
+
+
+def test_runtime_preload_reads_sonames_from_the_elf_files():
+    """simple_spectral_amd/_capi.py maps torch's bundled HIP runtime ahead of libssx_hip.so only when its SONAME is the one the library
+    needs: the ELF dynamic sections it reads that from."""
+    sys.path.insert(0, ROOT)
+    from simple_spectral_amd import _capi, build
+    if not os.path.exists(build.HIP_LIB):
+        import pytest
+        pytest.skip("library not built")
+    soname, needed = _capi._elf_dynamic(build.HIP_LIB)
+    assert any(n.startswith("libamdhip64.so") for n in needed) and "libstdc++.so.6" in needed
+    soname, needed = _capi._elf_dynamic(build.HOST_LIB)
+    assert "libz.so.1" in needed or any(n.startswith("libz") for n in needed)
+    assert _capi._elf_dynamic(__file__) == (None, [])          # not an ELF file
+    assert _capi._elf_dynamic("/nonexistent") == (None, [])
