@@ -593,7 +593,7 @@ def main():
                          "kernel_ms": round(kernel_ms, 3), "path_kernel_ms": round(path_ms, 3),
                          "pipeline_ms": round(pipeline_ms, 3), "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
                          "flop_per_sample": flop,
-                         "note": "FP32 VALU-issue bound (no MFMA: traversal/sampling); peak = 157.3/2 TFLOP/s because the parity contract forbids FMA contraction. HBM is busy but not the limiter: see hbm.",
+                         "note": "FP32 VALU-issue bound (no MFMA: traversal/sampling); peak = 157.3/2 TFLOP/s because the parity contract forbids FMA contraction. HBM is busy but not the limiter: see hbm.  Instruction-level account of the path kernel (regions x measured trip counts x measured opcode rates; pair-aware issue time 80 % of the kernel's time): profiles/r05/isa_census.txt, profiles/r05/NOTES.md.",
                          "hbm": {  # two yardsticks for the counter traffic: SURVEY 8(d)'s all-state-on-chip megakernel, and this design's own bytes
                                  "algorithmic_bytes_per_sample_8d": round(algorithmic_bytes_per_sample_8d(args.scene, spp_total), 3),
                                  "traffic_over_algorithmic_8d": round(traffic / (per_gpu_samples * algorithmic_bytes_per_sample_8d(args.scene, spp_total)), 1) if traffic else None,
