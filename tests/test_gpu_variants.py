@@ -65,3 +65,23 @@ def test_variant_stress_and_fuzz_bit_exact(workers, variant):
         assert rep["kernel"].endswith("_nq"), rep["kernel"]
     else:
         assert rep["kernel"] == "ssx_render_kernel_cornell", rep["kernel"]
+
+
+def test_formal_build_runs_the_whole_parity_suites():
+    """The parity suites themselves (tests/test_gpu_parity.py, tests/test_gpu_units.py: every scene, mode, per-sample and per-function
+    case) on libssx_hip_formal.so, in the driver's `pytest -m gpu` -- so that a red on the build that validates the default build's
+    below-the-model hand-over cannot hide in a builder-side log.  A child pytest with the library override; its
+    failing test ids and assertion lines (-rf) are this test's failure message."""
+    lib = VARIANTS["formal"]["SSX_HIP_LIB_OVERRIDE"]
+    assert os.path.exists(lib), "libssx_hip_formal.so missing: simple_spectral_amd/build.py builds it"
+    env = dict(os.environ, SSX_DEBUG_ENV="1", SSX_HIP_LIB_OVERRIDE=lib)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(HERE, "test_gpu_parity.py"), os.path.join(HERE, "test_gpu_units.py"), "-q", "-m", "gpu", "-rf",
+                        "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1100)
+    tail = [ln for ln in p.stdout.splitlines() if ln.startswith(("FAILED", "ERROR", "E  ")) or " passed" in ln or " failed" in ln]
+    assert p.returncode == 0, "\n".join(tail[-60:]) or p.stdout[-3000:] + p.stderr[-1000:]
+    summary = [ln for ln in tail if " passed" in ln]
+    assert summary and " failed" not in summary[-1], tail
+    import re
+    assert int(re.search(r"(\d+) passed", summary[-1]).group(1)) >= 140, summary[-1]  # the suites ran, not an empty selection

@@ -6,7 +6,7 @@
 # usage: tools/profile_round.sh <tag> [calib]   then locally: python tools/summarize_profile.py <tag> ...
 TAG=${1:-final}
 R=$(pwd)
-B="python $R/bench.py --steps 4 --warmup 1 --quick"
+B="python $R/bench.py --steps 4 --warmup 1 --quick $BENCH_ARGS" # BENCH_ARGS="--scene plane-srgb --res 1024 --spp 1024": another workload
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- $B > $O/${TAG}_stats.log 2>&1
