@@ -20,7 +20,15 @@ typedef struct {
 	unsigned interactions;
 } path_ctx;
 
-/* renderer.cpp:147-255: the recursive radiance lambda `L`. */
+/* renderer.cpp:147-255: the recursive radiance lambda `L`.  (-DORACLE_REFERENCE_SHAPED, oracle_scene.c: the lambda lives in a
+ * std::function and calls itself through it -- an indirect call per level that the compiler cannot see through.) */
+#ifdef ORACLE_REFERENCE_SHAPED
+static orc_hero radiance_L(path_ctx* c, const orc_ray* ray, int last_was_delta, unsigned depth, int ignore) __attribute__((noinline));
+static orc_hero (*volatile const std_function_L)(path_ctx*, const orc_ray*, int, unsigned, int) = radiance_L;
+#define ORC_CALL_L std_function_L
+#else
+#define ORC_CALL_L radiance_L
+#endif
 static orc_hero radiance_L(path_ctx* c, const orc_ray* ray, int last_was_delta, unsigned depth, int ignore) {
 	orc_hero radiance = { { 0, 0, 0, 0 } };
 	const float pi = 3.14159265358979323846f;
@@ -95,7 +103,7 @@ static orc_hero radiance_L(path_ctx* c, const orc_ray* ray, int last_was_delta, 
 				}
 				if (n_dot_l > 0.0f) {
 					orc_ray ray_next = { hit_pos, w_i };
-					orc_hero Lr = radiance_L(c, &ray_next, 0, depth + 1u, hitrec.prim);
+					orc_hero Lr = ORC_CALL_L(c, &ray_next, 0, depth + 1u, hitrec.prim);
 					for (int i = 0; i < 4; ++i) radiance.v[i] += ((Lr.v[i] * n_dot_l) * f_s[i]) / pdf_w_i;
 				}
 			}
@@ -138,7 +146,7 @@ void orc_render_sample(const orc_color* cd, const orc_scene* sc, orc_rng* rng, s
 	/* `indirect_only` carries two flags: bit 0 = Options::indirect_only, bit 1 = build without ELS */
 	path_ctx c = { cd, sc, rng, lambda_0, indirect_only & 1, !(indirect_only & 2), 0, st, 0 };
 	orc_ray ray_camera = { sc->camera.pos, camera_ray_dir };
-	orc_hero rad = radiance_L(&c, &ray_camera, 1, 0u, -1);
+	orc_hero rad = ORC_CALL_L(&c, &ray_camera, 1, 0u, -1);
 
 	/* FLAT_FIELD_CORRECTION: flux = radiance (:262-263); without it (:264-265) flux = radiance * glm::dot(camera_ray_dir, camera.dir) */
 	if (indirect_only & 4) {

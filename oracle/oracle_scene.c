@@ -9,10 +9,24 @@
 
 /* ----------------------------------------------------------------- geometry ---- */
 
+/* -DORACLE_REFERENCE_SHAPED (libssx_oracle_refshape.so, bench.py's cpu_baseline.reference_equivalent): the same arithmetic -- the same
+ * bits, tests/test_oracle_pins.py compares -- with the CALL STRUCTURE of the reference binary instead of what gcc makes of this
+ * restatement when it may inline everything: Scene::intersect calls PrimBase::intersect VIRTUALLY per primitive (scene.cpp:437-441), so
+ * the per-ray shear constants of geometry.cpp:17-37 (three divisions) are recomputed per triangle and nothing is hoisted out of the
+ * primitive loop; glm::vec3::operator[] with a run-time index (geometry.cpp:26-37,45-47) reads an array in memory; the materials'
+ * evaluate_bsdf / interact_bsdf / emission are virtual (material.hpp:60-110); the recursion goes through a std::function (renderer.cpp:148).
+ * Here: out-of-line functions called through volatile function pointers, and an indexed temporary. */
+#ifdef ORACLE_REFERENCE_SHAPED
+#define ORC_VIRTUAL __attribute__((noinline))
+static inline float v3_get_(const orc_v3* v, size_t k) { return (&v->x)[k]; } /* glm: `return (&x)[i]` */
+#define v3_get(v, k) v3_get_(&(v), (k))
+#else
+#define ORC_VIRTUAL
 static inline float v3_get(orc_v3 v, size_t k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+#endif
 
 /* geometry.cpp:12-101 (Woop/Benthin/Wald watertight test) */
-int orc_tri_intersect(const orc_tri* tri, const orc_ray* ray, orc_hit* hitrec, int prim_id, orc_stats* st) {
+ORC_VIRTUAL int orc_tri_intersect(const orc_tri* tri, const orc_ray* ray, orc_hit* hitrec, int prim_id, orc_stats* st) {
 	if (st) st->tri_tests++;
 	orc_v3 d = ray->dir;
 	orc_v3 abs_dir = v3_make(fabsf(d.x), fabsf(d.y), fabsf(d.z));
@@ -82,7 +96,7 @@ int orc_tri_intersect(const orc_tri* tri, const orc_ray* ray, orc_hit* hitrec, i
 }
 
 /* geometry.cpp:128-139; a PrimTri primitive (geometry.cpp:12-101) is its one triangle */
-static int quad_intersect(const orc_quad* q, int prim_id, const orc_ray* ray, orc_hit* hitrec, orc_stats* st) {
+ORC_VIRTUAL static int quad_intersect(const orc_quad* q, int prim_id, const orc_ray* ray, orc_hit* hitrec, orc_stats* st) {
 	if (q->is_tri) return orc_tri_intersect(&q->tri0, ray, hitrec, prim_id, st);
 	if (orc_tri_intersect(&q->tri0, ray, hitrec, prim_id, st)) goto HIT;
 	if (orc_tri_intersect(&q->tri1, ray, hitrec, prim_id, st)) goto HIT;
@@ -98,9 +112,16 @@ int orc_scene_intersect(const orc_scene* sc, const orc_ray* ray, orc_hit* hitrec
 	hitrec->prim = -1;
 	hitrec->dist = INFINITY;
 	int hit = 0;
+#ifdef ORACLE_REFERENCE_SHAPED
+	static int (*volatile const vtable_intersect)(const orc_quad*, int, const orc_ray*, orc_hit*, orc_stats*) = quad_intersect; /* prim->intersect(ray, hitrec): virtual */
+	for (int p = 0; p < sc->n_prims; ++p) {
+		if (p != ignore) hit |= vtable_intersect(&sc->prims[p], p, ray, hitrec, st);
+	}
+#else
 	for (int p = 0; p < sc->n_prims; ++p) {
 		if (p != ignore) hit |= quad_intersect(&sc->prims[p], p, ray, hitrec, st);
 	}
+#endif
 	return hit;
 }
 
@@ -150,7 +171,7 @@ void orc_texture_sample(const orc_color* cd, const orc_texture* tex, orc_v2 st, 
 }
 
 /* albedo lookup shared by evaluate_bsdf / interact_bsdf (material.cpp:120-143,146-167) */
-void orc_material_albedo(const orc_color* cd, const orc_scene* sc, const orc_material* m, orc_v2 st, float lambda_0, float out[4], orc_stats* stt) {
+ORC_VIRTUAL void orc_material_albedo(const orc_color* cd, const orc_scene* sc, const orc_material* m, orc_v2 st, float lambda_0, float out[4], orc_stats* stt) {
 	(void)sc;
 	if (m->albedo_mode == ORC_ALBEDO_CONSTANT) {
 		if (cd->rgb_mode) { out[0] = m->rgb_albedo[0]; out[1] = m->rgb_albedo[1]; out[2] = m->rgb_albedo[2]; out[3] = 0.0f; return; } /* material.cpp:125,138 */
@@ -167,7 +188,7 @@ static int material_is_emissive(int rgb_mode, const orc_material* m) {
 	return orc_spectrum_integrate(&m->emission) > 0.0f;
 }
 /* material.hpp:101-103 emission[lambda_0], or the lRGB triple in RGB mode */
-void orc_material_emission(const orc_color* cd, const orc_material* m, float lambda_0, float out[4]) {
+ORC_VIRTUAL void orc_material_emission(const orc_color* cd, const orc_material* m, float lambda_0, float out[4]) {
 	if (cd->rgb_mode) { out[0] = m->rgb_emission[0]; out[1] = m->rgb_emission[1]; out[2] = m->rgb_emission[2]; out[3] = 0.0f; return; }
 	orc_spectrum_hero(&m->emission, lambda_0, cd->lambda_step, out);
 }

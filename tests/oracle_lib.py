@@ -102,7 +102,7 @@ _libs = {}
 
 
 def load(variant=""):
-    """variant '' = build-defined transcendentals (the parity oracle); 'libm' = glibc variant."""
+    """variant '' = build-defined transcendentals (the parity oracle); 'libm' = glibc variant; 'refshape' = the oracle's arithmetic in the reference binary's call structure (bench.py: cpu_baseline.reference_equivalent)."""
     if variant in _libs:
         return _libs[variant]
     build()
