@@ -216,18 +216,36 @@ def oracle_check(img, scene, W, H, spp_total, observer, texture, n_tiles=6):
             "against": "oracle/libssx_oracle.so (CPU restatement), uint32 compare of float4 XYZA", "mean_alpha": round(alpha, 5), "seconds": round(time.time() - t, 2)}
 
 
-def n1_reference():
-    """The N = 1 figure the efficiency field is quoted against: the driver's own last N = 1 record in the tree (BENCH_rNN.json), else round 4's."""
-    best = {"value": 3149.36, "source": "BENCH_r04.json (driver's N=1 run, round 4)"}
-    try:
-        import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json"))):
-            d = json.load(open(f)).get("parsed") or {}
-            if d.get("n_gpus") == 1 and d.get("value"):
-                best = {"value": float(d["value"]), "source": "%s (driver's N=1 run)" % os.path.basename(f)}
-    except Exception:
-        pass
-    return best
+def n1_reference(src_id=None):
+    """The N = 1 figure the efficiency field is quoted against -- only one taken on THIS build's kernel sources counts (VERDICT r05 item 5:
+    a figure of another round's kernel must be refused, not divided by): the driver's N = 1 records in the tree (BENCH_rNN.json, whose
+    `config` carries kernel_source_id since round 6) and the builder's own closing lines (profiles/rNN/bench.json), newest match first;
+    or SSX_BENCH_N1_VALUE=<Msamples/s>, named as what it is.  No match: value None and the reason."""
+    import glob
+    src_id = src_id or kernel_source_id()
+    env = os.environ.get("SSX_BENCH_N1_VALUE")
+    if env:
+        try:
+            return {"value": float(env), "source": "SSX_BENCH_N1_VALUE (given by the caller: not checked against the kernel sources)", "kernel_source_id": None}
+        except ValueError:
+            pass
+    seen = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json"))) + sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "bench.json"))):
+        try:
+            d = json.load(open(f))
+            d = d.get("parsed") or d
+            if d.get("n_gpus") == 1 and d.get("value") and "cornell-srgb 512x512 spp=256/GPU" in str((d.get("config") or {}).get("workload", "")):
+                seen.append((os.path.relpath(f, ROOT), float(d["value"]), (d.get("config") or {}).get("kernel_source_id")))
+        except Exception:
+            pass
+    match = [x for x in seen if x[2] == src_id]
+    if match:
+        f, v, _ = match[-1]
+        return {"value": v, "source": "%s (N = 1 run on these kernel sources)" % f, "kernel_source_id": src_id}
+    newest = seen[-1] if seen else None
+    return {"value": None, "source": None, "kernel_source_id": src_id,
+            "refused": "no N = 1 figure taken on this build's kernel sources (id %s) in the tree%s" % (
+                src_id, "; newest other: %s = %.2f Msamples/s on %s" % (newest[0], newest[1], newest[2] or "sources without an id (before round 6)") if newest else "")}
 
 
 def sha256_of(*paths):
@@ -242,9 +260,18 @@ def sha256_of(*paths):
 
 
 def kernel_source_id():
-    """Identifies the device code the traffic belongs to: hash of the kernel sources (not of the .so, whose bytes differ per build host)."""
-    c = os.path.join(ROOT, "simple_spectral_amd", "csrc")
-    return sha256_of(*[os.path.join(c, f) for f in ("ssx_kernels.hip", "ssx_api.hip", "ssx_blob.h", "ssx_exact.h", "ssx_pass1_gen.h")] + [os.path.join(ROOT, "include", "ssx_fmath.h")])
+    """Identifies the device code a measurement belongs to: hash of every source the HIP library is compiled from (simple_spectral_amd/build.py
+    HIP_DEPS minus the generated file -- the .hip files, their headers incl. ssx_jit.h / ssx_lanestat.h, include/ssx.h and ssx_fmath.h), not of the
+    .so, whose bytes differ per build host."""
+    from simple_spectral_amd import build as b
+    return sha256_of(*sorted(d for d in b.HIP_DEPS if not d.endswith("ssx_sources_gen.h")))
+
+
+def newest_pmc_summary():
+    """profiles/rNN/pmc_summary.csv of the latest round that has one (what a replayed traffic figure is said to agree with)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]", "pmc_summary.csv")))
+    return found[-1] if found else None
 
 
 PMC_KERNELS = (("path", "ssx_render_kernel"), ("generate", "ssx_generate_kernel"))
@@ -303,8 +330,8 @@ def pmc_passes(args):
 
 def measured_traffic(args, world):
     """HBM bytes per launch of the path kernel (roofline.traffic) and of the generate kernel.  N = 1: measured in this run by two
-    rocprofv3 --pmc passes (pmc_passes) unless --no-pmc / SSX_BENCH_NO_PMC=1 or the passes fail; the result also refreshes
-    profiles/traffic.json.  Otherwise replayed from that file -- stamped with the hash of the kernel sources it was taken on and of
+    rocprofv3 --pmc passes (pmc_passes) unless --no-pmc / SSX_BENCH_NO_PMC=1 or the passes fail; the result goes to
+    gpurun_out/traffic_measured.json (and refreshes profiles/traffic.json only with --update-traffic).  Otherwise replayed from that file -- stamped with the hash of the kernel sources it was taken on and of
     the counter summary it agrees with, and marked stale when the sources have changed since, so that it cannot go stale silently."""
     path = os.environ.get("SSX_BENCH_TRAFFIC_JSON") or os.path.join(ROOT, "profiles", "traffic.json")   # (tests point it elsewhere)
     key = "%s %d spp%d obs%d gpus%d" % (args.scene, args.res, args.spp, args.observer, world)
@@ -313,13 +340,19 @@ def measured_traffic(args, world):
         by_kernel, detail = pmc_passes(args)
         if by_kernel:
             detail["kernel_source_id"] = src_id
-            try:
-                t = json.load(open(path)) if os.path.exists(path) else {}
-                t[key] = by_kernel["path"]
-                t[key + " detail"] = detail
-                json.dump(t, open(path, "w"), indent=1, sort_keys=True)
-            except Exception:
-                pass
+            # A run does not touch the tracked replay file (every driver run dirtied the tree, and the stored evidence followed
+            # whichever box ran last): the fresh figures go to gpurun_out/traffic_measured.json (scratch), and into profiles/traffic.json
+            # only with --update-traffic (the builder's closing run of a round).
+            targets = [os.path.join(ROOT, "gpurun_out", "traffic_measured.json")] + ([path] if args.update_traffic else [])
+            for tp in targets:
+                try:
+                    if os.path.isdir(os.path.dirname(tp)):
+                        t = json.load(open(tp)) if os.path.exists(tp) else {}
+                        t[key] = by_kernel["path"]
+                        t[key + " detail"] = detail
+                        json.dump(t, open(tp, "w"), indent=1, sort_keys=True)
+                except Exception:
+                    pass
             return by_kernel["path"], detail, "measured in this run: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over a child run of the same workload; FETCH_SIZE x 2 (gfx950 wide-read correction), KiB -> bytes; path kernel (traffic) and generate kernel (traffic_detail.bytes_per_launch)"
         why = detail
     else:
@@ -328,8 +361,9 @@ def measured_traffic(args, world):
         t = json.load(open(path))
         detail = dict(t.get(key + " detail") or {})
         taken_on = detail.get("kernel_source_id")
+        summary = newest_pmc_summary()
         detail["replayed"] = {"file": "profiles/traffic.json", "file_sha256_16": sha256_of(path), "why_not_measured": why,
-                              "agrees_with": "profiles/r04/pmc_summary.csv", "pmc_summary_sha256_16": sha256_of(os.path.join(ROOT, "profiles", "r04", "pmc_summary.csv")),
+                              "agrees_with": os.path.relpath(summary, ROOT) if summary else None, "pmc_summary_sha256_16": sha256_of(summary) if summary else None,
                               "taken_on_kernel_source_id": taken_on, "this_build_kernel_source_id": src_id,
                               "stale": (taken_on != src_id) if taken_on else "unknown (taken before round 5 stamped the sources)"}
         return t.get(key), detail, "REPLAYED from profiles/traffic.json (not measured in this run: %s); see traffic_detail.replayed for the stamp" % why
@@ -374,6 +408,100 @@ def spawn_ranks(args):
     sys.exit(rc)
 
 
+def dist_dry_run(args, r, rank, world, local_rank, use_dist, test_one_gpu, W, H, spp_total, batch, per_spp_bytes):
+    """bench.py --dist-dry-run [--gpus N]: the first real multi-GPU run should be boring.  No benchmark: every rank
+    reports its device, its free memory, the scratch its share of the workload will take, peer access to the devices it can see; the ranks
+    run the collectives the timed loop uses (an all_reduce that must equal the world size, a full-size framebuffer reduce to rank 0,
+    timed) and one render of their share at 1/16 of the samples; rank 0 runs the C++ host's combine as a probe (ssx_rccl_probe:
+    ncclCommInitAll over every visible device).  Whatever fails is written into the line, which is printed in any case."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from simple_spectral_amd import _capi
+    rep = {"rank": rank, "local_rank": local_rank, "hostname": socket.gethostname(), "visible_devices": torch.cuda.device_count()}
+    try:
+        props = torch.cuda.get_device_properties(local_rank)
+        free_b, total_b = torch.cuda.mem_get_info(local_rank)
+        rep.update({"device": props.name, "device_uuid": str(getattr(props, "uuid", "")), "free_bytes": int(free_b), "total_bytes": int(total_b),
+                    "peer_access": {str(k): bool(torch.cuda.can_device_access_peer(local_rank, k)) for k in range(torch.cuda.device_count()) if k != local_rank},
+                    "scratch_after_upload": r.scratch_info(),
+                    "sample_bytes_needed": int(per_spp_bytes * (batch or spp_total)), "spp_per_launch": batch or spp_total, "spp_total": spp_total,
+                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")})
+    except Exception as e:  # noqa: BLE001
+        rep["device_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+    try:
+        small = Renderer_share(r, args, rank, world, local_rank, W, H, max(1, spp_total // 16))
+        rep.update(small)
+    except Exception as e:  # noqa: BLE001
+        rep["render_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+    coll = {}
+    if use_dist:
+        dev = "cpu" if test_one_gpu else "cuda"
+        try:
+            one = torch.ones(1, dtype=torch.float32, device=dev)
+            dist.all_reduce(one)
+            coll["all_reduce_ones"] = float(one[0])
+            img = torch.full((H, W, 4), float(rank + 1), dtype=torch.float32, device=dev)
+            times = []
+            for _ in range(3):
+                if dev == "cuda":
+                    torch.cuda.synchronize()
+                dist.barrier()
+                t = time.perf_counter()
+                dist.reduce(img, dst=0, op=dist.ReduceOp.SUM)
+                if dev == "cuda":
+                    torch.cuda.synchronize()
+                times.append(round((time.perf_counter() - t) * 1e3, 3))
+                img.fill_(float(rank + 1))
+            coll["framebuffer_reduce_ms"] = times
+            coll["framebuffer_bytes"] = H * W * 16
+        except Exception as e:  # noqa: BLE001
+            coll["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+        gathered = [None] * world
+        try:
+            dist.all_gather_object(gathered, rep)
+        except Exception as e:  # noqa: BLE001
+            gathered = [rep]
+            coll["gather_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+    else:
+        gathered = [rep]
+    if rank == 0:
+        probe = None
+        try:
+            lib = _capi.hip_lib()
+            buf = C.create_string_buffer(16384)
+            n_ok = lib.ssx_rccl_probe(buf, len(buf))
+            probe = json.loads(buf.value.decode() or "{}")
+            probe["returned"] = n_ok
+        except Exception as e:  # noqa: BLE001
+            probe = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        devs = [(x or {}).get("device_uuid") for x in gathered]
+        print(json.dumps({"dry_run": True, "n_gpus": world, "backend": dist.get_backend() if use_dist else None, "ranks": gathered, "collectives": coll,
+                          "devices_distinct": len(set(devs)) == len(devs), "rccl_probe_single_process": probe,
+                          "expect": {"all_reduce_ones": float(world)}}), flush=True)
+    if use_dist:
+        try:
+            dist.barrier(); dist.destroy_process_group()
+        except Exception:
+            pass
+
+
+def Renderer_share(r, args, rank, world, local_rank, W, H, spp_small):
+    """one render of this rank's share at `spp_small` samples per pixel, timed: the kernels launch, the tile split is what the bench uses"""
+    import torch
+    from simple_spectral_amd import Options, Renderer
+    rs = Renderer(Options(scene_name=args.scene, res=(W, H), spp=spp_small, texture=args.texture, device=local_rank, tile_first=rank, tile_stride=world,
+                          tile_skew=1 if world > 1 else 0, seed=0, observer=args.observer, uplift=args.uplift))
+    out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    st = torch.cuda.current_stream()
+    rs.render_device(out.data_ptr(), st.cuda_stream); torch.cuda.synchronize()
+    t = time.perf_counter()
+    rs.render_device(out.data_ptr(), st.cuda_stream); torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) * 1e3
+    own = int((out[..., 3] != 0).sum())
+    return {"share_render_ms": round(ms, 3), "share_spp": spp_small, "share_pixels_nonzero": own, "share_scratch": rs.scratch_info(), "kernel": rs.plan_info().get("kernel")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -389,6 +517,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the timed image (A/B scripts; the driver's command never passes it)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure HBM traffic with rocprofv3 --pmc passes in this run (replay profiles/traffic.json, stamped)")
+    ap.add_argument("--scratch-cap-gb", type=float, default=8.0, help="per-rank cap on the library's device scratch (sample arrays + level logs): a render that would need more is split into batches of fewer samples per pixel (the default workload needs 4.4 GB and is not split)")
+    ap.add_argument("--dist-dry-run", action="store_true", help="no benchmark: go through the multi-GPU plumbing on whatever devices exist (process group, a timed framebuffer reduce, ssx_rccl_probe, per-rank scratch) and REPORT what was found in one JSON line")
+    ap.add_argument("--update-traffic", action="store_true", help="also write the measured HBM traffic into the tracked replay file profiles/traffic.json (a round's closing run)")
     ap.add_argument("--quick", action="store_true", help="= --no-cpu-baseline --no-check --no-pmc (A/B and profiling scripts)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the run under rocprofv3 --pmc: renders, prints nothing
     args = ap.parse_args()
@@ -443,9 +574,22 @@ def main():
     W = H = args.res
     spp_total = args.spp * world
     texture = args.texture
+    # what this rank's render keeps on the device: 48 B per sample of a launch (+ 5 words per 64 samples) and the persistent waves' level
+    # logs (1.2 / 2.4 GB whatever the launch renders).  Above --scratch-cap-gb the render is split into batches of fewer samples per pixel
+    # (the pixel sums continue from batch to batch: same image); the line's `ranks` carry what each rank really allocated.
+    n_tiles_all = ((W + 7) // 8) * ((H + 7) // 8)
+    tiles_mine = (n_tiles_all - rank + world - 1) // world
+    log_bytes_est = 2.5e9 if args.scene == "plane-srgb" else 1.25e9
+    per_spp_bytes = max(tiles_mine, 1) * 64 * (48 + 5 * 4 / 64.0)
+    batch = args.batch
+    fit_spp = int(max(1, (args.scratch_cap_gb * 2**30 - log_bytes_est) // per_spp_bytes))
+    if fit_spp < spp_total and (batch == 0 or batch > fit_spp):
+        batch = fit_spp
     r = Renderer(Options(scene_name=args.scene, res=(W, H), spp=spp_total, texture=texture, device=local_rank,
                          tile_first=rank, tile_stride=world, tile_skew=1 if world > 1 else 0, seed=0, observer=args.observer, uplift=args.uplift,
-                         spp_per_launch=args.batch))
+                         spp_per_launch=batch))
+    if args.dist_dry_run:
+        return dist_dry_run(args, r, rank, world, local_rank, use_dist, test_one_gpu, W, H, spp_total, batch, per_spp_bytes)
     out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream()
 
@@ -527,41 +671,50 @@ def main():
         elapsed, kernel_ms, elapsed_resident, path_ms = float(tt[0]), float(tt[1]), float(tt[2]), float(tt[3])
     # ---- who took part: one record per rank, gathered on rank 0; a run in which two ranks share a device, or in which
     # two ranks' images overlap (a pixel nonzero on both: the partition is wrong), does not print a bench line.
-    my_ms, my_path_ms = elapsed_local / args.steps * 1e3, stage_ms["path"]
+    my_ms, my_path_ms = elapsed_local / max(args.steps, 1) * 1e3, stage_ms["path"]
     n_tiles_img = ((W + 7) // 8) * ((H + 7) // 8)
     my_tiles = (n_tiles_img - rank + world - 1) // world
-    unit_spp = 4 if r.plan_info()["frames_per_sample"] >= 2.0 else 8                    # make_batch (csrc/ssx_api.hip): units of 4 samples per pixel for long paths, else 8,
-    while unit_spp > 1 and ((spp_total + unit_spp - 1) // unit_spp) * my_tiles < 3072:    # halved while a launch would leave SIMDs without a wave (kMinUnits)
-        unit_spp //= 2
-    n_units = max(1, my_tiles * ((spp_total + unit_spp - 1) // unit_spp) * args.steps)    # work units of the timed steps
     sums = {k: sums1[k] - sums0[k] for k in sums0}
+    n_units = max(1, sums.get("units", 0))                                                # work units of the timed steps: the library's own count (ssx_units_info)
     props = torch.cuda.get_device_properties(local_rank)
+    scratch = r.scratch_info()
     me = {"rank": rank, "local_rank": local_rank, "hostname": socket.gethostname(), "pid": os.getpid(),
           "device": props.name, "device_uuid": str(getattr(props, "uuid", "")), "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
           "ms_per_step": round(my_ms, 3), "path_ms": round(my_path_ms, 3), "generate_ms": round(stage_ms["generate"], 3),
-          "tiles_owned": my_tiles, "units_parked_frac": round(sums["units_parked"] / float(n_units), 4)}
+          "tiles_owned": my_tiles, "units_parked_frac": round(sums["units_parked"] / float(n_units), 4),
+          "device_scratch_bytes": scratch, "device_scratch_total": int(sum(scratch.values())) if isinstance(scratch, dict) else None}
     ranks = [me]
     overlap = None
     evidence_error = None
     if use_dist:
-        # (every rank takes the same path through these collectives; an exception here -- a torch without all_gather_object on this backend,
-        # say -- is reported in the line instead of costing the run its measurement: the device and overlap checks then say "not checked")
+        # Every rank takes the same path through the collectives: the work that can fail on ONE rank -- an extra render, its
+        # buffers -- comes first, without a collective in it; the ranks then agree on an ok flag (MIN), and only if every rank is fine do they
+        # gather the records and sum the row masks.  A rank that failed reports why; nobody is left waiting in a collective the other skipped.
+        local_error, nz = None, None
+        rows = sorted({0, H // 2, H - 1})
         try:
-            gathered = [None] * world
-            dist.all_gather_object(gathered, me)
-            ranks = gathered
-            # the un-reduced image of every rank on three sampled rows: nonzero sets must be pairwise disjoint
+            # the un-reduced image of this rank on three sampled rows: the nonzero sets must be pairwise disjoint across ranks
             own = torch.zeros_like(out)
             r.render_device(own.data_ptr(), stream.cuda_stream)
             torch.cuda.synchronize()
-            rows = sorted({0, H // 2, H - 1})
             nz = (own[rows] != 0).any(dim=-1).to(torch.int32)                        # [rows, W]
-            tot = nz.clone() if not test_one_gpu else nz.cpu()
-            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-            overlap = {"rows": rows, "pixels_nonzero_on_more_than_one_rank": int((tot > 1).sum()), "pixels_nonzero_on_some_rank": int((tot > 0).sum()), "row_pixels": len(rows) * W}
-        except SystemExit:
-            raise
+            del own
         except Exception as e:  # noqa: BLE001
+            local_error = "%s: %s" % (type(e).__name__, str(e)[:300])
+        okf = torch.tensor([0 if local_error else 1], dtype=torch.int32, device="cpu" if test_one_gpu else "cuda")
+        try:
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            all_ok = int(okf[0]) == 1
+            gathered = [None] * world
+            dist.all_gather_object(gathered, dict(me, evidence_error=local_error))
+            ranks = gathered
+            if all_ok:
+                tot = nz.clone() if not test_one_gpu else nz.cpu()
+                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+                overlap = {"rows": rows, "pixels_nonzero_on_more_than_one_rank": int((tot > 1).sum()), "pixels_nonzero_on_some_rank": int((tot > 0).sum()), "row_pixels": len(rows) * W}
+            else:
+                evidence_error = "; ".join("rank %d: %s" % (x["rank"], x["evidence_error"]) for x in gathered if x and x.get("evidence_error")) or "a rank failed"
+        except Exception as e:  # noqa: BLE001 -- (a backend without all_gather_object, say: every rank raises at the same call)
             evidence_error = "%s: %s" % (type(e).__name__, str(e)[:300])
     if os.environ.get("SSX_BENCH_DUMP"):  # tests: rank 0's combined image
         if rank == 0:
@@ -572,19 +725,32 @@ def main():
         if use_dist:
             dist.barrier(); dist.destroy_process_group()
         return
+    refusal = None
+    check = None
+    devs = []
     if rank == 0:
         # ---- the timed image is a checked image: no line for an image that differs from the oracle
-        check = None
         if not args.no_check:
             from simple_spectral_amd import textures as _tx
             check = oracle_check(last_host_img, args.scene, W, H, spp_total, args.observer, _tx.resolve(texture)) if args.uplift == "ours" else {"skipped": "uplift %s: the check needs the model the renderer fitted" % args.uplift}
             if check.get("differing_floats"):
-                raise SystemExit("bench.py: the timed image differs from the CPU oracle (%d floats on %d tiles): no bench line" % (check["differing_floats"], check["tiles"]))
+                refusal = "bench.py: the timed image differs from the CPU oracle (%d floats on %d tiles): no bench line" % (check["differing_floats"], check["tiles"])
         devs = [(x["hostname"], x["device_uuid"] or x["pci_bus_id"]) for x in ranks]
-        if len(ranks) == world and len(set(devs)) != len(devs) and not test_one_gpu:
-            raise SystemExit("bench.py: two ranks report the same device: %s" % devs)
-        if overlap and overlap["pixels_nonzero_on_more_than_one_rank"]:
-            raise SystemExit("bench.py: rank images overlap on %d sampled pixels: the tile partition is wrong" % overlap["pixels_nonzero_on_more_than_one_rank"])
+        if not refusal and len(ranks) == world and len(set(devs)) != len(devs) and not test_one_gpu:
+            refusal = "bench.py: two ranks report the same device: %s" % devs
+        if not refusal and overlap and overlap["pixels_nonzero_on_more_than_one_rank"]:
+            refusal = "bench.py: rank images overlap on %d sampled pixels: the tile partition is wrong" % overlap["pixels_nonzero_on_more_than_one_rank"]
+    # rank 0's verdict reaches every rank BEFORE anybody leaves (a rank 0 that raised left the others in the closing barrier until
+    # the launcher's timeout): one broadcast word, then every rank exits with the same code
+    if use_dist:
+        verdict = torch.tensor([1 if refusal else 0], dtype=torch.int32, device="cpu" if test_one_gpu else "cuda")
+        dist.broadcast(verdict, src=0)
+        if int(verdict[0]):
+            dist.destroy_process_group()
+            raise SystemExit(refusal or "bench.py: rank 0 refused to print a bench line (its message is on rank 0's stderr)")
+    elif refusal:
+        raise SystemExit(refusal)
+    if rank == 0:
         samples_per_step = W * H * spp_total
         value = samples_per_step * args.steps / elapsed / 1e6
         per_gpu_samples = W * H * args.spp
@@ -599,17 +765,17 @@ def main():
         line = {
             "metric": "Msamples/s (w*h*spp/s) %s %dx%d" % (args.scene, W, H),
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             # `value`: every step ends with the combined image in (pinned) host memory on rank 0 -- the metric as SURVEY 8(d) defines it
             # ("framebuffer reduce + D2H of XYZA included"); value_device_resident: the same steps without that copy (what rounds 1-3
             # reported as `value`; value_host_inclusive is kept as an alias of `value` for readers of those rounds)
             "value_device_resident": round(samples_per_step * args.steps / elapsed_resident / 1e6, 2),
-            "ms_per_step_device_resident": round(elapsed_resident / args.steps * 1e3, 3),
+            "ms_per_step_device_resident": round(elapsed_resident / max(args.steps, 1) * 1e3, 3),
             "value_host_inclusive": round(value, 2),
             "config": {"workload": "%s %dx%d spp=%d/GPU (total spp %d) CIE%d uplift=%s hero-wavelength megakernel" % (args.scene, W, H, args.spp, spp_total, args.observer, args.uplift),
                        "parallelism": "tile-split x%d (round-robin over the tile list, rows rotated: tile_skew 1) + RCCL reduce" % world if world > 1 else ("single GPU + RCCL reduce (world size 1, SSX_BENCH_FORCE_DIST)" if force_dist else "single GPU"),
-                       "texture": texture, "seed": 0},
+                       "texture": texture, "seed": 0, "kernel_source_id": kernel_source_id()},
             "roofline": {"bound": "valu", "achieved": round(achieved_tflops, 3), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved_tflops / PEAK_VALU_TFLOPS, 4),
                          "traffic": traffic,
@@ -643,7 +809,8 @@ def main():
                                "devices_distinct": (len(set(devs)) == len(devs)) if len(ranks) == world else None, "overlap": overlap, "evidence_error": evidence_error,
                                "slowest_rank_ms": max(x["ms_per_step"] for x in ranks), "fastest_rank_ms": min(x["ms_per_step"] for x in ranks)}
         # weak-scaling efficiency against a stated N = 1 figure (the driver computes its own from its per-N runs; this one names what it used)
-        line["efficiency_vs_n1_reference"] = {"value": round(value / (world * n1["value"]), 4), "n1_value": n1["value"], "n1_source": n1["source"]}
+        line["efficiency_vs_n1_reference"] = {"value": round(value / (world * n1["value"]), 4) if n1["value"] else None, "n1_value": n1["value"], "n1_source": n1["source"],
+                                              "kernel_source_id": n1.get("kernel_source_id"), "refused": n1.get("refused")}
         if world == 1 and not args.no_cpu_baseline:
             from simple_spectral_amd import textures
             line["cpu_baseline"] = cpu_baseline(args.scene, W, H, textures.resolve(texture))  # "procedural:N[:SEED]" -> the same texels the GPU run used

@@ -247,6 +247,12 @@ int ssx_accumulate_peer(ssx_ctx* ctx, void* d_dst, int src_device, const void* d
  * communicators are created by the first combine of a group of contexts and kept in them for the next (a call with other
  * contexts, or the same in another order, replaces them; ssx_destroy releases a context's). */
 int ssx_reduce_rccl(ssx_ctx** ctxs, int n, uint32_t width, uint32_t height);
+/* A dry run of that combine on whatever devices this process sees, REPORTING what it finds instead of failing on it: device list with
+ * free memory, peer access pair by pair, ncclCommInitAll over all of them, one grouped 4 MiB ncclReduce to device 0 checked element by
+ * element.  `report` receives JSON text.  Returns the number of devices the reduce went through correctly (0: it did not happen -- the
+ * report says why), or SSX_ERR_ARG.  Needs no context; releases what it created.  (bench.py --dist-dry-run prints it next to the
+ * per-rank view of torch.distributed.) */
+int ssx_rccl_probe(char* report, size_t report_size);
 /* Groups of communicators ssx_reduce_rccl has created in this process so far (a repeated combine must not add any). */
 uint64_t ssx_rccl_groups_made(void);
 
@@ -284,6 +290,10 @@ int ssx_scratch_info(ssx_ctx* ctx, uint64_t* sample_bytes, uint64_t* log_bytes);
  * large count is normal for a device that owns few tiles at many samples per pixel (a rank of a multi-GPU render: three quarters
  * of the units at 512 tiles x 2048 samples).  Waits for a queued ssx_render_device. */
 int ssx_sums_info(ssx_ctx* ctx, uint64_t* units_parked, uint64_t* units_chained);
+/* Work units the context has enqueued since ssx_create (every launch of the path kernel: tiles owned x groups of consecutive samples;
+ * the calibration render of ssx_upload_scene not counted): the denominator of the counts above, from the code that sizes the
+ * launches -- a host need not re-derive the unit size (bench.py did, and was wrong for a render split into batches). */
+int ssx_units_info(ssx_ctx* ctx, uint64_t* units_enqueued);
 /* Which path kernel the uploaded scene runs: 0 = the generic one (pass 1 of the intersection loops over the
  * quads), 1 / 2 = the kernel whose pass 1 is specialised to the mesh topology of the reference's Cornell box /
  * plane scene (the scene's quad corners coincide in exactly that pattern; positions are free), 3 = specialised to

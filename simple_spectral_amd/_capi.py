@@ -75,7 +75,7 @@ HIP_SYMBOLS = ["ssx_create", "ssx_destroy", "ssx_upload_scene", "ssx_render_star
                "ssx_is_rendering", "ssx_progress", "ssx_render_wait", "ssx_render_device", "ssx_last_error",
                "ssx_abi_version", "ssx_kernel_info", "ssx_plan_info", "ssx_set_timing", "ssx_get_timing",
                "ssx_device_framebuffer", "ssx_device_index", "ssx_read_framebuffer", "ssx_accumulate_peer",
-               "ssx_debug_eval", "ssx_debug_samples", "ssx_debug_sweep", "ssx_kernel_variant", "ssx_kernel_name", "ssx_scratch_info", "ssx_calibration_info", "ssx_set_jit", "ssx_debug_pass1_source", "ssx_done_spp", "ssx_reduce_rccl", "ssx_sums_info", "ssx_rccl_groups_made", "ssx_jit_status", "ssx_jit_counters", "ssx_done_tiles", "ssx_render_device_wait"]
+               "ssx_debug_eval", "ssx_debug_samples", "ssx_debug_sweep", "ssx_kernel_variant", "ssx_kernel_name", "ssx_scratch_info", "ssx_calibration_info", "ssx_set_jit", "ssx_debug_pass1_source", "ssx_done_spp", "ssx_reduce_rccl", "ssx_sums_info", "ssx_rccl_groups_made", "ssx_jit_status", "ssx_jit_counters", "ssx_done_tiles", "ssx_render_device_wait", "ssx_units_info", "ssx_rccl_probe"]
 (SSX_SWEEP_RCP, SSX_SWEEP_SQRT, SSX_SWEEP_INVERSESQRT, SSX_SWEEP_SIN, SSX_SWEEP_COS, SSX_SWEEP_ACOS, SSX_SWEEP_DIV_PI,
  SSX_SWEEP_RCP64, SSX_SWEEP_DIV_PAIRS, SSX_SWEEP_ACOS_SIN, SSX_SWEEP_SIN_PROOF, SSX_SWEEP_COS_PROOF, SSX_SWEEP_ACOS_PROOF) = range(1, 14)
 # ssx_debug_eval ops (include/ssx.h)
@@ -246,6 +246,10 @@ def hip_lib():
             lib.ssx_debug_pass1_source.argtypes = [C.POINTER(C.c_uint8), C.c_uint32, C.c_char_p, C.c_char_p, C.c_size_t]
         if not override or hasattr(lib, "ssx_sums_info"):
             lib.ssx_sums_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        if hasattr(lib, "ssx_rccl_probe"):
+            lib.ssx_rccl_probe.argtypes = [C.c_char_p, C.c_size_t]
+        if hasattr(lib, "ssx_units_info"):  # (new in round 6: an older build loaded through SSX_HIP_LIB_OVERRIDE has none)
+            lib.ssx_units_info.argtypes = [vp, C.POINTER(C.c_uint64)]
         if not override or hasattr(lib, "ssx_jit_status"):
             lib.ssx_jit_status.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t]
             lib.ssx_jit_counters.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

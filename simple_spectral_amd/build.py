@@ -12,8 +12,9 @@ ROOT = os.path.dirname(PKG)
 HIP_LIB = os.path.join(PKG, "libssx_hip.so")
 # The same library with the inter-wave hand-over of the pixel sums stated in the HIP memory model (csrc/ssx_kernels.hip unit_fold:
 # acquire / release agent-scope read-modify-writes instead of relaxed atomics + s_waitcnt; 25 % slower).  Not what runs by default:
-# tests/test_gpu_variants.py runs it next to the default build on every `pytest -m gpu`, which is what validates the default build's
-# below-the-model ordering on the box and toolchain at hand.
+# tests/test_gpu_variants.py runs it next to the default build on every `pytest -m gpu` (stress cases, fuzzed scenes and the whole
+# parity suites), which is what validates the default build's below-the-model ordering on the box and toolchain at hand.  Built on
+# request only (build_hip(formal=True): __graft_entry__.build(), `python -m simple_spectral_amd.build --variants`, SSX_BUILD_FORMAL=1).
 HIP_LIB_FORMAL = os.path.join(PKG, "libssx_hip_formal.so")
 HOST_LIB = os.path.join(PKG, "libssx_host.so")
 
@@ -92,7 +93,9 @@ def embed_sources():
         open(SOURCES_GEN, "w").write(text)
 
 
-def build_hip(force=False, verbose=False):
+def build_hip(force=False, verbose=False, formal=False):
+    """libssx_hip.so; with formal=True (python -m simple_spectral_amd.build --variants, __graft_entry__.build(): what the GPU tests need)
+    also libssx_hip_formal.so -- a second full compilation that only tests/test_gpu_variants.py loads, so not part of a plain build."""
     if force or _stale(HIP_LIB, HIP_DEPS):
         check_toolchain()
         embed_sources()
@@ -100,7 +103,9 @@ def build_hip(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    if force or _stale(HIP_LIB_FORMAL, HIP_DEPS):
+    if formal and (force or _stale(HIP_LIB_FORMAL, HIP_DEPS)):
+        check_toolchain()
+        embed_sources()
         cmd = [hipcc()] + HIP_FLAGS + ["-DSSX_ACCUM_FORMAL"] + HIP_SRC + ["-o", HIP_LIB_FORMAL, "-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd))
@@ -124,8 +129,8 @@ def build_host(force=False, verbose=False):
     return HOST_LIB
 
 
-def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_host(force, verbose)
+def build_all(force=False, verbose=False, formal=False):
+    return build_hip(force, verbose, formal), build_host(force, verbose)
 
 
 if __name__ == "__main__":
@@ -133,4 +138,4 @@ if __name__ == "__main__":
     if "--embed-only" in sys.argv:
         embed_sources()
     else:
-        build_all(force="--force" in sys.argv, verbose=True)
+        build_all(force="--force" in sys.argv, verbose=True, formal="--variants" in sys.argv or os.environ.get("SSX_BUILD_FORMAL") == "1")

@@ -6,6 +6,7 @@
 
 #include "../../include/ssx.h"
 
+#include <chrono>
 #include <array>
 #include <atomic>
 #include <cstdarg>
@@ -91,10 +92,10 @@ struct ssx_ctx {
 	std::atomic<int> rendering{0};
 	std::atomic<int> stop_flag{0};
 	std::atomic<uint32_t> done_spp{0};
-	uint32_t device_spp_cap = 0;         // ssx_render_device: max_spp_per_launch of the last render outside a stream capture (what a captured one is held to)
 	std::atomic<uint32_t> done_tiles{0}; // tile_major renders: the device's tiles finished so far (ssx_done_tiles)
 	uint32_t total_spp = 0;
 	int worker_rc = 0;
+	uint64_t units_enqueued = 0;          // work units of every path-kernel launch so far (ssx_units_info)
 	ssx_render_params cur{};
 
 
@@ -145,6 +146,18 @@ struct RcclApi {
 	std::mutex mutex;
 };
 RcclApi& rccl_api() { static RcclApi api; return api; }
+// opens RCCL once per process (caller holds rccl.mutex); false + the reason when it is not there or lacks an entry point
+bool load_rccl(RcclApi& rccl, std::string* why) {
+	if (rccl.lib) return true;
+	// the soname first: a process that already holds an RCCL under that name (torch's) must not map a second one
+	for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so" }) if ((rccl.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+	if (!rccl.lib) { const char* e = dlerror(); *why = std::string("RCCL is not available (") + (e ? e : "dlopen failed") + ")"; return false; }
+	rccl.init_all = (decltype(rccl.init_all))dlsym(rccl.lib, "ncclCommInitAll"); rccl.group_start = (decltype(rccl.group_start))dlsym(rccl.lib, "ncclGroupStart");
+	rccl.group_end = (decltype(rccl.group_end))dlsym(rccl.lib, "ncclGroupEnd"); rccl.reduce = (decltype(rccl.reduce))dlsym(rccl.lib, "ncclReduce");
+	rccl.comm_destroy = (decltype(rccl.comm_destroy))dlsym(rccl.lib, "ncclCommDestroy"); rccl.error_string = (decltype(rccl.error_string))dlsym(rccl.lib, "ncclGetErrorString");
+	if (!rccl.init_all || !rccl.group_start || !rccl.group_end || !rccl.reduce || !rccl.comm_destroy || !rccl.error_string) { dlclose(rccl.lib); rccl.lib = nullptr; *why = "RCCL lacks an entry point"; return false; }
+	return true;
+}
 void drop_rccl_comm(ssx_ctx* ctx) {
 	if (ctx->rccl_comm && rccl_api().comm_destroy) { (void)hipSetDevice(ctx->device); (void)rccl_api().comm_destroy(ctx->rccl_comm); }
 	ctx->rccl_comm = nullptr; ctx->rccl_group = 0; ctx->rccl_rank = -1; ctx->rccl_size = 0;
@@ -466,6 +479,16 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p, bool ask_device =
 	return pl;
 }
 
+// A render recorded into a hipGraph (ssx_render_device while the stream is capturing) cannot ask the device for its free memory and
+// cannot grow a buffer: the samples per pixel one of its launches may cover follow from the sample arrays the context already holds --
+// a budget in RECORDS, so it holds whatever the captured render's image size and tile split are (the cap used to be the
+// earlier render's, in ITS samples per pixel).  Nothing fits: the cap stays, and the caller reports that the buffers would have to grow.
+void cap_to_allocation(const ssx_ctx* ctx, LaunchPlan& pl) {
+	const size_t per_spp = (size_t)(pl.args.my_tiles ? pl.args.my_tiles : 1u) * 64u;
+	const size_t fit = ctx->sample_slots / per_spp;
+	if (fit >= 1 && fit < pl.max_spp_per_launch) pl.max_spp_per_launch = (uint32_t)fit;
+}
+
 int ensure_samples(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t n_k) {
 	size_t need = (size_t)pl.args.my_tiles * 64u * n_k;
 	if (ctx->sample_slots < need) {
@@ -697,6 +720,7 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	uint32_t blocks = want_blocks < (uint32_t)ctx->resident_blocks ? want_blocks : (uint32_t)ctx->resident_blocks;
 	if (blocks * 4u > ctx->max_wave_slots) blocks = ctx->max_wave_slots / 4u; // every wave of the grid owns a log region
 	{ int r = launch_kernel(ctx, path_kernel, blocks, path_lds, stream, b.a); if (r) return r; }
+	if (!calibration) ctx->units_enqueued += b.units;
 	if (calibration) ctx->resident_blocks = 0; // computed for the calibration kernel: recompute for the path kernel
 	if (ctx->timing) for (int k = 2; k < 6; ++k) SSX_HIP(ctx, hipEventRecord(b.tev[k], stream)); // (fold and pixel sums ran inside the path kernel: their slots stay ~0)
 	return SSX_OK;
@@ -1106,8 +1130,8 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	{
 		LaunchPlan probe = make_plan(ctx, p, !capturing);
 		// the batch ensure_samples below will size the arrays for -- the same expression.  While capturing the device cannot be asked
-		// for its free memory: the cap the warm-up render outside the capture worked with is the one that holds (device_spp_cap).
-		if (capturing && ctx->device_spp_cap && probe.max_spp_per_launch > ctx->device_spp_cap) probe.max_spp_per_launch = ctx->device_spp_cap;
+		// for its free memory and no buffer may grow: a launch may cover what the sample arrays of the warm-up render hold (cap_to_allocation).
+		if (capturing) cap_to_allocation(ctx, probe);
 		uint32_t probe_batch = p->spp_per_launch ? p->spp_per_launch : p->spp;
 		if (probe_batch > p->spp) probe_batch = p->spp;
 		if (probe_batch > probe.max_spp_per_launch) probe_batch = probe.max_spp_per_launch;
@@ -1123,8 +1147,7 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	SSX_HIP(ctx, hipMemsetAsync(ctx->d_accum, 0, accum_slots(p->width, p->height) * 4 * sizeof(double), stream));
 	if (!capturing) maybe_swap_jit(ctx, (uint64_t)p->width * p->height * p->spp / p->tile_stride);
 	LaunchPlan pl = make_plan(ctx, p, !capturing);
-	if (!capturing) ctx->device_spp_cap = pl.max_spp_per_launch;
-	else if (ctx->device_spp_cap && pl.max_spp_per_launch > ctx->device_spp_cap) pl.max_spp_per_launch = ctx->device_spp_cap;
+	if (capturing) cap_to_allocation(ctx, pl);
 	// one batch when the whole render fits the buffer budget, else batches back to back
 	uint32_t batch = p->spp_per_launch ? p->spp_per_launch : p->spp;
 	if (batch > p->spp) batch = p->spp;
@@ -1264,15 +1287,7 @@ int ssx_reduce_rccl(ssx_ctx** ctxs, int n, uint32_t width, uint32_t height) {
 	ssx_ctx* root = ctxs[0];
 	RcclApi& rccl = rccl_api();
 	std::lock_guard<std::mutex> load_guard(rccl.mutex); // one combine at a time per process (loading the library, and the communicators below)
-	if (!rccl.lib) {
-		// the soname first: a process that already holds an RCCL under that name (torch's) must not map a second one
-		for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so" }) if ((rccl.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
-		if (!rccl.lib) { const char* why = dlerror(); return fail(root, SSX_ERR_DEVICE, std::string("RCCL is not available (") + (why ? why : "dlopen failed") + ")"); }
-		rccl.init_all = (decltype(rccl.init_all))dlsym(rccl.lib, "ncclCommInitAll"); rccl.group_start = (decltype(rccl.group_start))dlsym(rccl.lib, "ncclGroupStart");
-		rccl.group_end = (decltype(rccl.group_end))dlsym(rccl.lib, "ncclGroupEnd"); rccl.reduce = (decltype(rccl.reduce))dlsym(rccl.lib, "ncclReduce");
-		rccl.comm_destroy = (decltype(rccl.comm_destroy))dlsym(rccl.lib, "ncclCommDestroy"); rccl.error_string = (decltype(rccl.error_string))dlsym(rccl.lib, "ncclGetErrorString");
-		if (!rccl.init_all || !rccl.group_start || !rccl.group_end || !rccl.reduce || !rccl.comm_destroy || !rccl.error_string) { dlclose(rccl.lib); rccl.lib = nullptr; return fail(root, SSX_ERR_DEVICE, "RCCL lacks an entry point"); }
-	}
+	{ std::string why; if (!load_rccl(rccl, &why)) return fail(root, SSX_ERR_DEVICE, why); }
 	std::vector<int> devs(n);
 	for (int i = 0; i < n; ++i) {
 		if (!ctxs[i] || !ctxs[i]->d_out || ctxs[i]->out_pixels < (size_t)width * height) return fail(root, SSX_ERR_STATE, "ssx_reduce_rccl: a context has no rendered framebuffer of that size");
@@ -1308,6 +1323,75 @@ int ssx_reduce_rccl(ssx_ctx** ctxs, int n, uint32_t width, uint32_t height) {
 		return fail(root, SSX_ERR_DEVICE, std::string("ncclReduce: ") + (rc > 0 ? rccl.error_string(rc) : "hipSetDevice failed"));
 	}
 	return SSX_OK;
+}
+
+// A dry run of the combine above on whatever this process can see (the first real multi-GPU run should be boring):
+// every visible device gets a communicator (ncclCommInitAll), peer access is looked up pair by pair, one grouped ncclReduce of a
+// 4 MiB float buffer per device (rank i holds i + 1 in every element) goes to device 0 and is checked there -- and whatever it finds
+// is REPORTED (JSON text), not failed on: a missing library, one device only, a pair without peer access, an error code.  Returns the
+// number of devices the reduce went through correctly (0 when it did not happen), or SSX_ERR_ARG.  No context needed; communicators
+// and buffers are released again.
+int ssx_rccl_probe(char* report, size_t report_size) {
+	if (!report || report_size < 64) return SSX_ERR_ARG;
+	std::string out = "{";
+	auto finish = [&](int n_ok) { out += fmt("\"devices_reduced_ok\": %d}", n_ok); snprintf(report, report_size, "%s", out.c_str()); return n_ok; };
+	int n = 0, before = 0;
+	(void)hipGetDevice(&before);
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); out += "\"error\": \"no HIP device\", "; return finish(0); }
+	out += fmt("\"visible_devices\": %d, \"devices\": [", n);
+	for (int i = 0; i < n; ++i) {
+		hipDeviceProp_t prop; size_t free_b = 0, total_b = 0;
+		(void)hipGetDeviceProperties(&prop, i); (void)hipSetDevice(i); (void)hipMemGetInfo(&free_b, &total_b);
+		out += fmt("%s{\"index\": %d, \"name\": \"%s\", \"pci\": \"%04x:%02x:%02x\", \"free_bytes\": %zu, \"total_bytes\": %zu}", i ? ", " : "", i, prop.name, prop.pciDomainID, prop.pciBusID, prop.pciDeviceID, free_b, total_b);
+	}
+	out += "], \"peer_access\": [";
+	int no_peer = 0;
+	for (int i = 0; i < n; ++i) {
+		out += i ? ", [" : "[";
+		for (int k = 0; k < n; ++k) { int can = (i == k); if (i != k) (void)hipDeviceCanAccessPeer(&can, i, k); if (!can) ++no_peer; out += fmt("%s%d", k ? ", " : "", can); }
+		out += "]";
+	}
+	out += fmt("], \"pairs_without_peer_access\": %d, ", no_peer);
+	RcclApi& rccl = rccl_api();
+	std::lock_guard<std::mutex> guard(rccl.mutex);
+	{ std::string why; if (!load_rccl(rccl, &why)) { out += "\"rccl\": \"" + why + "\", "; (void)hipSetDevice(before); return finish(0); } }
+	std::vector<int> devs(n); for (int i = 0; i < n; ++i) devs[i] = i;
+	std::vector<void*> comms(n, nullptr);
+	const auto t0 = std::chrono::steady_clock::now();
+	int rc = rccl.init_all(comms.data(), n, devs.data());
+	out += fmt("\"ncclCommInitAll_ms\": %.1f, ", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+	if (rc) { out += std::string("\"rccl\": \"ncclCommInitAll: ") + rccl.error_string(rc) + "\", "; (void)hipSetDevice(before); return finish(0); }
+	const size_t count = (size_t)1 << 20; // floats per device: the headline image's 4 MiB
+	std::vector<float*> buf(n, nullptr); std::vector<hipStream_t> st(n, nullptr);
+	bool ok = true;
+	for (int i = 0; i < n && ok; ++i) {
+		ok = hipSetDevice(i) == hipSuccess && hipMalloc((void**)&buf[i], count * sizeof(float)) == hipSuccess && hipStreamCreate(&st[i]) == hipSuccess;
+		if (ok) { std::vector<float> h(count, (float)(i + 1)); ok = hipMemcpy(buf[i], h.data(), count * sizeof(float), hipMemcpyHostToDevice) == hipSuccess; }
+	}
+	int n_ok = 0;
+	if (!ok) out += "\"rccl\": \"could not set up the probe buffers\", ";
+	else {
+		const auto t1 = std::chrono::steady_clock::now();
+		rc = rccl.group_start();
+		for (int i = 0; i < n && !rc; ++i) { (void)hipSetDevice(i); rc = rccl.reduce(buf[i], buf[i], count, 7 /* ncclFloat */, 0 /* ncclSum */, 0, comms[i], st[i]); }
+		const int rc_end = rccl.group_end();
+		if (!rc) rc = rc_end;
+		for (int i = 0; i < n; ++i) { (void)hipSetDevice(i); (void)hipStreamSynchronize(st[i]); }
+		out += fmt("\"reduce_4MiB_ms\": %.2f, ", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+		if (rc) out += std::string("\"rccl\": \"ncclReduce: ") + (rc > 0 ? rccl.error_string(rc) : "failed") + "\", ";
+		else {
+			std::vector<float> h(count);
+			(void)hipSetDevice(0);
+			const float want = 0.5f * (float)n * (float)(n + 1);
+			size_t bad = 0;
+			if (hipMemcpy(h.data(), buf[0], count * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess) { for (float v : h) bad += v != want; } else bad = count;
+			out += fmt("\"rccl\": \"ok\", \"reduce_elements_wrong\": %zu, ", bad);
+			if (bad == 0) n_ok = n;
+		}
+	}
+	for (int i = 0; i < n; ++i) { (void)hipSetDevice(i); if (st[i]) (void)hipStreamDestroy(st[i]); if (buf[i]) (void)hipFree(buf[i]); if (comms[i]) (void)rccl.comm_destroy(comms[i]); }
+	(void)hipSetDevice(before);
+	return finish(n_ok);
 }
 
 // communicators created so far in this process (tests: a second combine of the same contexts must not create any)
@@ -1473,6 +1557,12 @@ int ssx_sums_info(ssx_ctx* ctx, uint64_t* units_parked, uint64_t* units_chained)
 	}
 	if (units_parked) *units_parked = c[2];
 	if (units_chained) *units_chained = c[3];
+	return SSX_OK;
+}
+
+int ssx_units_info(ssx_ctx* ctx, uint64_t* units_enqueued) {
+	if (!ctx) return SSX_ERR_ARG;
+	if (units_enqueued) *units_enqueued = ctx->units_enqueued;
 	return SSX_OK;
 }
 

@@ -31,7 +31,7 @@
 // c*d - a*b in round-to-nearest), and with U, V, W negated det, T and 1/det are negated exactly, the mixed-sign test, |det| > EPS
 // and sign(T) == sign(det) read the same, and dist = T/det and the barycentrics U/det are the same floats -- also through the
 // binary64 fallback.  So three tables do where the reference's rule names six orders, and the ray set-up selects half as much
-// (rounds 1-4 kept all six; profiles/r05/isa_census.md).  The order per p is chosen so that each of the two slots is one select:
+// (rounds 1-4 kept all six; profiles/r05/isa_census.txt).  The order per p is chosen so that each of the two slots is one select:
 // slot A = x unless x is dominant (then y), slot B = z unless z is dominant (then y).
 #define SSX_PERM_COUNT 3u
 #define SSX_PERM_WORDS_PER_QUAD (SSX_PERM_COUNT * 12u)
@@ -84,7 +84,7 @@ struct SsxBlobHeader {
 	// index: for that the same vertices once more as 16-byte records {v[kx], v[ky], v[kz], 0} per permutation (off_vtab4, stride
 	// 4 * n_verts words) and per triangle t = 2 * quad + which the byte offsets of its A, B, C records within a permutation's
 	// table, off_triofs + 2 t: { A | B << 16, C } -- one 8-byte and three 12-byte LDS reads behind 6 integer instructions where the
-	// {x,y} / z tables and the vertex ids took 17 (profiles/r05/isa_census.md).
+	// {x,y} / z tables and the vertex ids took 17 (profiles/r05/isa_census.txt).
 	// The per-quad permuted table (off_perm) is the LAST section of the blob: the specialised kernels do not stage it.
 	uint32_t topology, n_verts, off_vtab, vtab_stride, off_vid, words_without_perm, off_vtab4, off_triofs;
 	// Intersection candidates are kept as 64-bit masks of 32 primitives (two triangle bits each); scenes with more primitives are

@@ -305,7 +305,10 @@ class Renderer:
         a, b = C.c_uint64(), C.c_uint64()
         if hasattr(self._lib, "ssx_sums_info"):
             self._check(self._lib.ssx_sums_info(self._ctx, C.byref(a), C.byref(b)))
-        return {"units_parked": a.value, "units_chained": b.value}
+        u = C.c_uint64()
+        if hasattr(self._lib, "ssx_units_info"):
+            self._check(self._lib.ssx_units_info(self._ctx, C.byref(u)))
+        return {"units_parked": a.value, "units_chained": b.value, "units": u.value}
 
     def save(self, path):
         fb = np.ascontiguousarray(self.framebuffer, dtype=np.float32)

@@ -20,7 +20,7 @@ def declared_functions(header):
 
 
 def test_libraries_export_every_declared_symbol():
-    sbuild.build_all()
+    sbuild.build_all(formal=True)  # (the GPU box gets the formal variant from the same build: tests/test_gpu_variants.py)
     hip = C.CDLL(sbuild.HIP_LIB)   # loads without a GPU; no compute call is made
     host = C.CDLL(sbuild.HOST_LIB)
     fx, fh = declared_functions("ssx.h"), declared_functions("ssx_host.h")

@@ -62,8 +62,20 @@ def test_bench_helpers_replay_stamp_and_n1_reference(tmp_path, monkeypatch):
     assert bench.measured_traffic(args, 2)[1]["replayed"]["stale"] is True
     tj.write_text(json.dumps({key: 123, key + " detail": {}}))
     assert "unknown" in str(bench.measured_traffic(args, 2)[1]["replayed"]["stale"])
-    n1 = bench.n1_reference()
-    assert n1["value"] > 1000 and "BENCH_r" in n1["source"]
+    # the N = 1 reference of the efficiency field: only a figure taken on THIS build's kernel sources counts
+    monkeypatch.delenv("SSX_BENCH_N1_VALUE", raising=False)
+    n1 = bench.n1_reference("f" * 16)                      # sources nobody has measured: refused, with the newest other figure named
+    assert n1["value"] is None and "no N = 1 figure" in n1["refused"] and "newest other" in n1["refused"]
+    rec = tmp_path / "BENCH_r99.json"
+    rec.write_text(json.dumps({"parsed": {"n_gpus": 1, "value": 3210.5, "config": {"workload": "cornell-srgb 512x512 spp=256/GPU (total spp 256)", "kernel_source_id": "f" * 16}}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    n1 = bench.n1_reference("f" * 16)
+    assert n1["value"] == 3210.5 and "BENCH_r99.json" in n1["source"] and not n1.get("refused")
+    assert bench.n1_reference("e" * 16)["value"] is None   # the same record is stale for other sources
+    monkeypatch.setenv("SSX_BENCH_N1_VALUE", "3000")
+    assert bench.n1_reference("e" * 16)["value"] == 3000.0
+    monkeypatch.delenv("SSX_BENCH_N1_VALUE")
+    monkeypatch.setattr(bench, "ROOT", ROOT)
     # the design's byte model the line quotes next to the counters
     assert 440 < bench.design_bytes_per_sample("cornell-srgb", levels=4.07) < 500      # 470.8: the counters read 1.23 x the path kernel's share of it
     assert abs(bench.algorithmic_bytes_per_sample_8d("cornell-srgb", 256) - (16.0 / 256 + 3.8)) < 1e-9

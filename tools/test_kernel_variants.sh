@@ -10,5 +10,5 @@ for E in "SSX_GENERIC_KERNEL=1" "SSX_NARROW_QUEUE=1" "SSX_PRE_HITS=0" "SSX_PRE_H
 done
 # The pixel sums' hand-over expressed in the HIP memory model (-DSSX_ACCUM_FORMAL, ssx_kernels.hip unit_fold: -25 %) against the default build's
 # relaxed atomics + s_waitcnt: the same suites on that build.
-tools/build_variant.sh formal -DSSX_ACCUM_FORMAL > /dev/null 2>&1
+python -m simple_spectral_amd.build --variants > /dev/null 2>&1
 echo "== -DSSX_ACCUM_FORMAL"; SSX_HIP_LIB_OVERRIDE=$PWD/simple_spectral_amd/libssx_hip_formal.so timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_units.py -q -m gpu -rf 2>&1 | grep -E "^(FAILED|ERROR)|^E  | passed| failed| error" | cut -c1-300
