@@ -216,6 +216,13 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	h.spec_basis_r = s->spec_basis_r; h.spec_basis_g = s->spec_basis_g; h.spec_basis_b = s->spec_basis_b;
 	h.n_textures = s->n_textures;
 	h.n_lights_recip = 1.0 / (double)(float)s->n_lights;
+	// a black surface ends its path on the random draws alone (ssx_kernels.hip path_step) -- provided (emitted * n_dot_l) * 0 is 0: no NaN / inf / huge emission sample
+	h.black_ends_path = 1u;
+	for (uint32_t i = 0; i < s->n_lights; ++i) {
+		const ssx_spectrum& es = s->spectra[s->materials[s->quads[s->lights[i]].material].emission_spectrum];
+		for (uint32_t k = 0; k < es.n; ++k) if (!(std::fabs(s->samples[es.offset + k]) <= 0x1p60f)) h.black_ends_path = 0u;
+	}
+	if (const char* e = debug_env("SSX_BLACK_SHORTCUT")) { if (e[0] == '0') h.black_ends_path = 0u; } // A/B runs and tests: evaluate everything
 	for (int i = 0; i < 4; ++i) { volatile float fi = (float)i; h.lambda_steps[i] = fi * s->lambda_step; } // one IEEE float multiply each, as spectrum.cpp:63
 	{
 		const ssx_spectrum &r = s->spectra[s->spec_basis_r], &g = s->spectra[s->spec_basis_g], &b = s->spectra[s->spec_basis_b];
@@ -1107,6 +1114,19 @@ int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 	return calibrate(ctx);
 }
 
+// samples per pixel of one launch of ssx_render_device: what the caller asked for, or the whole render; where the sample arrays' budget
+// allows less, launches of EQUAL size (plane-srgb 1024^2 at 1024 spp ran as 341 + 341 + 341 + 1 before round 6: a launch of one sample
+// per pixel at the end of every render)
+static uint32_t device_batch(const ssx_render_params* p, const LaunchPlan& pl) {
+	uint32_t batch = p->spp_per_launch ? p->spp_per_launch : p->spp;
+	if (batch > p->spp) batch = p->spp;
+	if (batch > pl.max_spp_per_launch) {
+		const uint32_t n = (p->spp + pl.max_spp_per_launch - 1u) / pl.max_spp_per_launch;
+		batch = (p->spp + n - 1u) / n;
+	}
+	return batch;
+}
+
 int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out, void* hip_stream) {
 	if (!ctx) return SSX_ERR_ARG;
 	int rc = check_params(ctx, p);
@@ -1132,9 +1152,7 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 		// the batch ensure_samples below will size the arrays for -- the same expression.  While capturing the device cannot be asked
 		// for its free memory and no buffer may grow: a launch may cover what the sample arrays of the warm-up render hold (cap_to_allocation).
 		if (capturing) cap_to_allocation(ctx, probe);
-		uint32_t probe_batch = p->spp_per_launch ? p->spp_per_launch : p->spp;
-		if (probe_batch > p->spp) probe_batch = p->spp;
-		if (probe_batch > probe.max_spp_per_launch) probe_batch = probe.max_spp_per_launch;
+		const uint32_t probe_batch = device_batch(p, probe);
 		const size_t need = (size_t)probe.args.my_tiles * 64u * probe_batch;
 		const bool grow = ctx->accum_pixels < accum_slots(p->width, p->height) || ctx->sample_slots < need;
 		if (grow && capturing) return fail(ctx, SSX_ERR_STATE, "the context's buffers have to grow for this render: run it once outside the stream capture first");
@@ -1149,9 +1167,7 @@ int ssx_render_device(ssx_ctx* ctx, const ssx_render_params* p, void* d_xyza_out
 	LaunchPlan pl = make_plan(ctx, p, !capturing);
 	if (capturing) cap_to_allocation(ctx, pl);
 	// one batch when the whole render fits the buffer budget, else batches back to back
-	uint32_t batch = p->spp_per_launch ? p->spp_per_launch : p->spp;
-	if (batch > p->spp) batch = p->spp;
-	if (batch > pl.max_spp_per_launch) batch = pl.max_spp_per_launch;
+	const uint32_t batch = device_batch(p, pl);
 	if ((rc = ensure_samples(ctx, pl, batch))) return rc;
 	if ((rc = launch_batches(ctx, pl, p->spp, batch, stream))) return rc;
 	if ((rc = launch_finalize(ctx, p, p->spp, (float*)d_xyza_out, stream))) return rc;

@@ -95,7 +95,9 @@ struct SsxBlobHeader {
 	// read from the blob's copy in HBM: perm_hbm = 1 and the table's device address
 	uint32_t perm_hbm, perm_ptr_lo, perm_ptr_hi;
 	float cam_dir[3];           // camera.dir (no_flat_field_correction renders)
-	uint32_t pad4_[2];
+	uint32_t black_ends_path;   // 1: every light's emission table is finite (|x| <= 2^60), so a black Lambertian surface's next-event term is exactly +-0 and
+	                            // path_step may end the path there on the random draws alone (ssx_kernels.hip); 0: a NaN / inf emission sample exists, evaluate everything
+	uint32_t pad4_[1];
 	float lambda_steps[4];      // float(i) * lambda_step, i = 0..3 (spectrum.cpp:63: lambda_0 + i*LAMBDA_STEP)
 	double n_lights_recip;      // RN64(1 / (double)(float)n_lights): `pdf /= float(lights.size())` (scene.cpp:430) as one multiply (ssx_exact.h)
 	double pad2_;

@@ -823,6 +823,26 @@ __device__ __forceinline__ void sample_light(const Lds& L, Rng& rng, V3 from, V3
 	pdf = ssx_exact::div64_by(pdf, L.hdr().n_lights_recip); // pdf /= float(n_lights): the divisor's binary64 reciprocal comes with the scene
 }
 
+// The draws of sample_light without its arithmetic: what a BLACK surface needs of it (path_step).  scene.cpp:423 (light pick, Lemire),
+// geometry.cpp:143 (the quad's triangle pick; a PrimTri light has none), util/random.cpp:103-104 (Arvo's two numbers, drawn before
+// anything is computed).
+__device__ __forceinline__ void skip_light_draws(const Lds& L, Rng& rng) {
+	const uint32_t nl = L.hdr().n_lights;
+	uint32_t pick = 0u;
+	if (nl == 1u) (void)rng_next(rng); else pick = rand_choice(rng, nl);
+	if (L.quad(L.light(pick)).is_tri == 0u) (void)rng_next(rng);
+	(void)rng_next(rng); (void)rng_next(rng);
+}
+// ... and of rand_coshemi (util/random.cpp:29-49): the angle's draw, the radius' draw, and the rejection test on the same float
+// sqrt(1 - radius_sq) the sampler makes it on -- without the sine / cosine the direction would need.
+__device__ __forceinline__ void skip_coshemi_draws(Rng& rng) {
+	float pdf;
+	do {
+		(void)rng_next(rng);
+		pdf = ssx_exact::sqrt_normal(1 - rand_1f(rng));
+	} while (pdf <= SSX_EPS);
+}
+
 // ------------------------------------------------------------------ BSDF sampling ----
 // util/random.cpp:29-49
 __device__ __forceinline__ V3 rand_coshemi(Rng& rng, float& pdf) {
@@ -1034,6 +1054,23 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 #pragma unroll
 	for (int k = 0; k < 4; ++k) f_lamb[k] = SSX_DIV_CONST(alb.v[k], SSX_PI_F);
 
+	// A BLACK Lambertian surface (f_s = albedo / pi = 0 at all four wavelengths: the walls of plane-srgb's light box, scene.cpp:357-413)
+	// ends the path here, and nothing of what it would multiply by zero is evaluated -- exactly:
+	//   * next-event term (:216) ((emitted * n_dot_l) * f_s) / pdf: emitted is finite (header flag black_ends_path: every light's emission
+	//     table is, checked at upload), n_dot_l is a float > 0 where the term exists at all (a NaN direction fails `n_dot_l > 0`), so the
+	//     numerator is +-0; pdf = (1 / area) [* 0.5] / n_lights with 0 <= area <= 2 pi never NaN (spherical-tri.cpp:71-72 clamps it) lies
+	//     in (0, +inf]; +-0 / pdf = +-0, and `radiance += +-0` leaves radiance as it is (it starts from +0 and every addend is >= 0 or NaN);
+	//   * continuation (:235): glm::dot(f_s, f_s) > 0 fails, no ray.
+	// What the reference does that still matters is CONSUME RANDOM NUMBERS (the sample's final PCG32 state is part of the per-sample
+	// parity contract): the light sampler's and the hemisphere sampler's draws are made, rejection loops included, their arithmetic --
+	// six binary64 arc cosines, Arvo's sampler, a sine and a cosine: ~55 % of a level's instructions -- is not.  In plane-srgb every path's
+	// second hit is such a wall (wave-uniform there); a wave of the Cornell box never takes the branch.
+	if (M.kind == 0u && h.black_ends_path != 0u && f_lamb[0] == 0.0f && f_lamb[1] == 0.0f && f_lamb[2] == 0.0f && f_lamb[3] == 0.0f) {
+		SSX_STAT(18); // black surface: draws only
+		if (els && (!a.indirect_only || p.depth > 0u)) skip_light_draws(L, p.rng);
+		skip_coshemi_draws(p.rng);
+		return false;
+	}
 	// direct lighting (:182-219): sample the light; the shadow ray is parked (see ShadowQ)
 	if (els && (!a.indirect_only || p.depth > 0u)) {
 		V3 sdir; uint32_t light; float spdf;

@@ -4,6 +4,7 @@ against the oracle's unit-level functions and per-sample results -- bit for bit,
 provably reach the rare branches (tests/test_unit_cases_cpu.py holds the branch-counter proofs).
 Run with -m gpu on MI355X."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -14,6 +15,8 @@ import oracle_lib as ol
 import unit_cases as uc
 from unit_cases import unit
 from simple_spectral_amd import Options, Renderer, _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -405,3 +408,78 @@ def test_light_sampling_a_hair_from_a_light_vertex_at_the_origin():
     got = r.debug_eval(_capi.SSX_DBG_SAMPLE_LIGHT, w, 7)
     ok = same_bits_or_both_nan(got, ref, (0, 1, 2, 4))
     assert ok.all(), (np.argwhere(~ok)[:5], pts[np.argwhere(~ok)[0][0]])
+
+
+_BLACK_CHILD = r"""
+import os, sys, json, hashlib
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+from simple_spectral_amd import Options, Renderer
+out = {}
+for io, els in ((False, True), (True, True), (False, False)):
+    r = Renderer(Options(scene_name="plane-srgb", res=(24, 16), spp=12, seed=3, texture="test-img.png", indirect_only=io, explicit_light_sampling=els))
+    xyza, state, levels = r.debug_samples()
+    out["%%d%%d" %% (io, els)] = hashlib.sha256(xyza.tobytes() + state.tobytes() + levels.tobytes()).hexdigest()
+print(json.dumps(out))
+"""
+
+
+def test_black_surfaces_end_the_path_on_the_random_draws_alone():
+    """Round 6: a black Lambertian surface (plane-srgb's light box, src/scene.cpp:357-413: albedo 0) ends its path in path_step without the
+    light sampler's and the hemisphere sampler's arithmetic -- whatever they produce is multiplied by f_s = 0 -- but WITH their random
+    draws (csrc/ssx_kernels.hip).  Per sample against the oracle, which evaluates everything: XYZA bits, the final PCG32 state (= the draws
+    consumed, rejection loops included) and the levels, for plane-srgb with and without --indirect-only and without explicit light sampling
+    (the plane is a mirror then: src/scene.cpp:346-355), in RGB mode, and for a Cornell box whose floor is black and whose red wall carries
+    a texture with black texels; a light whose emission is not finite switches the shortcut off (header flag), same bits; and the
+    library with the shortcut disabled (SSX_BLACK_SHORTCUT=0) returns the same per-sample arrays."""
+    import hashlib, json, subprocess, sys
+    import custom_scene as cs
+    got = {}
+    for io, els in ((False, True), (True, True), (False, False)):
+        r = Renderer(Options(scene_name="plane-srgb", res=(24, 16), spp=12, seed=3, texture="test-img.png", indirect_only=io, explicit_light_sampling=els))
+        xyza, state, levels = r.debug_samples()
+        orc = ol.Oracle("plane-srgb", texture="test-img.png")
+        if not els:
+            orc.lib.orc_scene_set_material_kind(orc.scene, orc.lib.orc_scene_quad_material(orc.scene, 0), 1)
+        ref_xyza, ref_state, st = orc.samples(24, 16, 12, seed=3, indirect_only=io, els=els)
+        assert np.array_equal(state, ref_state) and np.array_equal(bits(xyza), bits(ref_xyza)), (io, els)
+        assert st.path_len_hist[2] == 24 * 16 * 12 or not els or io     # S = 2 always (SURVEY 8): every path's second hit is a black wall
+        got["%d%d" % (io, els)] = hashlib.sha256(xyza.tobytes() + state.tobytes() + levels.tobytes()).hexdigest()
+    # the same library with the shortcut off
+    env = dict(os.environ, SSX_DEBUG_ENV="1", SSX_BLACK_SHORTCUT="0")
+    out = subprocess.run([sys.executable, "-c", _BLACK_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1]) == got
+    # RGB mode: albedo {r, g, b, 0}
+    r = Renderer(Options(scene_name="plane-srgb", res=(16, 16), spp=6, seed=9, texture="test-img.png", render_mode="rgb"))
+    xyza, state, _ = r.debug_samples()
+    ref_xyza, ref_state, _st = ol.Oracle("plane-srgb", texture="test-img.png", rgb=True).samples(16, 16, 6, seed=9)
+    assert np.array_equal(state, ref_state) and np.array_equal(bits(xyza), bits(ref_xyza))
+    # a Cornell box with a black floor (constant albedo 0) and black texels on the textured wall: lanes of both kinds in one wave
+    c = cs.CustomScene("cornell-srgb")
+    zero = c.add_spectrum(np.zeros(8, dtype=np.float32), 400.0, 700.0)
+    black = c.add_material(kind=0, albedo_spectrum=zero)
+    pos, st_, _m = c.quads[0]
+    c.quads[0] = (pos, st_, black)
+    c.textures[0][::2, :, :] = 0                                       # every other texel row black
+    orc = c.oracle()
+    r = Renderer(Options(scene_name="cornell-srgb", res=(8, 8), spp=1, texture="test-img.png"))
+    r.upload_scene_desc(c.desc(orc))
+    r.options.res = (24, 24); r.options.spp = 8; r.options.seed = 4
+    xyza, state, _ = r.debug_samples()
+    ref_xyza, ref_state, st = orc.samples(24, 24, 8, seed=4)
+    assert np.array_equal(state, ref_state) and np.array_equal(bits(xyza), bits(ref_xyza))
+    assert st.interactions > 0
+    # an emission table that is not "finite and below 2^60": the flag is off, everything is evaluated (same bits as the oracle either way)
+    c2 = cs.CustomScene("plane-srgb")
+    li = next(i for i, m in enumerate(c2.materials) if c2.spectra[m["emission_spectrum"]][0].any())
+    data, low, high = c2.spectra[c2.materials[li]["emission_spectrum"]]
+    data = data.copy(); data[3] = np.float32(2.0 ** 61)
+    c2.spectra[c2.materials[li]["emission_spectrum"]] = (data, low, high)
+    orc2 = c2.oracle()
+    r2 = Renderer(Options(scene_name="plane-srgb", res=(8, 8), spp=1, texture="test-img.png"))
+    r2.upload_scene_desc(c2.desc(orc2))
+    r2.options.res = (16, 16); r2.options.spp = 4; r2.options.seed = 2
+    xyza, state, _ = r2.debug_samples()
+    ref_xyza, ref_state, _st = orc2.samples(16, 16, 4, seed=2)
+    assert np.array_equal(state, ref_state) and np.array_equal(bits(xyza), bits(ref_xyza))
