@@ -282,7 +282,7 @@ def pmc_passes(args):
     them, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over a short child run of this script (--pmc-child: same scene, same launches,
     prints nothing).  Corrections of that guide: both counters are KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced read
     streams (what this pipeline's reads are: calibrated on known byte counts, tools/ubench/traffic_calib) -> doubled; WRITE_SIZE as is.
-    Returns ({kernel: bytes per launch}, detail) or (None, reason)."""
+    Returns ({kernel: bytes per render}, detail) or (None, reason)."""
     import csv
     import glob
     import shutil
@@ -292,7 +292,7 @@ def pmc_passes(args):
         return None, "rocprofv3 not found"
     out_root = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else tempfile.gettempdir()
     child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--steps", "2", "--warmup", "1", "--scene", args.scene, "--res", str(args.res), "--spp", str(args.spp),
-             "--observer", str(args.observer), "--uplift", args.uplift, "--texture", args.texture, "--batch", str(args.batch)]
+             "--observer", str(args.observer), "--uplift", args.uplift, "--texture", args.texture, "--batch", str(args.batch), "--scratch-cap-gb", str(args.scratch_cap_gb)]
     env = dict(os.environ, TMPDIR="/tmp")
     got = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -304,15 +304,21 @@ def pmc_passes(args):
             if not files:
                 return None, "rocprofv3 wrote no counter file for %s" % counter
             per = {k: [] for k, _ in PMC_KERNELS}
+            renders = 0
             for row in csv.DictReader(open(files[0])):
                 if row.get("Counter_Name") != counter:
                     continue
+                if "ssx_finalize_kernel" in row.get("Kernel_Name", ""):
+                    renders += 1                                                 # one per render: a render may be several launches (batches)
                 for k, pat in PMC_KERNELS:
                     if pat in row.get("Kernel_Name", ""):
                         per[k].append(float(row["Counter_Value"]))
-            # (the child's first launches are its warm-up: same size, so every launch counts)
-            got[counter] = {k: (sum(v) / len(v) if v else None) for k, v in per.items()}
+            # per RENDER (= per step of the bench), not per launch: a render split into batches is several launches of each kernel (until
+            # round 6 the mean over launches was divided by the whole step's samples -- right for the one-launch headline, wrong for plane-srgb
+            # 1024^2 spp 1024, which runs in batches).  The child's first renders are its warm-up: same size, so every render counts.
+            got[counter] = {k: (sum(v) / renders if v and renders else (0.0 if renders and k == "generate" else None)) for k, v in per.items()}
             got[counter + "_launches"] = {k: len(v) for k, v in per.items()}
+            got[counter + "_renders"] = renders
         except Exception as e:  # a pool without counter access, a timeout: say so, the line then replays the stamped file
             return None, "%s pass failed: %s" % (counter, str(e)[:200])
         finally:
@@ -323,8 +329,8 @@ def pmc_passes(args):
         if f is None or w is None:
             return None, "no %s launches in the counter files" % k
         by_kernel[k] = int(2.0 * f * 1024 + w * 1024)
-    detail = {"FETCH_SIZE_KiB": got["FETCH_SIZE"], "WRITE_SIZE_KiB": got["WRITE_SIZE"], "fetch_correction": 2.0, "launches": got["FETCH_SIZE_launches"],
-              "bytes_per_launch": by_kernel}
+    detail = {"FETCH_SIZE_KiB": got["FETCH_SIZE"], "WRITE_SIZE_KiB": got["WRITE_SIZE"], "fetch_correction": 2.0, "launches": got["FETCH_SIZE_launches"], "renders": got["FETCH_SIZE_renders"],
+              "bytes_per_launch": by_kernel, "per": "render (= step): every launch of the kernel within one render summed"}
     return by_kernel, detail
 
 

@@ -674,7 +674,10 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	if (calibration) b.a.blob_words = ctx->blob_words;
 	// (the per-tile and per-unit words of the launch -- progress words and hand-over states of the pixel sums, camera-ray primitive
 	// masks -- live behind the sample arrays: make_batch)
-	{
+	// Kernels of the plane topology make their samples in the path loop where camera rays are traced there anyway (SsxKernelArgs::fuse_gen,
+	// ssx_kernels.hip refill): no generate kernel for such a launch.  (SSX_FUSE_GEN=0 under SSX_DEBUG_ENV=1: A/B runs and tests.)
+	b.a.fuse_gen = (!calibration && ctx->topology == 2u && !b.a.pre_hits && !(debug_env("SSX_FUSE_GEN") && debug_env("SSX_FUSE_GEN")[0] == '0')) ? 1u : 0u;
+	if (!b.a.fuse_gen) {
 		// camera rays + (where the scene pre-traces them) their closest hits: persistent workgroups striding over the record
 		// waves; they stage the whole blob -- the trace is the generic one, restricted per tile to the primitives its frustum
 		// can contain (ssx_tile_mask_kernel, a few microseconds)

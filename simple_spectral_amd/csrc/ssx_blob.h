@@ -46,6 +46,13 @@ struct SsxBlobSpectrum { // 4 words
 
 // Everything shading needs about a quad in ONE record (its material's fields are copied in, so a
 // hit costs one dependent LDS round trip before the spectrum data instead of three).
+// Record stride and LDS banks (profiles/r06/NOTES.md section 4): a lane reads the record of ITS hit quad, so the lanes of a group read the same field of
+// different records; a dword read is banked (address / 4) mod 32, and with a stride of 40 words the records q and q + 4 share their banks -- the
+// ~10 distinct quads a 32-lane group holds fall into 4 bank classes (2-3 way conflicts on every field).  The records must stay 16-byte aligned
+// (their table descriptors are read as 16 bytes), so the stride is a multiple of 4 words and the best period is 8 (stride 4 mod 8 words: 36, 44).
+#ifndef SSX_QUAD_PAD_WORDS
+#define SSX_QUAD_PAD_WORDS 0
+#endif
 struct SsxBlobQuad {   // 40 words (160 B): 16-byte aligned, stride 40 mod 32 = 8 banks
 	float pos[4][3];   // v00, v10, v11, v01 (light sampling needs the unpermuted positions)
 	float st[4][2];
@@ -57,9 +64,9 @@ struct SsxBlobQuad {   // 40 words (160 B): 16-byte aligned, stride 40 mod 32 = 
 	SsxBlobSpectrum albedo;
 	SsxBlobSpectrum emission;
 	uint32_t is_tri;      // the primitive is a PrimTri of v00, v10, v11 (SSX_PRIM_TRI): no second triangle, sampled as a triangle
-	uint32_t pad;
+	uint32_t pad[1 + SSX_QUAD_PAD_WORDS];
 };
-static_assert(sizeof(SsxBlobQuad) == 160, "layout");
+static_assert(sizeof(SsxBlobQuad) == 160 + 4 * SSX_QUAD_PAD_WORDS && sizeof(SsxBlobQuad) % 16 == 0, "layout");
 
 struct SsxBlobHeader {
 	double pv_inv[16];
@@ -194,4 +201,6 @@ struct SsxKernelArgs {
 	uint32_t pre_hits;        // 1: ssx_generate_kernel* traces the camera rays (hit[] valid, the path loop starts every sample at its first
 	                          // hit); 0: camera rays are traced in the path loop like any other ray (scenes whose rays rarely leave the scene)
 	uint32_t queue_words;     // words per entry of the shadow-ray queues: SSX_QUEUE_WORDS_WIDE or _NARROW (see above)
+	uint32_t fuse_gen;        // 1 (only with pre_hits == 0, kernels of the plane topology): no ssx_generate_kernel ran -- the path kernel's refill makes a sample's
+	                          // stream, camera ray and lambda_0 where it hands the sample to a lane (generate_sample), and ray[] / st[] are not read there
 };

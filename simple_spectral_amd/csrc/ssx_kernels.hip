@@ -939,7 +939,8 @@ __device__ __forceinline__ uint32_t log_append(const LogRef& lg, uint32_t which)
 // ssx_generate_kernel with every lane busy; the record carries the stream on to the path kernel.
 // renderer.cpp:114-131 up to the normalisation: the (unnormalised, binary64) direction from the camera through the image point
 // (x, y) in pixel units
-__device__ __forceinline__ void camera_dir(const SsxBlobHeader& h, const SsxKernelArgs& a, double x, double y, double& dx, double& dy, double& dz) {
+template <typename Args>
+__device__ __forceinline__ void camera_dir(const SsxBlobHeader& h, const Args& a, double x, double y, double& dx, double& dy, double& dz) {
 	// (i + subpixel) / res: for a power-of-two image size the division is exact, and so is the multiplication by the exact
 	// reciprocal -- the same binary64 in 2 instead of ~28 instructions (every BASELINE configuration; wave-uniform test)
 	const bool pow2 = ((a.width & (a.width - 1u)) | (a.height & (a.height - 1u))) == 0u;
@@ -955,7 +956,8 @@ __device__ __forceinline__ void camera_dir(const SsxBlobHeader& h, const SsxKern
 	double px = q[0] / w, py = q[1] / w, pz = q[2] / w;
 	dx = px - (double)h.cam_pos[0]; dy = py - (double)h.cam_pos[1]; dz = pz - (double)h.cam_pos[2];
 }
-__device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const SsxKernelArgs& a, uint32_t i, uint32_t j, uint32_t k, float4& ray, uint4& st) {
+template <typename Args>
+__device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const Args& a, uint32_t i, uint32_t j, uint32_t k, float4& ray, uint4& st) {
 	const uint64_t pixel = (uint64_t)j * (uint64_t)a.width + (uint64_t)i;
 	const uint64_t pa = mix64(a.seed + 0x9E3779B97F4A7C15ull * (pixel + 1ull));
 	const uint64_t b = mix64(pa + 0x9E3779B97F4A7C15ull * ((uint64_t)k + 1ull));
@@ -1474,6 +1476,7 @@ extern "C" __global__ void __launch_bounds__(256) ssx_tile_mask_kernel(SsxKernel
 struct WorkUnit { // wave-uniform description of one work unit: 8x8 tile x a group of consecutive samples (four SGPRs: a wave holds two)
 	uint32_t slot, grp;     // tile slot (index into the device's tiles) and group of consecutive samples: the unit's first sample is k0 + grp * group_spp
 	uint32_t tile;          // the tile's index in the image's row-major tile list (its block of the pixel sums)
+	uint32_t txy;           // its column | row << 16 (fused sample generation: the refill needs the pixel coordinates)
 	uint32_t dims;          // tile width | tile height << 4 | samples per pixel << 8
 	__device__ __forceinline__ uint32_t tw() const { return dims & 15u; }
 	__device__ __forceinline__ uint32_t th() const { return (dims >> 4) & 15u; }
@@ -1494,7 +1497,7 @@ __device__ __forceinline__ void unit_setup(const SsxKernelArgs& hot, uint32_t un
 	const uint32_t kb = min(ka + a.group_spp, a.k1);
 	u.dims = min(8u, a.width - tx * 8u) | (min(8u, a.height - ty * 8u) << 4) | ((kb - ka) << 8);
 	u.slot = slot; u.grp = grp;
-	u.tile = tile;
+	u.tile = tile; u.txy = tx | (ty << 16);
 }
 // Every lane folds the records of its own pixel of a finished unit.  The loads (levels and records
 // this wave wrote during the unit) overlap with the arithmetic of the other waves on the SIMD, which
@@ -1641,6 +1644,7 @@ __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, 
 // CALIB: the calibration render of ssx_upload_scene (ssx_calibrate_kernel) also counts the rays that leave the scene
 template <int TOPO, bool NARROW, bool CALIB = false>
 __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
+	constexpr bool FUSE_GEN = TOPO == 2; // the kernels that can make their samples themselves (SsxKernelArgs::fuse_gen): the plane topology's, whose scenes trace camera rays in the path loop
 	uint32_t* const lds_words = stage_lds(a);
 	Lds L; L.w = lds_words;
 
@@ -1697,13 +1701,27 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		if (!active) {
 			const uint32_t item = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
 			if (item < n_items) {
+				SSX_STAT(19); // refill: lanes taking a sample (entries = wave-level executions of this body)
 				uint32_t in_tile, kq;
 				const uint32_t npx = cur.npx(), tw = cur.tw();
 				if (npx == 64u) { in_tile = item & 63u; kq = item >> 6; }              // full tile (wave-uniform branch)
 				else { const uint32_t r = item % npx; kq = item / npx; in_tile = (r / tw) * 8u + r % tw; }
 				p.rec_index = cur.rec_base(a) + kq * 64u + in_tile;
-				const float4 ray = a.ray[p.rec_index];
-				const uint4 st = a.st[p.rec_index];
+				float4 ray; uint4 st;
+				if (FUSE_GEN && a.fuse_gen) {
+					// No generate kernel ran (plane topology, camera rays traced in the path loop): the sample's stream, camera ray and
+					// lambda_0 are made here -- the same function on the same (pixel, k), so the same record the kernel would have written
+					// and this load would have read; 64 B of HBM traffic per sample less and a launch less.  In plane-srgb every path has
+					// two interactions, so all 64 lanes of a wave refill together: the binary64 camera arithmetic runs at full occupancy.
+					// (the arguments it needs -- seed, image size, first sample -- from the kernarg segment where they are used: held in SGPRs
+					// across the loop they cost the shading code 13 spilled SGPRs and, through those, 9 spilled VGPRs)
+					const __attribute__((address_space(4))) SsxKernelArgs& c = cold_args();
+					generate_sample(L.hdr(), c, (cur.txy & 0xFFFFu) * 8u + (in_tile & 7u), (cur.txy >> 16) * 8u + (in_tile >> 3), c.k0 + cur.grp * c.group_spp + kq, ray, st);
+					if (c.no_flat_field) c.ray[p.rec_index] = ray; // (the fold of that mode reads the camera ray's direction back)
+				} else {
+					ray = a.ray[p.rec_index];
+					st = a.st[p.rec_index];
+				}
 				p.dir = mk(ray.x, ray.y, ray.z);
 				p.lambda_0 = ray.w;
 				p.rng.state = ((uint64_t)st.y << 32) | st.x;

@@ -45,8 +45,13 @@ def test_bench_two_ranks_json_line_and_image(tmp_path, launcher, world):
     assert d["evidence_error"] is None
     assert d["backend"] == "gloo" and d["world_size"] == world and d["overlap"]["pixels_nonzero_on_more_than_one_rank"] == 0 and d["overlap"]["pixels_nonzero_on_some_rank"] > 0
     assert d["devices_distinct"] is False            # both ranks on device 0 here (SSX_BENCH_TEST_ONE_GPU): the driver's 8-GPU run must say True, or bench.py refuses
+    # the efficiency field divides only by an N = 1 figure taken on THIS build's kernel sources; anything else in the tree is refused by name
     e = line["efficiency_vs_n1_reference"]
-    assert e["n1_value"] > 0 and abs(e["value"] - line["value"] / (world * e["n1_value"])) < 1e-3 and "BENCH_r" in e["n1_source"]
+    if e["n1_value"] is None:
+        assert e["value"] is None and "no N = 1 figure taken on this build's kernel sources" in e["refused"]
+    else:
+        assert abs(e["value"] - line["value"] / (world * e["n1_value"])) < 1e-3 and e["kernel_source_id"] == line["config"]["kernel_source_id"]
+    assert all(x["device_scratch_total"] > 0 and x["device_scratch_bytes"]["log_bytes"] > 0 for x in line["ranks"])
     assert "REPLAYED" in (line["roofline"]["traffic_source"] or "REPLAYED") or line["roofline"]["traffic"] is None
     img = np.load(dump)
     ref = ol.Oracle("cornell-srgb", texture="test-img.png").render(64, 64, 4 * world)   # total spp = 4 per GPU x world
@@ -108,7 +113,7 @@ def test_bench_measures_its_hbm_traffic_in_the_run(tmp_path):
     env = dict(os.environ, SSX_BENCH_TRAFFIC_JSON=tj)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SSX_BENCH_TEST_ONE_GPU", "SSX_BENCH_FORCE_DIST", "SSX_BENCH_NO_PMC"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--res", "256", "--spp", "32", "--no-cpu-baseline"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--res", "256", "--spp", "32", "--no-cpu-baseline", "--update-traffic"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
@@ -120,6 +125,36 @@ def test_bench_measures_its_hbm_traffic_in_the_run(tmp_path):
     per_sample = rf["traffic"] / samples
     assert 300.0 < per_sample < 900.0, per_sample                 # the design's own bytes are ~425 B per sample: counters within 2x of them
     d = rf["traffic_detail"]
-    assert d["bytes_per_launch"]["generate"] > 48 * samples * 0.8 and d["launches"]["path"] >= 3 and d["kernel_source_id"]
+    assert d["bytes_per_launch"]["generate"] > 48 * samples * 0.8 and d["launches"]["path"] >= 3 and d["renders"] == d["launches"]["path"] and d["kernel_source_id"]
     assert json.load(open(tj))["cornell-srgb 256 spp32 obs1931 gpus1"] == rf["traffic"]
     assert line["check"]["differing_floats"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2])
+def test_bench_dry_run_reports_the_multi_gpu_plumbing(world):
+    """`bench.py --dist-dry-run` goes through the process group, a timed framebuffer reduce, every rank's share of the
+    workload at 1/16 of the samples and the C++ host's RCCL combine as a probe (ssx_rccl_probe: ncclCommInitAll over the visible devices), and
+    REPORTS what it found in one JSON line -- here on one GPU (world 2: both ranks on device 0, gloo)."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SSX_BENCH_TEST_ONE_GPU", "SSX_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world == 1:
+        env["SSX_BENCH_FORCE_DIST"] = "1"      # RCCL with world size 1
+    else:
+        env["SSX_BENCH_TEST_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--dist-dry-run", "--res", "128", "--spp", "32", "--texture", "test-img.png"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == world and len(d["ranks"]) == world
+    assert d["collectives"]["all_reduce_ones"] == float(world) and len(d["collectives"]["framebuffer_reduce_ms"]) == 3
+    for x in d["ranks"]:
+        assert "device_error" not in x and "render_error" not in x, x
+        assert x["free_bytes"] > 0 and x["share_pixels_nonzero"] == 128 * 128 // world and x["share_render_ms"] > 0
+        assert x["sample_bytes_needed"] > 0 and x["scratch_after_upload"]["log_bytes"] > 0
+    p = d["rccl_probe_single_process"]
+    assert p["visible_devices"] >= 1 and p["returned"] == p["devices_reduced_ok"] == p["visible_devices"] and p["rccl"] == "ok" and p["reduce_elements_wrong"] == 0

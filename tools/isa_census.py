@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.environ.get("SSX_CENSUS_SRC") or os.path.join(ROOT, "simple_spectral_amd", "csrc", "ssx_kernels.hip")   # (another revision's source: a worktree)
 LLVM = "/opt/rocm/lib/llvm/bin"
 RARE = 0.002  # weight of code behind a branch that the counters do not see and the design calls rare
+UNIT_PASSES = 2.0  # fold passes per work unit: 2 for units of four samples per pixel (Cornell), 4 for units of eight (plane-srgb): --unit-passes
 
 
 # ------------------------------------------------------------------------------------------------ disassembly
@@ -203,24 +204,26 @@ def region_of(chain, R):
             return "cold (rare fallbacks / other uplifts / modes)", "rare"
         if has(chain, "sphtri_make"):
             if has(chain, "ssx_acos_sin_lds", "ssx_acosf_lds", "ssx_fm_asin_poly"):
-                return "light: sphtri_make acos/sin (binary64)", "iter"
-            return "light: sphtri_make f32 part", "iter"
+                return "light: sphtri_make acos/sin (binary64)", "light"
+            return "light: sphtri_make f32 part", "light"
         if has(chain, "rand_toward_sphericaltri"):
             if has(chain, "ssx_sincosf", "ssx_fm_reduce", "ssx_fm_ksin", "ssx_fm_kcos"):
-                return "light: Arvo sincos (binary64)", "iter"
-            return "light: Arvo f32 part", "iter"
+                return "light: Arvo sincos (binary64)", "light"
+            return "light: Arvo f32 part", "light"
+        if has(chain, "skip_light_draws", "skip_coshemi_draws"):
+            return "black surface: the samplers' draws only", "black"
         if has(chain, "sample_light"):
-            return "light: pick, normalize x3, pdf", "iter"
+            return "light: pick, normalize x3, pdf", "light"
         if has(chain, "material_albedo"):
             if has(chain, "texel_lrgb", "hero_gather3"):
                 return "albedo: textured branch", "albedo_tex"
             return "albedo: index + constant gather", "iter"
         if has(chain, "rand_coshemi"):
             if has(chain, "ssx_sincosf", "ssx_fm_reduce", "ssx_fm_ksin", "ssx_fm_kcos"):
-                return "bsdf: coshemi sincos (binary64)", "iter"
-            return "bsdf: coshemi f32 part", "iter"
+                return "bsdf: coshemi sincos (binary64)", "bsdf"
+            return "bsdf: coshemi f32 part", "bsdf"
         if has(chain, "get_rotated_to"):
-            return "bsdf: get_rotated_to", "iter"
+            return "bsdf: get_rotated_to", "bsdf"
         if within("path_step", "emission"):
             return "emission lookup (camera hit on a light)", "emission"
         if within("path_step", "nee_contrib"):
@@ -231,7 +234,9 @@ def region_of(chain, R):
             return "log level entry", "cont"
         return "path_step: rest (normal, f_lamb, continue test)", "iter"
     # render_body itself
-    for name, key in (("refill", "iter"), ("end_path", "iter"), ("flush_fold", "iter")):
+    if has(chain, "generate_sample", "camera_dir"):
+        return "loop: refill: sample made in the loop (fused generation)", "refill"
+    for name, key in (("refill", "refill"), ("end_path", "iter"), ("flush_fold", "iter")):
         if within("render_body", name) or has(chain, "operator()") and within("operator()", name):
             return "loop: " + name, key
     if within("render_body", "unit_fetch") or (has(chain, "operator()") and within("operator()", "unit_fetch")) or has(chain, "unit_setup", "tile_of_slot"):
@@ -259,26 +264,33 @@ def weights(lanestat_path):
     it = ent["iteration: lanes with a path"]
     ways = 2.0  # SSX_RESOLVE_WAYS: the counter sits inside the unrolled way loop
     passes = ent["flux -> XYZ"] / ways
+    e = lambda name, default=0.0: ent.get(name, default)   # (a scene without the region -- plane-srgb has no emission lookup, no camera pre-trace -- has no line)
     w = {
         "iter": 1.0, "once": 0.0, "rare": RARE,
-        "trace_primary": ent["primary trace: lanes with a ray"] / it,
-        "pass2_primary": ent["primary pass-2 trips"] / it,
-        "trace_shadow": ent["shadow trace: lanes with a ray"] / it,
-        "pass2_shadow": ent["shadow pass-2 trips"] / it,
-        "albedo_tex": ent["albedo: texture"] / it,
-        "emission": ent["emission lookup"] / it,
-        "nee": ent["NEE contribution"] / it,
-        "cont": ent["continue (store fs/np)"] / it,
-        "fold_level": ent["fold level x way"] / ways / it,
+        "trace_primary": e("primary trace: lanes with a ray") / it,
+        "pass2_primary": e("primary pass-2 trips") / it,
+        "trace_shadow": e("shadow trace: lanes with a ray") / it,
+        "pass2_shadow": e("shadow pass-2 trips") / it,
+        "albedo_tex": e("albedo: texture") / it,
+        "emission": e("emission lookup") / it,
+        "light": e("light sampling", it) / it,
+        "bsdf": e("BSDF sample", it) / it,
+        "black": e("black surface: draws only") / it,
+        "refill": e("refill: lanes taking a sample", it) / it,     # wave-level executions of the refill's body (round 6's counter; before: once per iteration)
+        "nee": e("NEE contribution") / it,
+        "cont": e("continue (store fs/np)") / it,
+        "fold_level": e("fold level x way") / ways / it,
         "fold_pass": passes / it,
-        "unit": passes / 2.0 / it,      # a unit of four samples per pixel is two passes (cohorts of two)
-        "parked": 0.05 * passes / 2.0 / it,
+        "unit": passes / UNIT_PASSES / it,      # a unit of four (eight) samples per pixel is two (four) passes (cohorts of two)
+        "parked": 0.05 * passes / UNIT_PASSES / it,
     }
+    l = lambda name: lanes.get(name, 64.0)
     occ = {
-        "iter": lanes["iteration: lanes with a path"], "trace_primary": lanes["primary trace: lanes with a ray"],
-        "pass2_primary": lanes["primary pass-2 trips"], "trace_shadow": lanes["shadow trace: lanes with a ray"],
-        "pass2_shadow": lanes["shadow pass-2 trips"], "albedo_tex": lanes["albedo: texture"], "emission": lanes["emission lookup"],
-        "nee": lanes["NEE contribution"], "cont": lanes["continue (store fs/np)"], "fold_level": lanes["fold level x way"],
+        "iter": l("iteration: lanes with a path"), "trace_primary": l("primary trace: lanes with a ray"),
+        "pass2_primary": l("primary pass-2 trips"), "trace_shadow": l("shadow trace: lanes with a ray"),
+        "pass2_shadow": l("shadow pass-2 trips"), "albedo_tex": l("albedo: texture"), "emission": l("emission lookup"),
+        "light": l("light sampling"), "bsdf": l("BSDF sample"), "black": l("black surface: draws only"), "refill": l("refill: lanes taking a sample"),
+        "nee": l("NEE contribution"), "cont": l("continue (store fs/np)"), "fold_level": l("fold level x way"),
         "fold_pass": 64.0, "unit": 64.0, "parked": 64.0, "rare": 1.0, "once": 64.0,
     }
     return w, occ, it
@@ -366,13 +378,16 @@ def main():
     ap.add_argument("--clock-mhz", type=float, default=2400.0)
     ap.add_argument("-D", action="append", default=[])
     ap.add_argument("--obj", default="", help="reuse / keep the object here")
+    ap.add_argument("--unit-passes", type=float, default=2.0, help="fold passes per work unit (2: units of four samples per pixel; 4: of eight, plane-srgb)")
     args = ap.parse_args()
+    global UNIT_PASSES
+    UNIT_PASSES = args.unit_passes
 
     R = source_ranges()
     with tempfile.TemporaryDirectory() as td:
         obj = args.obj or os.path.join(td, "k.o")
         if not (args.obj and os.path.exists(obj)):
-            build_object(["SSX_PROBE_BUILD"] + args.D, obj)
+            build_object(([] if ("plane" in args.kernel or args.kernel.endswith("_nq")) else ["SSX_PROBE_BUILD"]) + args.D, obj)   # (the probe build holds the generic and the Cornell kernel only)
         ins = disassemble(obj, args.kernel)
         chains = inline_chains(obj, [a for a, _, _ in ins])
     rates = load_rates(args.rates)

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 NAMES = {0: "primary trace: lanes with a ray", 1: "primary pass-2 trips", 2: "shadow trace: lanes with a ray", 3: "shadow pass-2 trips", 4: "path_step: lanes shading a hit",
          5: "emission lookup", 6: "albedo: texture", 7: "albedo: constant", 8: "light sampling", 9: "NEE contribution", 10: "shadow ray parked",
-         11: "BSDF sample", 12: "continue (store fs/np)", 13: "iteration: lanes with a path", 14: "fold level x way", 15: "flux -> XYZ", 16: "camera trace: lanes with a ray", 17: "camera pass-2 trips", 18: "black surface: draws only"}
+         11: "BSDF sample", 12: "continue (store fs/np)", 13: "iteration: lanes with a path", 14: "fold level x way", 15: "flux -> XYZ", 16: "camera trace: lanes with a ray", 17: "camera pass-2 trips", 18: "black surface: draws only", 19: "refill: lanes taking a sample"}
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="cornell-srgb"); ap.add_argument("--res", type=int, default=512); ap.add_argument("--spp", type=int, default=64)
 args = ap.parse_args()
