@@ -154,7 +154,7 @@ def test_bench_dry_run_reports_the_multi_gpu_plumbing(world):
     assert d["collectives"]["all_reduce_ones"] == float(world) and len(d["collectives"]["framebuffer_reduce_ms"]) == 3
     for x in d["ranks"]:
         assert "device_error" not in x and "render_error" not in x, x
-        assert x["free_bytes"] > 0 and x["share_pixels_nonzero"] == 128 * 128 // world and x["share_render_ms"] > 0
+        assert x["free_bytes"] > 0 and 0 < x["share_pixels_nonzero"] <= 128 * 128 // world and x["share_render_ms"] > 0   # (alpha is 0 where a camera ray leaves the open box)
         assert x["sample_bytes_needed"] > 0 and x["scratch_after_upload"]["log_bytes"] > 0
     p = d["rccl_probe_single_process"]
     assert p["visible_devices"] >= 1 and p["returned"] == p["devices_reduced_ok"] == p["visible_devices"] and p["rccl"] == "ok" and p["reduce_elements_wrong"] == 0

@@ -2,8 +2,8 @@
 # Round 6, third GPU call: parity with the fused sample generation, its A/B on plane-srgb, the quad-record stride ablation (LDS bank conflicts),
 # the headline render in four launches (device scratch below 2 GB)
 O=gpurun_out/r06; mkdir -p $O
-export SSX_DEBUG_ENV=1
 python -m pytest tests -m gpu -q > $O/pytest_gpu_2.log 2>&1; echo "pytest rc=$?"; grep -E "^FAILED|^ERROR| passed| failed" $O/pytest_gpu_2.log | cut -c1-300
+export SSX_DEBUG_ENV=1
 P='import json,sys; d=json.loads(sys.stdin.read()); print(sys.argv[1], d["value"], d["ms_per_step"], d["roofline"]["stage_ms"], d["ranks"][0]["device_scratch_bytes"])'
 for round in 1 2 3; do
 	for SW in 1 0; do
