@@ -676,7 +676,20 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	// masks -- live behind the sample arrays: make_batch)
 	// Kernels of the plane topology make their samples in the path loop where camera rays are traced there anyway (SsxKernelArgs::fuse_gen,
 	// ssx_kernels.hip refill): no generate kernel for such a launch.  (SSX_FUSE_GEN=0 under SSX_DEBUG_ENV=1: A/B runs and tests.)
-	b.a.fuse_gen = (!calibration && ctx->topology == 2u && !b.a.pre_hits && !(debug_env("SSX_FUSE_GEN") && debug_env("SSX_FUSE_GEN")[0] == '0')) ? 1u : 0u;
+	// Kernels of the Cornell topology do the same per WORK UNIT where camera rays are traced ahead of the path loop (pre_hits): the wave that
+	// fetches a unit makes its samples and traces their camera rays with all 64 lanes, then runs them (generate_unit) -- only the tile masks
+	// are computed ahead.  Only in builds with -DSSX_FUSE_UNIT, and there only with SSX_FUSE_GEN=1: measured, not kept (profiles/r06/NOTES.md section 3).
+	const char* fuse_env = debug_env("SSX_FUSE_GEN");
+	b.a.fuse_gen = (!calibration && ctx->topology == 2u && !b.a.pre_hits && !(fuse_env && fuse_env[0] == '0')) ? 1u : 0u;
+#ifdef SSX_FUSE_UNIT
+	if (!calibration && ctx->topology == 1u && b.a.pre_hits && fuse_env && fuse_env[0] == '1') b.a.fuse_gen = 1u;
+#endif
+	if (b.a.fuse_gen && b.a.pre_hits) {
+		SsxKernelArgs ga = b.a;
+		ga.blob_words = ctx->blob_words;
+		hipLaunchKernelGGL(ssx_tile_mask_kernel, dim3((ga.my_tiles + 3u) / 4u), dim3(256), 0, stream, ga);
+		SSX_HIP(ctx, hipGetLastError());
+	}
 	if (!b.a.fuse_gen) {
 		// camera rays + (where the scene pre-traces them) their closest hits: persistent workgroups striding over the record
 		// waves; they stage the whole blob -- the trace is the generic one, restricted per tile to the primitives its frustum
@@ -1104,11 +1117,11 @@ int ssx_upload_scene(ssx_ctx* ctx, const ssx_scene_desc* s) {
 		SsxBlobHeader* bh = reinterpret_cast<SsxBlobHeader*>(blob.data());
 		ctx->topology = bh->topology;
 		ctx->path_blob_words = (bh->topology || bh->perm_hbm) ? bh->words_without_perm : ctx->blob_words;
-		if (bh->perm_hbm) { // the permuted vertex table is read from this copy: tell the kernels where it is, and stage only what precedes it
+		if (bh->perm_hbm || bh->topology) { // the permuted vertex table is read from this copy (large scenes; the camera rays a Cornell-topology kernel traces for its own units): tell the kernels where it is
 			const uint64_t at = (uint64_t)(uintptr_t)(ctx->d_blob + bh->off_perm);
 			bh->perm_ptr_lo = (uint32_t)at; bh->perm_ptr_hi = (uint32_t)(at >> 32);
 			SSX_HIP(ctx, hipMemcpy(ctx->d_blob, blob.data(), sizeof(SsxBlobHeader), hipMemcpyHostToDevice));
-			ctx->blob_words = bh->words_without_perm;
+			if (bh->perm_hbm) ctx->blob_words = bh->words_without_perm; // ... and stage only what precedes it
 		}
 	}
 	ctx->have_cam_dir = have_cam_dir;

@@ -525,7 +525,9 @@ namespace {
 // vertices up in the distinct-vertex table.  Same floats, same candidates, same hits either way.
 // quad_mask (TOPO 0 only): wave-uniform bit per primitive, or nullptr; primitives whose bit is clear are known not to be
 // hit by any ray of the wave (ssx_tile_mask_kernel: the camera rays of a pixel tile) and are left out of pass 1.
-template <int TOPO>
+// PERM_FROM_HBM (TOPO 0): the per-quad vertex table is read from the blob's copy in HBM whatever the header says -- the generic trace inside a
+// topology-specialised kernel, which does not stage that table (generate_unit).
+template <int TOPO, bool PERM_FROM_HBM = false>
 __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_quad, bool has_ray, HitInfo& hit, int stat_base = 0, const uint32_t* quad_mask = nullptr, SsxTimer* tm = nullptr) {
 	const RaySetup rs = ray_setup(orig, dir);
 	const SsxBlobHeader& hd = L.hdr();
@@ -535,7 +537,7 @@ __device__ __forceinline__ void trace(const Lds& L, V3 orig, V3 dir, int ignore_
 	hit.U = hit.V = hit.W = hit.det_recip = 0.0f;
 	SSX_STAT(stat_base); // lanes holding a ray (of the lanes that called)
 	// Large scenes (generic kernel): the permuted vertex table stays in HBM when it does not fit into LDS (wave-uniform)
-	const bool perm_hbm = TOPO == 0 && hd.perm_hbm != 0u;
+	const bool perm_hbm = TOPO == 0 && (PERM_FROM_HBM || hd.perm_hbm != 0u);
 	const float* const gperm = reinterpret_cast<const float*>(((uint64_t)hd.perm_ptr_hi << 32) | (uint64_t)hd.perm_ptr_lo);
 	// "Mixed" flag of a triangle = sign bit of fma(min3, max3, +0): negative iff min < 0 < max strictly (a zero
 	// edge value gives -0 + +0 = +0, an underflowing product keeps its sign) -- one v_fma instead of two
@@ -1641,10 +1643,54 @@ __device__ __forceinline__ void unit_fold(const Lds& L, const SsxKernelArgs& a, 
 	}
 }
 
+// What ssx_generate_kernel does for the 64 x n_kq samples of ONE work unit, done by the wave that has just fetched the unit (kernels of the
+// Cornell topology with SsxKernelArgs::fuse_gen, scenes whose camera rays are traced ahead of the path loop): lane = pixel of the tile, one
+// round per sample of the pixel -- stream, camera ray, lambda_0 (generate_sample), the camera ray's closest hit by the generic trace over
+// the primitives of the tile's frustum (ssx_tile_mask_kernel; the vertex table from HBM, this kernel does not stage it), and the same three
+// records the generate kernel writes.  The refill reads them back (its acquire pairs with the release here: other lanes take the samples).
+// Why: the generate kernel's binary64 / 64-bit integer instruction stream runs at ~4.4 cycles per instruction on its own; inside the path
+// kernel it overlaps with the other waves' f32 work (plane-srgb, where the refill makes the samples: 10.0 ms of generate kernel became
+// 3.3 ms of path kernel, profiles/r06/NOTES.md).
+__device__ __forceinline__ void generate_unit(const Lds& L, const WorkUnit& u, uint32_t lane, V3 cam, uint32_t* cnt) {
+	const __attribute__((address_space(4))) SsxKernelArgs& c = cold_args();
+	const SsxBlobHeader& h = L.hdr();
+	const uint32_t i = (u.txy & 0xFFFFu) * 8u + (lane & 7u), j = (u.txy >> 16) * 8u + (lane >> 3);
+	const bool inside = (lane & 7u) < u.tw() && (lane >> 3) < u.th(); // lanes outside a ragged tile have no record
+	const uint32_t rec0 = (u.slot * (c.k1 - c.k0) + u.grp * c.group_spp) * 64u + lane, k_first = c.k0 + u.grp * c.group_spp;
+	for (uint32_t kq = 0, n_kq = u.n_kq(); kq < n_kq; ++kq) {
+		float4 ray = make_float4(0.0f, 0.0f, 1.0f, 0.0f); uint4 st = make_uint4(0u, 0u, 0u, 0u);
+		if (inside) generate_sample(h, c, i, j, k_first + kq, ray, st);
+		HitInfo hit;
+		trace<0, true>(L, cam, mk(ray.x, ray.y, ray.z), -1, inside, hit, 16, c.tile_mask + 4u * u.slot);
+		if (inside) {
+			float st_x = 0.0f, st_y = 0.0f;
+			if (hit.tri >= 0) {
+				const SsxBlobQuad& Q = L.quad((uint32_t)hit.tri >> 1);
+				if (Q.albedo_mode != 0u) hit_st(Q, (uint32_t)hit.tri & 1u, hit, st_x, st_y);
+			} else {
+				st = make_uint4(__float_as_uint(ray.w), (SSX_NO_SLOT << 6) | (SSX_NO_SLOT << 19), st.x, st.y); // a path that ends at level 0 without a hit (generate_body)
+			}
+			const uint32_t r = rec0 + kq * 64u;
+			c.ray[r] = ray; c.st[r] = st;
+			c.hit[r] = make_float4(hit.dist, st_x, st_y, __int_as_float(hit.tri));
+		}
+	}
+	wave_release(cnt);
+}
+
 // CALIB: the calibration render of ssx_upload_scene (ssx_calibrate_kernel) also counts the rays that leave the scene
 template <int TOPO, bool NARROW, bool CALIB = false>
 __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	constexpr bool FUSE_GEN = TOPO == 2; // the kernels that can make their samples themselves (SsxKernelArgs::fuse_gen): the plane topology's, whose scenes trace camera rays in the path loop
+	// ... and, in builds with -DSSX_FUSE_UNIT only, the Cornell topology's, per work unit (generate_unit), where camera rays are traced ahead of the
+	// loop.  Built, bit-exact on the whole parity suites, and NOT kept: +0.3 ... +1.0 % per step on one box (path kernel +0.95 ms for the 1.10 ms of
+	// generate kernel it replaces, HBM traffic unchanged: profiles/r06/ab_fuse_unit_cornell.log), below the 1.5 % the attempt was given beforehand
+	// (profiles/r06/NOTES.md section 3) -- and it costs the kernel 5 KB of code and 6 spilled SGPRs whether used or not.
+#ifdef SSX_FUSE_UNIT
+	constexpr bool FUSE_UNIT = TOPO == 1;
+#else
+	constexpr bool FUSE_UNIT = false;
+#endif
 	uint32_t* const lds_words = stage_lds(a);
 	Lds L; L.w = lds_words;
 
@@ -1698,6 +1744,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		const uint32_t n_items = cur.n_items();
 		if (!(cur_valid && next_item < n_items)) return;
 		const uint64_t idle = __ballot(!active);
+		if (FUSE_UNIT && a.fuse_gen) wave_acquire(log_cnt); // the records were stored by this wave's lanes in generate_unit: any lane may take any of them
 		if (!active) {
 			const uint32_t item = next_item + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
 			if (item < n_items) {
@@ -1774,6 +1821,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
 			if (u < c.my_tiles * c.n_groups) {
 				unit_setup(a, u, cur); cur_tag ^= 1u; next_item = 0; cur_valid = true;
+				if (FUSE_UNIT && a.fuse_gen) generate_unit(L, cur, lane, cam, log_cnt);
 				if (lane < 2u * SSX_UNIT_COHORTS) log_cnt[2u * SSX_UNIT_COHORTS * cur_tag + lane] = 0u; // the logs of its cohorts are empty (the last unit with this tag has been folded)
 			}
 			else more = false;

@@ -27,7 +27,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "simple_spectral_amd", "csrc", "ssx_pass1_gen.h")
 
-TOPOLOGIES = [("cornell", 1, "cornell"), ("plane", 2, "plane-srgb")]  # (name, id, host scene that has it)
+# (name, id, host scene that has it, cull triangles behind the ray's origin in pass 1)
+# The cull (plane topology only): a triangle whose three scaled depths Sz * (v - o)[kz] -- the reference's ABCz (src/geometry.cpp:75) -- are all
+# <= 0 has T = U*Az + V*Bz + W*Cz of the sign opposite to det = U + V + W (the edge values of a candidate share a sign), or T = +-0: the reference
+# rejects it at the sign test (:80-83) or at dist >= EPS (:88), it never becomes the hit and never stands in for its quad's other triangle.  Such a
+# triangle need not be a candidate: its flag is ORed with the sign bit of max3(Sz*zA, Sz*zB, Sz*zC) (set iff all three are < 0 or -0; a NaN ray
+# hits nothing either way).  Costs a multiply per vertex and two instructions per triangle in pass 1 (all lanes busy) and saves a pass-2 trip
+# per trace in plane-srgb, where every line through the box meets a wall behind its origin (camera rays 3 -> 2 candidates, bounce rays 2 -> 1).
+# In the Cornell box the candidates behind the origin are too few for the 104 instructions the test would add to its pass 1.
+TOPOLOGIES = [("cornell", 1, "cornell", False), ("plane", 2, "plane-srgb", True)]
 
 
 def scene_vids(scene_name):
@@ -85,7 +93,7 @@ def E(u, v):
     return "e%d_%d" % (u, v) if u < v else "-e%d_%d" % (v, u)
 
 
-def emit_topology(name, vids):
+def emit_topology(name, vids, cull_behind=False):
     nq = len(vids)
     lines = []
     lines.append("// topology \"%s\": %d quads, %d distinct vertices of %d corners" % (name, nq, 1 + max(max(r) for r in vids), 4 * nq))
@@ -99,6 +107,8 @@ def emit_topology(name, vids):
         for k in verts:
             lines.append("\t\tconst float z%d = vz[%d] - rs.okz, x%d = (vt[%d] - rs.okx) - rs.Sx * z%d, y%d = (vt[%d] - rs.oky) - rs.Sy * z%d;"
                          % (k, k, k, 2 * k, k, k, 2 * k + 1, k))
+            if cull_behind:
+                lines.append("\t\tconst float b%d = rs.Sz * z%d;" % (k, k))
         edges = set()
         for q in range(first, first + count):
             a, b, c, d = vids[q]
@@ -112,9 +122,10 @@ def emit_topology(name, vids):
             a, b, c, d = vids[q]
             acc = "acc0" if q < 16 else "acc1"
             # tri0 = (a,b,c): U = E(b,c), V = E(c,a), W = E(a,b);  tri1 = (a,c,d): U = E(c,d), V = E(d,a), W = E(a,c)
-            for tri in ((E(b, c), E(c, a), E(a, b)), (E(c, d), E(d, a), E(a, c))):
-                lines.append("\t\t{ const float u = %s, v = %s, w = %s; %s = __builtin_amdgcn_alignbit(%s, __float_as_uint(__builtin_fmaf(__builtin_fminf(__builtin_fminf(u, v), w), __builtin_fmaxf(__builtin_fmaxf(u, v), w), 0.0f)), 31u); } // quad %d"
-                             % (tri[0], tri[1], tri[2], acc, acc, q))
+            for tri, vs3 in (((E(b, c), E(c, a), E(a, b)), (a, b, c)), ((E(c, d), E(d, a), E(a, c)), (a, c, d))):
+                behind = " | SSX_P1_BEHIND(b%d, b%d, b%d)" % vs3 if cull_behind else ""
+                lines.append("\t\t{ const float u = %s, v = %s, w = %s; %s = __builtin_amdgcn_alignbit(%s, __float_as_uint(__builtin_fmaf(__builtin_fminf(__builtin_fminf(u, v), w), __builtin_fmaxf(__builtin_fmaxf(u, v), w), 0.0f))%s, 31u); } // quad %d"
+                             % (tri[0], tri[1], tri[2], acc, acc, behind, q))
         lines.append("\t}")
     lines.append("}")
     lines[0] += ", %d distinct edges of %d" % (n_edges, 5 * nq)
@@ -124,18 +135,24 @@ def emit_topology(name, vids):
 def generate():
     out = ["// ssx_pass1_gen.h -- GENERATED by tools/gen_pass1.py (see there for the why); do not edit.",
            "// Pass 1 of trace() straight-line for the mesh topologies of the reference's built-in scenes.",
-           "#pragma once", ""]
+           "#pragma once",
+           "// sign bit set iff the three scaled depths are all < 0 (or -0): the triangle lies behind the ray's origin and is no candidate (tools/gen_pass1.py)",
+           "#ifdef SSX_NO_BEHIND_CULL // (A/B builds)",
+           "#define SSX_P1_BEHIND(a, b, c) 0u",
+           "#else",
+           "#define SSX_P1_BEHIND(a, b, c) __float_as_uint(__builtin_fmaxf(__builtin_fmaxf((a), (b)), (c)))",
+           "#endif", ""]
     host = ["// corner -> distinct-vertex id per quad (v00, v10, v11, v01), numbered by first occurrence: what ssx_upload_scene",
             "// compares an uploaded scene's sharing pattern with, and what pass 2 of the specialised kernels looks vertices up by",
             "struct SsxTopology { uint32_t id, n_quads, n_verts; const uint8_t (*vid)[4]; };"]
     dev = []
     table = []
-    for name, tid, scene in TOPOLOGIES:
+    for name, tid, scene, cull in TOPOLOGIES:
         vids = scene_vids(scene)
         nv = 1 + max(max(r) for r in vids)
         host.append("static const uint8_t ssx_topo_%s_vid[%d][4] = { %s };" % (name, len(vids), ", ".join("{ %d, %d, %d, %d }" % tuple(r) for r in vids)))
         table.append("{ %du, %du, %du, ssx_topo_%s_vid }" % (tid, len(vids), nv, name))
-        dev += emit_topology(name, vids) + [""]
+        dev += emit_topology(name, vids, cull) + [""]
     host.append("static const SsxTopology ssx_topologies[%d] = { %s };" % (len(table), ", ".join(table)))
     return "\n".join(out + host + [""] + dev)
 
