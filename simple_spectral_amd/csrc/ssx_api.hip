@@ -216,6 +216,8 @@ int pack_blob(ssx_ctx* ctx, const ssx_scene_desc* s, const std::vector<uint8_t*>
 	h.spec_basis_r = s->spec_basis_r; h.spec_basis_g = s->spec_basis_g; h.spec_basis_b = s->spec_basis_b;
 	h.n_textures = s->n_textures;
 	h.n_lights_recip = 1.0 / (double)(float)s->n_lights;
+	for (int r = 0; r < 4; ++r) { volatile double z = 0.0, one = 1.0; h.q_const[r] = h.pv_inv[2 * 4 + r] * z + h.pv_inv[3 * 4 + r] * one; } // (volatile: the two products and the sum as written, whatever the host compiler would like to fold)
+	for (int k = 0; k < 3; ++k) h.cam_pos_d[k] = (double)s->cam_pos[k];
 	// a black surface ends its path on the random draws alone (ssx_kernels.hip path_step) -- provided (emitted * n_dot_l) * 0 is 0: no NaN / inf / huge emission sample
 	h.black_ends_path = 1u;
 	for (uint32_t i = 0; i < s->n_lights; ++i) {
@@ -457,6 +459,7 @@ LaunchPlan make_plan(ssx_ctx* ctx, const ssx_render_params* p, bool ask_device =
 	SsxKernelArgs& a = pl.args;
 	a.blob = ctx->d_blob; a.blob_words = ctx->path_blob_words;
 	a.width = p->width; a.height = p->height;
+	a.inv_width = 1.0 / (double)p->width; a.inv_height = 1.0 / (double)p->height;
 	a.tiles_x = (p->width + 7u) / 8u;
 	a.n_tiles = a.tiles_x * ((p->height + 7u) / 8u);
 	// tile_skew only ever enters as (ty * tile_skew) % tiles_x: reduced here, so that the kernels' 32-bit product cannot wrap where the

@@ -107,7 +107,10 @@ struct SsxBlobHeader {
 	uint32_t pad4_[1];
 	float lambda_steps[4];      // float(i) * lambda_step, i = 0..3 (spectrum.cpp:63: lambda_0 + i*LAMBDA_STEP)
 	double n_lights_recip;      // RN64(1 / (double)(float)n_lights): `pdf /= float(lights.size())` (scene.cpp:430) as one multiply (ssx_exact.h)
-	double pad2_;
+	// the camera ray's wave-uniform subexpressions (renderer.cpp:121-131), evaluated once by the host with the same IEEE operations: row r of
+	// matr_PV_inv * dvec4(ndc, 0, 1) is (m[0][r]*ndc.x + m[1][r]*ndc.y) + q_const[r] with q_const[r] = m[2][r]*0.0 + m[3][r]*1.0; camera.pos widened
+	double q_const[4];
+	double cam_pos_d[3];
 };
 static_assert(sizeof(SsxBlobHeader) % 16 == 0, "header must keep 16-byte alignment");
 
@@ -201,6 +204,7 @@ struct SsxKernelArgs {
 	uint32_t pre_hits;        // 1: ssx_generate_kernel* traces the camera rays (hit[] valid, the path loop starts every sample at its first
 	                          // hit); 0: camera rays are traced in the path loop like any other ray (scenes whose rays rarely leave the scene)
 	uint32_t queue_words;     // words per entry of the shadow-ray queues: SSX_QUEUE_WORDS_WIDE or _NARROW (see above)
+	double inv_width, inv_height; // 1.0 / width, 1.0 / height (binary64): for a power-of-two image size (i + subpixel) / res is the exact product with them (camera_dir)
 	uint32_t fuse_gen;        // 1 (only with pre_hits == 0, kernels of the plane topology): no ssx_generate_kernel ran -- the path kernel's refill makes a sample's
 	                          // stream, camera ray and lambda_0 where it hands the sample to a lane (generate_sample), and ray[] / st[] are not read there
 };

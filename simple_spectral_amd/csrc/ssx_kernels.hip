@@ -930,7 +930,14 @@ __device__ __forceinline__ uint32_t log_region(const SsxKernelArgs& a, uint32_t 
 // it with release semantics at WAVEFRONT scope; the fold starts with an acquire load of it.  Read-modify-writes continue
 // each other's release sequences, so the one load synchronises with every such store of the wave: the hand-over is a
 // release/acquire pair of the HIP memory model at the scope it happens in, at the cost of one LDS atomic per site.
+#ifdef SSX_RELEASE_ONE_LANE // (measurement only, profiles/r06/NOTES.md section 4: what the all-lanes read-modify-write of ONE LDS word costs in bank-conflict cycles)
+__device__ __forceinline__ void wave_release(uint32_t* cnt) {
+	const unsigned long long m = __ballot(1);
+	if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(m)) (void)__hip_atomic_fetch_add(cnt + 4u * SSX_UNIT_COHORTS, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
+#else
 __device__ __forceinline__ void wave_release(uint32_t* cnt) { (void)__hip_atomic_fetch_add(cnt + 4u * SSX_UNIT_COHORTS, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+#endif
 __device__ __forceinline__ void wave_acquire(uint32_t* cnt) { (void)__hip_atomic_load(cnt + 4u * SSX_UNIT_COHORTS, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 __device__ __forceinline__ uint32_t log_append(const LogRef& lg, uint32_t which) {
 	return __hip_atomic_fetch_add(lg.cnt + 2u * lg.group() + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -947,16 +954,16 @@ __device__ __forceinline__ void camera_dir(const SsxBlobHeader& h, const Args& a
 	// reciprocal -- the same binary64 in 2 instead of ~28 instructions (every BASELINE configuration; wave-uniform test)
 	const bool pow2 = ((a.width & (a.width - 1u)) | (a.height & (a.height - 1u))) == 0u;
 	double st_x, st_y;
-	if (pow2) { st_x = x * (1.0 / (double)a.width); st_y = y * (1.0 / (double)a.height); }
+	if (pow2) { st_x = x * a.inv_width; st_y = y * a.inv_height; } // (the two reciprocals come with the launch: make_plan)
 	else { st_x = x / (double)a.width; st_y = y / (double)a.height; }
 	double ndc_x = st_x * 2.0 - 1.0, ndc_y = st_y * 2.0 - 1.0;
 	double q[4];
 #pragma unroll
 	for (int r = 0; r < 4; ++r)
-		q[r] = (h.pv_inv[0 * 4 + r] * ndc_x + h.pv_inv[1 * 4 + r] * ndc_y) + (h.pv_inv[2 * 4 + r] * 0.0 + h.pv_inv[3 * 4 + r] * 1.0);
+		q[r] = (h.pv_inv[0 * 4 + r] * ndc_x + h.pv_inv[1 * 4 + r] * ndc_y) + h.q_const[r]; // q_const[r] = pv_inv[2*4+r] * 0.0 + pv_inv[3*4+r] * 1.0, by the host (ssx_blob.h)
 	double w = q[3];
 	double px = q[0] / w, py = q[1] / w, pz = q[2] / w;
-	dx = px - (double)h.cam_pos[0]; dy = py - (double)h.cam_pos[1]; dz = pz - (double)h.cam_pos[2];
+	dx = px - h.cam_pos_d[0]; dy = py - h.cam_pos_d[1]; dz = pz - h.cam_pos_d[2];
 }
 template <typename Args>
 __device__ __forceinline__ void generate_sample(const SsxBlobHeader& h, const Args& a, uint32_t i, uint32_t j, uint32_t k, float4& ray, uint4& st) {
