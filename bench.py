@@ -50,7 +50,12 @@ FLOP_PER_SAMPLE = {"cornell-srgb": 1.28e4, "cornell": 1.28e4, "plane-srgb": 2.8e
 #   fold      : read tail 16 + (fs 16 + np 8 + chain word 4) L + nee 16 R + emission 16 E; the pixel sums (4 x binary64 per pixel)
 #               are read and written once per work unit of U samples per pixel: 64 / U
 LEVELS = {"cornell-srgb": 4.07, "cornell": 4.07, "plane-srgb": 1.0}
-SHADOW = {"cornell-srgb": 3.08, "cornell": 3.08, "plane-srgb": 1.36}
+SHADOW = {"cornell-srgb": 3.08, "cornell": 3.08, "plane-srgb": 0.5}   # (plane-srgb: 0.5 parked -- the other 0.86 of SURVEY's 1.36 shadow rays start on black walls and carry nothing)
+# SURVEY 8(d)'s formula prices every surface interaction S at 550 flop (next-event estimation ~450 incl. 16 transcendentals, BSDF sample ~100).  In
+# plane-srgb the second of a path's two interactions lies on a BLACK wall: everything it computes is multiplied by f_s = 0, and since round 6 the
+# kernel reduces it, exactly, to its random draws (csrc/ssx_kernels.hip path_step).  The contract's figure (2.8e3) stays the one `roofline.achieved`
+# uses; the line also states the fraction with those 500 flop per sample taken out of the numerator (roofline.frac_without_eliminated_work).
+FLOP_ELIMINATED_PER_SAMPLE = {"plane-srgb": 500.0}
 # gfx950 FP32 vector peak is 157.3 TFLOP/s counting FMA as 2; the parity contract forbids
 # contraction, so the ceiling that applies is the non-fused issue rate, half of it.
 PEAK_VALU_TFLOPS = 78.6
@@ -70,13 +75,20 @@ def algorithmic_bytes_per_sample_8d(scene, spp):
     return 16.0 / spp + TEXEL_BYTES_PER_SAMPLE.get(scene, 3.8)
 
 
-def design_bytes_per_sample(scene, path_kernel_only=False, levels=None):
+def design_bytes_per_sample(scene, path_kernel_only=False, levels=None, plan=None):
     L = levels if levels else LEVELS.get(scene, 4.07)
     R = SHADOW.get(scene, 3.08)
     E = 0.01
     U = 4.0 if L >= 2.0 else 8.0                                                          # samples per pixel of a work unit (make_batch)
-    path = (48 + 28 * L + 16 * E + 16) + 16 * R + (16 + 28 * L + 16 * R + 16 * E + 64.0 / U)   # path loop + shadow flush + fold
-    return path if path_kernel_only else 48 + path
+    # the records the generate kernel writes and the refill reads: ray 16 + stream 16 (+ camera hit 16 where camera rays are traced ahead); none
+    # where the path kernel makes its samples itself (plan_info: samples_made_in, round 6: plane-srgb)
+    rec = 48.0
+    if plan and plan.get("camera_rays") == "path loop":
+        rec = 32.0
+    if plan and str(plan.get("samples_made_in", "")).startswith("path kernel"):
+        rec = 0.0
+    path = (rec + 28 * L + 16 * E + 16) + 16 * R + (16 + 28 * L + 16 * R + 16 * E + 64.0 / U)   # path loop + shadow flush + fold
+    return path if path_kernel_only else rec + path
 
 
 def host_cpu_info():
@@ -764,7 +776,7 @@ def main():
         achieved_tflops = per_gpu_samples * flop / (kernel_ms * 1e-3) / 1e12
         plan = r.plan_info()
         L = plan["frames_per_sample"]  # continued levels per sample, measured on this scene at upload
-        hbm_bytes = per_gpu_samples * design_bytes_per_sample(args.scene, levels=L)
+        hbm_bytes = per_gpu_samples * design_bytes_per_sample(args.scene, levels=L, plan=plan)
         traffic, traffic_detail, traffic_source = measured_traffic(args, world)
         info = r.kernel_info()
         n1 = n1_reference()
@@ -784,10 +796,11 @@ def main():
                        "texture": texture, "seed": 0, "kernel_source_id": kernel_source_id()},
             "roofline": {"bound": "valu", "achieved": round(achieved_tflops, 3), "peak": PEAK_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved_tflops / PEAK_VALU_TFLOPS, 4),
+                         "frac_without_eliminated_work": round(achieved_tflops * (1.0 - FLOP_ELIMINATED_PER_SAMPLE.get(args.scene, 0.0) / flop) / PEAK_VALU_TFLOPS, 4),
                          "traffic": traffic,
                          "traffic_source": traffic_source,
                          "traffic_detail": traffic_detail,
-                         "kernel": "ssx_generate_kernel + %s" % (plan.get("kernel") or "ssx_render_kernel"),
+                         "kernel": ("%s (makes its samples in its refill: no generate kernel)" if str(plan.get("samples_made_in", "")).startswith("path kernel") else "ssx_generate_kernel + %s") % (plan.get("kernel") or "ssx_render_kernel"),
                          "kernel_ms": round(kernel_ms, 3), "path_kernel_ms": round(path_ms, 3),
                          "pipeline_ms": round(pipeline_ms, 3), "stage_ms": {k: round(v, 3) for k, v in stage_ms.items()},
                          "flop_per_sample": flop,
@@ -796,9 +809,9 @@ def main():
                                  "algorithmic_bytes_per_sample_8d": round(algorithmic_bytes_per_sample_8d(args.scene, spp_total), 3),
                                  "traffic_over_algorithmic_8d": round(traffic / (per_gpu_samples * algorithmic_bytes_per_sample_8d(args.scene, spp_total)), 1) if traffic else None,
                                  "why": "the recursion's levels and next-event terms are logged to HBM and folded post-order at the end of each work unit: the price of reproducing the reference's float rounding (radiance = direct + ((L_next * n.l) * f_s) / pdf, innermost first) with samples, not pixels, as the parallel unit; HBM stays at ~20 % of peak and is not the limiter (VALU issue is)",
-                                 "design_bytes_per_sample": round(design_bytes_per_sample(args.scene, levels=L), 1),
-                                 "path_kernel_design_bytes_per_sample": round(design_bytes_per_sample(args.scene, True, L), 1),
-                                 "traffic_over_path_kernel_design": round(traffic / (per_gpu_samples * design_bytes_per_sample(args.scene, True, L)), 3) if traffic else None,
+                                 "design_bytes_per_sample": round(design_bytes_per_sample(args.scene, levels=L, plan=plan), 1),
+                                 "path_kernel_design_bytes_per_sample": round(design_bytes_per_sample(args.scene, True, L, plan), 1),
+                                 "traffic_over_path_kernel_design": round(traffic / (per_gpu_samples * design_bytes_per_sample(args.scene, True, L, plan)), 3) if traffic else None,
                                  "traffic_bytes_per_sample": round(traffic / per_gpu_samples, 1) if traffic else None,
                                  "design_GBps": round(hbm_bytes / (pipeline_ms * 1e-3) / 1e9, 1),
                                  "measured_GBps": round(traffic / (path_ms * 1e-3) / 1e9, 1) if traffic else None,

@@ -288,8 +288,12 @@ class Renderer:
         left, pre = C.c_float(), C.c_int()
         if hasattr(self._lib, "ssx_calibration_info"):  # (an older build loaded through SSX_HIP_LIB_OVERRIDE for an A/B run has neither)
             self._check(self._lib.ssx_calibration_info(self._ctx, None, C.byref(left), C.byref(pre)))
+        # where a sample's stream / camera ray / lambda_0 are made: the generate kernel, or -- kernels of the plane topology whose camera rays are
+        # traced in the path loop (csrc/ssx_api.hip enqueue_front: fuse_gen) -- the path kernel's refill
+        fused = (not pre.value) and variant == "plane topology" and not (os.environ.get("SSX_DEBUG_ENV") == "1" and os.environ.get("SSX_FUSE_GEN", "")[:1] == "0")
         return {"frames_per_sample": round(f.value, 3), "fold": "path kernel", "pass1": variant,
                 "rays_left_per_sample": round(left.value, 3), "camera_rays": "pre-traced (generate kernel)" if pre.value else "path loop",
+                "samples_made_in": "path kernel (refill)" if fused else "generate kernel",
                 "kernel": name.decode() if name else None}
 
     def scratch_info(self):

@@ -5,7 +5,7 @@
 # The tests that assert WHICH variant the library chose are deselected (they fail by construction under a forced choice).
 export SSX_DEBUG_ENV=1 # the master switch of the A/B environment variables (README)
 SKIP="not specialised_for_builtin and not compiled_at_upload and not shadow_queue_layouts and not camera_rays_pretraced and not calibration_and_device_scratch and not background and not two_threads"
-for E in "SSX_GENERIC_KERNEL=1" "SSX_NARROW_QUEUE=1" "SSX_PRE_HITS=0" "SSX_PRE_HITS=1" "SSX_JIT_PASS1=1"; do
+for E in "SSX_GENERIC_KERNEL=1" "SSX_NARROW_QUEUE=1" "SSX_PRE_HITS=0" "SSX_PRE_HITS=1" "SSX_JIT_PASS1=1" "SSX_FUSE_GEN=0" "SSX_BLACK_SHORTCUT=0"; do
 	echo "== $E"; env $E timeout 400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_units.py -q -m gpu -rf -k "$SKIP" 2>&1 | grep -E "^(FAILED|ERROR)|^E  | passed| failed| error" | cut -c1-300
 done
 # The pixel sums' hand-over expressed in the HIP memory model (-DSSX_ACCUM_FORMAL, ssx_kernels.hip unit_fold: -25 %) against the default build's
