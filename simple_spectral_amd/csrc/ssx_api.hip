@@ -606,6 +606,10 @@ Batch make_batch(ssx_ctx* ctx, const LaunchPlan& pl, uint32_t k0, uint32_t k1) {
 	a.n_groups = (n_k + a.group_spp - 1) / a.group_spp;
 	a.unit_cohorts = (a.group_spp + SSX_COHORT_KS - 1u) / SSX_COHORT_KS;
 	b.units = a.my_tiles * a.n_groups;
+	// units per grab (ssx_kernels.hip rotate_fetch): four where paths are short and a wave's lanes run dry together (plane-srgb: +0.9 %), one where they are
+	// long (Cornell box: four cost 0.3 %); SSX_UNIT_GRAB=n under SSX_DEBUG_ENV=1 for A/B runs
+	a.unit_grab = ctx->calib_frames >= 2.0f ? 1u : 4u;
+	if (const char* e = debug_env("SSX_UNIT_GRAB")) { const int v = atoi(e); if (v >= 1 && v <= 16) a.unit_grab = (uint32_t)v; }
 	b.n_rec = a.n_records;
 	// sample arrays and logs are shared by all batches of a render: their kernels run one after the other in stream order
 	b.rc = ensure_logs(ctx, a.unit_cohorts);

@@ -204,6 +204,8 @@ struct SsxKernelArgs {
 	uint32_t pre_hits;        // 1: ssx_generate_kernel* traces the camera rays (hit[] valid, the path loop starts every sample at its first
 	                          // hit); 0: camera rays are traced in the path loop like any other ray (scenes whose rays rarely leave the scene)
 	uint32_t queue_words;     // words per entry of the shadow-ray queues: SSX_QUEUE_WORDS_WIDE or _NARROW (see above)
+	uint32_t unit_grab;       // work units a wave takes from unit_counter per read-modify-write (>= 1; the path kernel's rotate_fetch): 4 for scenes of short paths
+	uint32_t pad_grab_;
 	double inv_width, inv_height; // 1.0 / width, 1.0 / height (binary64): for a power-of-two image size (i + subpixel) / res is the exact product with them (camera_dir)
 	uint32_t fuse_gen;        // 1 (only with pre_hits == 0, kernels of the plane topology): no ssx_generate_kernel ran -- the path kernel's refill makes a sample's
 	                          // stream, camera ray and lambda_0 where it hands the sample to a lane (generate_sample), and ray[] / st[] are not read there

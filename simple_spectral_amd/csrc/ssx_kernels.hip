@@ -53,9 +53,6 @@ __device__ __forceinline__ uint32_t* stage_lds(const SsxKernelArgs& a) {
 	return blob;
 }
 
-#ifndef SSX_UNIT_GRAB
-#define SSX_UNIT_GRAB 1 // work units a wave takes from the global counter per read-modify-write (rotate_fetch; > 1: measured in profiles/r06/NOTES.md)
-#endif
 #define SSX_EPS 0.001f          // stdafx.hpp:58
 #define SSX_MAX_DEPTH_ 10u       // stdafx.hpp:47
 #define SSX_PI_F 3.14159265358979323846f
@@ -1737,9 +1734,8 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 	bool cur_valid = false, old_pending = false, more = true;
 	uint32_t cur_tag = 0, old_tag = 0;
 	uint32_t next_item = 0; // wave-uniform
-#if SSX_UNIT_GRAB > 1
-	uint32_t grab_next = 0, grab_left = 0; bool grab_single = false; // wave-uniform: units taken from the counter and not started yet (rotate_fetch)
-#endif
+	uint32_t grab = 0; // wave-uniform, ONE SGPR (three cost the loop eight spilled ones): units taken from the counter and not started yet (rotate_fetch):
+	                   // next unit | units left << 26 | "one at a time from now on" << 31  (a launch has fewer than 2^26 units: its records are indexed with 32 bits)
 	// the tail word (ssx_blob.h) of the lane's path ending at level p.depth: hit_anything (0 only for a camera ray that left
 	// the scene) | the level has an emission term << 1 | p.depth << 2 | slot of the entry of level
 	// p.depth-1 << 6 | slot of the level's next-event term << 19; lambda_0 and the final PCG32 state replace the sample's
@@ -1830,28 +1826,23 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 		if (!cur_valid && more) {
 			const __attribute__((address_space(4))) SsxKernelArgs& c = cold_args(); // (once per unit: not worth SGPRs across the loop)
 			uint32_t u = 0;
-#if SSX_UNIT_GRAB > 1
-			// Units are taken from the counter SSX_UNIT_GRAB at a time (one device-scope read-modify-write per grab instead of per unit: the wave stands
-			// still for its round trip -- 10 % of a plane-srgb wave's time, profiles/r06/plane/regtime.log), one at a time near the end of the launch,
-			// where a wave that still holds units while others have run dry would be the launch's tail.
+			// Units are taken from the counter SsxKernelArgs::unit_grab at a time (one device-scope read-modify-write per grab instead of per unit: the
+			// wave stands still for its round trip -- 10 % of a plane-srgb wave's time, all of whose lanes run dry together: profiles/r06/plane/regtime.log;
+			// 4 there, 1 for scenes of long paths, where lanes refill one by one under the other waves' work and a grab only lengthens the launch's
+			// tail: profiles/r06/ab_unit_grab.log), one at a time near the end of the launch, where a wave that still holds units while others have
+			// run dry would BE the tail.
 			const uint32_t total = c.my_tiles * c.n_groups;
-			if (grab_left) { u = grab_next++; --grab_left; }
+			if ((grab >> 26) & 31u) { u = grab & 0x3FFFFFFu; grab += 1u - (1u << 26); } // (next + 1, left - 1)
 			else {
-				const uint32_t want = grab_single ? 1u : (uint32_t)SSX_UNIT_GRAB;
+				const uint32_t single = grab >> 31, want = single ? 1u : c.unit_grab;
 				if (lane == 0u) u = atomicAdd(c.unit_counter, want);
 				u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
 				if (u < total) {
 					const uint32_t got = min(want, total - u);
-					grab_next = u + 1u; grab_left = got - 1u;
-					if (total - u < gridDim.x * 4u * (uint32_t)SSX_UNIT_GRAB * 4u) grab_single = true; // fewer than four more grabs per wave are left
+					grab = (u + 1u) | ((got - 1u) << 26) | ((single | (total - u < gridDim.x * 4u * want * 4u ? 1u : 0u)) << 31); // fewer than four more grabs per wave are left: one at a time
 				}
 			}
 			if (u < total) {
-#else
-			if (lane == 0u) u = atomicAdd(c.unit_counter, 1u);
-			u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
-			if (u < c.my_tiles * c.n_groups) {
-#endif
 				unit_setup(a, u, cur); cur_tag ^= 1u; next_item = 0; cur_valid = true;
 				if (FUSE_UNIT && a.fuse_gen) generate_unit(L, cur, lane, cam, log_cnt);
 				if (lane < 2u * SSX_UNIT_COHORTS) log_cnt[2u * SSX_UNIT_COHORTS * cur_tag + lane] = 0u; // the logs of its cohorts are empty (the last unit with this tag has been folded)
