@@ -535,7 +535,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the oracle check of the timed image (A/B scripts; the driver's command never passes it)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure HBM traffic with rocprofv3 --pmc passes in this run (replay profiles/traffic.json, stamped)")
-    ap.add_argument("--scratch-cap-gb", type=float, default=8.0, help="per-rank cap on the library's device scratch (sample arrays + level logs): a render that would need more is split into batches of fewer samples per pixel (the default workload needs 4.4 GB and is not split)")
+    ap.add_argument("--scratch-cap-gb", type=float, default=16.0, help="per-rank cap on the library's device scratch (sample arrays + level logs): a render that would need more is split into batches of fewer samples per pixel (the default workload needs 4.4 GB and is not split)")
     ap.add_argument("--dist-dry-run", action="store_true", help="no benchmark: go through the multi-GPU plumbing on whatever devices exist (process group, a timed framebuffer reduce, ssx_rccl_probe, per-rank scratch) and REPORT what was found in one JSON line")
     ap.add_argument("--update-traffic", action="store_true", help="also write the measured HBM traffic into the tracked replay file profiles/traffic.json (a round's closing run)")
     ap.add_argument("--quick", action="store_true", help="= --no-cpu-baseline --no-check --no-pmc (A/B and profiling scripts)")

@@ -31,7 +31,8 @@ extern "C" {
  *      ssx_render_params.reserved became no_flat_field_correction (a stale nonzero value changes the image); SSX_MAX_QUADS 32 -> 128,
  *      SSX_MAX_TEXTURES and the struct sizes grew; ssx_set_jit takes a mode (default: background compilation); ssx_jit_status,
  *      ssx_jit_counters, ssx_sums_info, ssx_rccl_groups_made, ssx_done_tiles and ssx_render_params.tile_major and tile_skew (the
- *      struct grew by 8 bytes) are new. */
+ *      struct grew by 8 bytes) are new.  Added since without a change of existing entry points or structures (same version): ssx_units_info,
+ *      ssx_rccl_probe (round 6). */
 #define SSX_ABI_VERSION 2
 
 enum {
