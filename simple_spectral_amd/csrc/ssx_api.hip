@@ -687,7 +687,9 @@ int enqueue_front(ssx_ctx* ctx, const LaunchPlan& pl, Batch& b, hipStream_t stre
 	// fetches a unit makes its samples and traces their camera rays with all 64 lanes, then runs them (generate_unit) -- only the tile masks
 	// are computed ahead.  Only in builds with -DSSX_FUSE_UNIT, and there only with SSX_FUSE_GEN=1: measured, not kept (profiles/r06/NOTES.md section 3).
 	const char* fuse_env = debug_env("SSX_FUSE_GEN");
-	b.a.fuse_gen = (!calibration && ctx->topology == 2u && !b.a.pre_hits && !(fuse_env && fuse_env[0] == '0')) ? 1u : 0u;
+	// (the unit carries its tile's column and row in 16 bits each: WorkUnit::txy -- an image more than 524 280 pixels wide or high keeps the generate kernel)
+	const bool tiles_fit = b.a.tiles_x <= 0xFFFFu && (b.a.height + 7u) / 8u <= 0xFFFFu;
+	b.a.fuse_gen = (!calibration && ctx->topology == 2u && !b.a.pre_hits && tiles_fit && !(fuse_env && fuse_env[0] == '0')) ? 1u : 0u;
 #ifdef SSX_FUSE_UNIT
 	if (!calibration && ctx->topology == 1u && b.a.pre_hits && fuse_env && fuse_env[0] == '1') b.a.fuse_gen = 1u;
 #endif

@@ -484,3 +484,20 @@ def test_black_surfaces_end_the_path_on_the_random_draws_alone():
     xyza, state, _ = r2.debug_samples()
     ref_xyza, ref_state, _st = orc2.samples(16, 16, 4, seed=2)
     assert np.array_equal(state, ref_state) and np.array_equal(bits(xyza), bits(ref_xyza))
+
+
+def test_image_wider_than_65535_tiles_plane_kernel_reads_its_samples():
+    """The plane-topology kernels make a sample where a lane takes it, from the tile's column and row the work unit carries in 16 bits each
+    (csrc/ssx_kernels.hip WorkUnit::txy); an image of more than 65 535 tiles in a direction keeps the generate kernel (csrc/ssx_api.hip
+    enqueue_front).  One pixel row of 65 537 tiles, ragged at the end, against the oracle."""
+    W, H, spp = 8 * 65536 + 3, 1, 1
+    r = Renderer(Options(scene_name="plane-srgb", res=(W, H), spp=spp, seed=5, texture="test-img.png"))
+    r.render_start(); r.render_wait()
+    ref = ol.Oracle("plane-srgb", texture="test-img.png").render(W, H, spp, seed=5)
+    assert np.array_equal(bits(r.xyza), bits(ref))
+    # and the neighbour below the limit (65 535 tiles: the fused path), same check
+    W2 = 8 * 65535 - 2
+    r2 = Renderer(Options(scene_name="plane-srgb", res=(W2, 1), spp=1, seed=5, texture="test-img.png"))
+    r2.render_start(); r2.render_wait()
+    ref2 = ol.Oracle("plane-srgb", texture="test-img.png").render(W2, 1, 1, seed=5)
+    assert np.array_equal(bits(r2.xyza), bits(ref2))

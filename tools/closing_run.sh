@@ -20,7 +20,7 @@ bash tools/formal_repeat.sh 10 > $O/formal_repeat.log 2>&1; grep -E "passed|fail
 bash tools/test_kernel_variants.sh > $O/parity_per_kernel_variant.log 2>&1; cat $O/parity_per_kernel_variant.log
 python tools/rank_share.py --all-ranks --configs headline,plane > $O/rank_share.log 2>&1; tail -12 $O/rank_share.log | cut -c1-200
 python tools/bench_sweep.py "--res 128 --spp 16" "--scene cornell --spp 1024 --uplift jh" "--scene plane-srgb --res 1024 --spp 1024" "--res 2048 --spp 2048 --observer 2006 --steps 2 --warmup 1" "--texture procedural:4096" "--observer 2006" > $O/configs.log 2>&1; cut -c1-130 $O/configs.log
-python tools/fuzz_scenes.py 120000 3000 > $O/fuzz_scenes.log 2>&1; tail -2 $O/fuzz_scenes.log
+python tools/fuzz_scenes.py 130000 6000 > $O/fuzz_scenes.log 2>&1; tail -2 $O/fuzz_scenes.log
 bash tools/sanitize.sh --gpu-only $O/sanitize_gpu.log > /dev/null 2>&1; echo "sanitize rc=$?"; tail -6 $O/sanitize_gpu.log
 python tools/stress_parity.py > $O/stress_parity.log 2>&1; tail -2 $O/stress_parity.log | cut -c1-200
 python tools/stress_long.py 24 > $O/stress_long.log 2>&1; tail -2 $O/stress_long.log | cut -c1-200
