@@ -1024,7 +1024,10 @@ __device__ __forceinline__ void hit_st(const SsxBlobQuad& Q, uint32_t which, con
 // when the path continues, appends the level's entry (the factors of the continuation and the chain word) to
 // the unit's log; returns true when it continues (p then holds the next ray), else level_word describes the
 // path's last level for the tail word.
-template <bool NARROW>
+// BLACK: the kernel knows the shortcut for black surfaces (below).  It changes no result, so a kernel may leave it out: the kernels of the Cornell
+// topology do -- the scenes that have it rarely hold a black surface, and the test and the merge behind the branch cost their loop 25 instructions
+// per iteration (+0.7 % of the headline's time, profiles/r06/NOTES.md section 8).
+template <bool NARROW, bool BLACK>
 __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const SsxKernelArgs& a, const LogRef& lg, Path& p, bool& pushed, uint32_t& level_word) {
 	const SsxBlobHeader& h = L.hdr();
 	// what the level's entry (or the path's tail word) says about this level: slot of its next-event term << 13 | has an emission term << 26
@@ -1076,7 +1079,7 @@ __device__ __forceinline__ bool path_step(const Lds& L, const ShadowQ& q, const 
 	// parity contract): the light sampler's and the hemisphere sampler's draws are made, rejection loops included, their arithmetic --
 	// six binary64 arc cosines, Arvo's sampler, a sine and a cosine: ~55 % of a level's instructions -- is not.  In plane-srgb every path's
 	// second hit is such a wall (wave-uniform there); a wave of the Cornell box never takes the branch.
-	if (M.kind == 0u && h.black_ends_path != 0u && f_lamb[0] == 0.0f && f_lamb[1] == 0.0f && f_lamb[2] == 0.0f && f_lamb[3] == 0.0f) {
+	if (BLACK && M.kind == 0u && h.black_ends_path != 0u && f_lamb[0] == 0.0f && f_lamb[1] == 0.0f && f_lamb[2] == 0.0f && f_lamb[3] == 0.0f) {
 		SSX_STAT(18); // black surface: draws only
 		if (els && (!a.indirect_only || p.depth > 0u)) skip_light_draws(L, p.rng);
 		skip_coshemi_draws(p.rng);
@@ -1831,15 +1834,16 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 			// 4 there, 1 for scenes of long paths, where lanes refill one by one under the other waves' work and a grab only lengthens the launch's
 			// tail: profiles/r06/ab_unit_grab.log), one at a time near the end of the launch, where a wave that still holds units while others have
 			// run dry would BE the tail.
+			// (Compiled out of the Cornell topology's kernels, whose scenes have long paths: one unit per read-modify-write, no state.)
 			const uint32_t total = c.my_tiles * c.n_groups;
-			if ((grab >> 26) & 31u) { u = grab & 0x3FFFFFFu; grab += 1u - (1u << 26); } // (next + 1, left - 1)
+			if (TOPO != 1 && ((grab >> 26) & 31u)) { u = grab & 0x3FFFFFFu; grab += 1u - (1u << 26); } // (next + 1, left - 1)
 			else {
-				const uint32_t single = grab >> 31, want = single ? 1u : c.unit_grab;
+				const uint32_t single = TOPO != 1 ? grab >> 31 : 1u, want = single ? 1u : c.unit_grab;
 				if (lane == 0u) u = atomicAdd(c.unit_counter, want);
 				u = (uint32_t)__builtin_amdgcn_readfirstlane((int)u);
 				if (u < total) {
 					const uint32_t got = min(want, total - u);
-					grab = (u + 1u) | ((got - 1u) << 26) | ((single | (total - u < gridDim.x * 4u * want * 4u ? 1u : 0u)) << 31); // fewer than four more grabs per wave are left: one at a time
+					if (TOPO != 1) grab = (u + 1u) | ((got - 1u) << 26) | ((single | (total - u < gridDim.x * 4u * want * 4u ? 1u : 0u)) << 31); // fewer than four more grabs per wave are left: one at a time
 				}
 			}
 			if (u < total) {
@@ -1872,7 +1876,7 @@ __device__ __forceinline__ void render_body(const SsxKernelArgs& a) {
 				LogRef lg;
 				lg.cnt = log_cnt; lg.wave_base = wave_slot * 2u * a.unit_cohorts; lg.tagw = p_tag;
 				uint32_t level_word;
-				if (!path_step<NARROW>(L, sq, a, lg, p, pushed, level_word)) end_path(level_word, 1u);
+				if (!path_step<NARROW, TOPO != 1>(L, sq, a, lg, p, pushed, level_word)) end_path(level_word, 1u);
 			}
 			sq.count += (uint32_t)__popcll(__ballot(pushed));
 		}

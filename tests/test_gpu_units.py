@@ -423,6 +423,29 @@ for io, els in ((False, True), (True, True), (False, False)):
 print(json.dumps(out))
 """
 
+# the Cornell box with a black floor and black texels on the generic kernel (SSX_GENERIC_KERNEL=1 in the child's environment): the kernels of the
+# Cornell topology are compiled without the shortcut (path_step<NARROW, BLACK = false>), the generic one has it -- lanes of both kinds in one wave
+_BLACK_CORNELL_CHILD = r"""
+import os, sys, json, hashlib
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import custom_scene as cs
+from simple_spectral_amd import Options, Renderer
+c = cs.CustomScene("cornell-srgb")
+zero = c.add_spectrum(np.zeros(8, dtype=np.float32), 400.0, 700.0)
+black = c.add_material(kind=0, albedo_spectrum=zero)
+pos, st_, _m = c.quads[0]
+c.quads[0] = (pos, st_, black)
+c.textures[0][::2, :, :] = 0
+orc = c.oracle()
+r = Renderer(Options(scene_name="cornell-srgb", res=(8, 8), spp=1, texture="test-img.png"))
+r.upload_scene_desc(c.desc(orc))
+assert r.plan_info()["pass1"] == "generic", r.plan_info()
+r.options.res = (24, 24); r.options.spp = 8; r.options.seed = 4
+xyza, state, levels = r.debug_samples()
+print(json.dumps({"sha": hashlib.sha256(xyza.tobytes() + state.tobytes() + levels.tobytes()).hexdigest()}))
+"""
+
 
 def test_black_surfaces_end_the_path_on_the_random_draws_alone():
     """Round 6: a black Lambertian surface (plane-srgb's light box, src/scene.cpp:357-413: albedo 0) ends its path in path_step without the
@@ -467,10 +490,16 @@ def test_black_surfaces_end_the_path_on_the_random_draws_alone():
     r = Renderer(Options(scene_name="cornell-srgb", res=(8, 8), spp=1, texture="test-img.png"))
     r.upload_scene_desc(c.desc(orc))
     r.options.res = (24, 24); r.options.spp = 8; r.options.seed = 4
-    xyza, state, _ = r.debug_samples()
+    xyza, state, levels = r.debug_samples()
     ref_xyza, ref_state, st = orc.samples(24, 24, 8, seed=4)
     assert np.array_equal(state, ref_state) and np.array_equal(bits(xyza), bits(ref_xyza))
     assert st.interactions > 0
+    # ... which the Cornell topology's kernel evaluates in full (compiled without the shortcut: profiles/r06/NOTES.md section 8); the generic kernel,
+    # which takes the shortcut on the lanes that sit on the floor or a black texel, returns the same per-sample arrays
+    env = dict(os.environ, SSX_DEBUG_ENV="1", SSX_GENERIC_KERNEL="1")
+    out = subprocess.run([sys.executable, "-c", _BLACK_CORNELL_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1])["sha"] == hashlib.sha256(xyza.tobytes() + state.tobytes() + levels.tobytes()).hexdigest()
     # an emission table that is not "finite and below 2^60": the flag is off, everything is evaluated (same bits as the oracle either way)
     c2 = cs.CustomScene("plane-srgb")
     li = next(i for i, m in enumerate(c2.materials) if c2.spectra[m["emission_spectrum"]][0].any())
