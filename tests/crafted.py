@@ -178,3 +178,61 @@ def origin_light_scene():
     c.add_quad((0, 0, 0), (1, 0, 0), (1, 0, 1), (0, 0, 1), LIGHT)
     c.set_camera((2.0, 2.0, -3.0), (0.5, 0.0, 0.5), up=(0, 1, 0), vfov_deg=40.0)
     return c
+
+
+def _distinct_corners(c):
+    """{position bits: position} over the corners of the scene's quads, in order of first occurrence"""
+    pts = {}
+    for pos, _, _ in c.quads:
+        for p in pos:
+            pts.setdefault(np.asarray(p, dtype=np.float32).tobytes(), np.asarray(p, dtype=np.float64))
+    return pts
+
+
+def warped_builtin(seed):
+    """One of the reference's built-in scenes (src/scene.cpp:32-415) with every distinct corner moved -- the same way wherever it occurs, so the
+    corners still coincide in the built-in pattern and the library keeps the kernel whose pass 1 is specialised to that mesh topology
+    (csrc/ssx_pass1_gen.h: the sharing pattern is compiled in, positions are run-time data).  The random scenes of `random_scene` run the generic
+    kernel or one compiled at upload; this is the fuzz of the kernels the headline numbers are measured on: the Cornell box and the plane scene
+    rotated, scaled by 2^-10 .. 2^10 and translated (the light stays in the ceiling's plane: shadow rays inside the plane of ten triangles, now
+    along no axis), with every corner jittered (quads that are neither planar nor rectangles, lights included, rooms that leak), flattened into
+    slivers, or sheared -- with a camera that follows.  Returns (scene, name of the base scene, render options)."""
+    g = np.random.default_rng(5000 + seed)
+    base = ("cornell-srgb", "plane-srgb", "cornell")[seed % 3]
+    kind = (seed // 3) % 4            # 0: similarity, 1: jitter, 2: similarity + jitter, 3: flatten + shear
+    c = cs.CustomScene(base, observer=(1931, 2006)[int(g.integers(0, 4) == 0)])
+    pts = _distinct_corners(c)
+    allp = np.array(list(pts.values()))
+    ctr = 0.5 * (allp.min(axis=0) + allp.max(axis=0))
+    size = float(np.abs(allp - ctr).max())
+    q, _ = np.linalg.qr(g.normal(size=(3, 3)))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    if kind in (0, 2):
+        s = 2.0 ** float(g.integers(-10, 11))
+        A = s * q
+        new_ctr = ctr * s + g.uniform(-1.0, 1.0, size=3) * size * s
+    elif kind == 3:
+        flat = np.diag([1.0, 1.0, 2.0 ** float(-g.integers(3, 13))])           # one axis of a rotated frame pressed flat: every triangle a sliver from most directions
+        shear = np.eye(3); shear[0, 1] = g.uniform(-0.8, 0.8)
+        A = q @ flat @ shear @ q.T
+        new_ctr = ctr
+    else:
+        A = np.eye(3)
+        new_ctr = ctr
+    amp = 0.03 * size if kind in (1, 2) else 0.0
+    while True:
+        moved = {k: (A @ ((p + g.normal(size=3) * amp) - ctr) + new_ctr).astype(np.float32) for k, p in pts.items()}
+        if len({m.tobytes() for m in moved.values()}) == len(moved):               # distinct corners stay distinct (else the sharing pattern would change)
+            break
+    for i, (pos, st, m) in enumerate(c.quads):
+        c.quads[i] = (np.array([moved[np.asarray(p, dtype=np.float32).tobytes()] for p in pos], dtype=np.float32), st, m)
+    eye = A @ (c.cam_pos.astype(np.float64) - ctr) + new_ctr
+    target = new_ctr + A @ (g.uniform(-0.2, 0.2, size=3) * size)
+    if kind == 3 and base != "plane-srgb":                                         # (the flattened box seen from its opening is a line: look around from inside)
+        eye = new_ctr + A @ (g.uniform(-0.35, 0.35, size=3) * size)
+        target = new_ctr + A @ (g.uniform(-0.35, 0.35, size=3) * size)
+    up = A @ np.array([0.0, 1.0, 0.0]); up /= np.linalg.norm(up)
+    c.set_camera(tuple(eye), tuple(target), up=tuple(up), vfov_deg=float(g.uniform(30.0, 70.0)))
+    opts = dict(indirect_only=bool(g.integers(0, 4) == 0), els=bool(g.integers(0, 4) != 0), flat_field=bool(g.integers(0, 4) != 0))
+    return c, base, opts

@@ -371,6 +371,29 @@ def test_random_scenes(seed):
     assert np.array_equal(bits(r.xyza), bits(ref)) or same_bits_or_both_nan(bits(r.xyza).reshape(-1, 4), bits(ref).reshape(-1, 4), range(4)).all()
 
 
+@pytest.mark.parametrize("seed", range(36))
+def test_warped_builtin_scenes_on_their_topology_kernels(seed):
+    """The fuzz of the kernels the headline numbers are measured on (tests/crafted.py warped_builtin): the Cornell box and the plane scene with every
+    distinct corner moved the same way wherever it occurs -- rotated / scaled / translated, jittered, flattened into slivers -- so the library keeps the
+    kernel whose pass 1 is specialised to the mesh topology (positions are run-time data there), against the oracle per sample and as an image."""
+    c, base, o = crafted.warped_builtin(seed)
+    orc = c.oracle()
+    r = Renderer(Options(scene_name=base, res=(8, 8), spp=1, texture=None if base == "cornell" else "test-img.png", observer=c.observer))
+    r.upload_scene_desc(c.desc(orc))
+    assert r.plan_info()["pass1"] == ("plane topology" if base == "plane-srgb" else "cornell topology")
+    W, H, spp = 28, 20, 4
+    r.options.res = (W, H); r.options.spp = spp; r.options.seed = 300 + seed
+    r.options.indirect_only = o["indirect_only"]; r.options.explicit_light_sampling = o["els"]; r.options.flat_field_correction = o["flat_field"]
+    xyza, state, _ = r.debug_samples()
+    ref_xyza, ref_state, st = orc.samples(W, H, spp, seed=300 + seed, indirect_only=o["indirect_only"], els=o["els"], flat_field=o["flat_field"])
+    assert np.array_equal(state, ref_state)
+    assert np.array_equal(bits(xyza), bits(ref_xyza)) or same_bits_or_both_nan(bits(xyza).reshape(-1, 4), bits(ref_xyza).reshape(-1, 4), range(4)).all()
+    r.xyza = np.zeros((H, W, 4), dtype=np.float32)
+    r.render_start(); r.render_wait()
+    ref = orc.render(W, H, spp, seed=300 + seed, indirect_only=o["indirect_only"], els=o["els"], flat_field=o["flat_field"])
+    assert np.array_equal(bits(r.xyza), bits(ref)) or same_bits_or_both_nan(bits(r.xyza).reshape(-1, 4), bits(ref).reshape(-1, 4), range(4)).all()
+
+
 def test_scene_limits_are_errors_not_surprises():
     c = crafted.many_prims_scene(129)
     orc = c.oracle()

@@ -128,3 +128,22 @@ def test_random_scenes_are_valid_and_varied():
         img = c.oracle().render(12, 10, 2, seed=seed, indirect_only=opts["indirect_only"], els=opts["els"], flat_field=opts["flat_field"])
         assert img.shape == (10, 12, 4)
     assert kinds >= {0, 1, "tri", "tex"} and len(seen_opts) >= 4
+
+
+def test_warped_builtin_scenes_keep_the_sharing_pattern():
+    """tests/crafted.py warped_builtin: the corners of the warped scene coincide exactly where the base scene's do (what the library's choice of the
+    topology-specialised kernel looks at), every kind of warp and every base scene occurs, and the oracle renders them."""
+    import custom_scene as cs
+    seen = set()
+    for seed in range(12):
+        c, base, opts = crafted.warped_builtin(seed)
+        b = cs.CustomScene(base)
+        ids_w, ids_b = {}, {}
+        pat_w = [[ids_w.setdefault(np.asarray(p, np.float32).tobytes(), len(ids_w)) for p in pos] for pos, _, _ in c.quads]
+        pat_b = [[ids_b.setdefault(np.asarray(p, np.float32).tobytes(), len(ids_b)) for p in pos] for pos, _, _ in b.quads]
+        assert pat_w == pat_b and len(ids_w) == (12 if base == "plane-srgb" else 28)
+        assert any(not np.array_equal(pw, pb) for (pw, _, _), (pb, _, _) in zip(c.quads, b.quads))
+        seen.add((base, (seed // 3) % 4))
+        img, st = c.oracle().render(12, 10, 2, seed=seed, indirect_only=opts["indirect_only"], els=opts["els"], flat_field=opts["flat_field"], stats=True)
+        assert img.shape == (10, 12, 4) and st.interactions > 0
+    assert len(seen) == 12
