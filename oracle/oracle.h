@@ -161,6 +161,7 @@ typedef struct {
 
 /* ---------- exported API (ctypes) ---------- */
 const char* orc_last_error(void);
+int orc_reference_shaped(void); /* 1: built with -DORACLE_REFERENCE_SHAPED (oracle_scene.c) */
 
 /* Color::init (color.cpp:72-155).  data_dir holds the CSV tables. */
 orc_color* orc_color_create(const char* data_dir, int observer);

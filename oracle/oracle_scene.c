@@ -16,6 +16,14 @@
  * primitive loop; glm::vec3::operator[] with a run-time index (geometry.cpp:26-37,45-47) reads an array in memory; the materials'
  * evaluate_bsdf / interact_bsdf / emission are virtual (material.hpp:60-110); the recursion goes through a std::function (renderer.cpp:148).
  * Here: out-of-line functions called through volatile function pointers, and an indexed temporary. */
+/* 1 in the reference-shaped build, 0 in the port: what tests/test_oracle_pins.py asks instead of timing the two */
+int orc_reference_shaped(void) {
+#ifdef ORACLE_REFERENCE_SHAPED
+	return 1;
+#else
+	return 0;
+#endif
+}
 #ifdef ORACLE_REFERENCE_SHAPED
 #define ORC_VIRTUAL __attribute__((noinline))
 static inline float v3_get_(const orc_v3* v, size_t k) { return (&v->x)[k]; } /* glm: `return (&x)[i]` */

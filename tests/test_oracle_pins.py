@@ -221,11 +221,10 @@ def test_reference_native_mode_follows_the_references_own_ordering():
     assert not np.array_equal(out, o.render(W, H, spp))                          # (not the per-sample seeding contract of the GPU path)
 
 
-def test_reference_shaped_build_has_the_oracles_bits_and_is_not_faster():
+def test_reference_shaped_build_has_the_oracles_bits():
     """oracle/libssx_oracle_refshape.so (bench.py: cpu_baseline.reference_equivalent) is the oracle's arithmetic in the reference binary's
     call structure -- virtual intersect per primitive, shear constants per triangle, indexed vec3 temporaries, recursion through a function
     pointer (oracle/oracle_scene.c) -- and nothing else: the same image bit for bit on all three scenes, per-sample work statistics included."""
-    import time
     for scene in ("cornell-srgb", "cornell", "plane-srgb"):
         a = ol.Oracle(scene, texture="test-img.png")
         b = ol.Oracle(scene, texture="test-img.png", variant="refshape")
@@ -233,8 +232,6 @@ def test_reference_shaped_build_has_the_oracles_bits_and_is_not_faster():
         ib, sb = b.render(32, 24, 3, seed=5, nthreads=2, stats=True)
         assert np.array_equal(ia.view(np.uint32), ib.view(np.uint32)), scene
         assert sa.as_dict() == sb.as_dict(), scene
-    # (a rate check would be a timing test; the structure is what the build flag guarantees -- but a shaped build that is FASTER than the
-    # port by a margin would mean the flag did not reach the compiler)
-    t = time.time(); a.render(64, 64, 4, nthreads=1); ta = time.time() - t
-    t = time.time(); b.render(64, 64, 4, nthreads=1); tb = time.time() - t
-    assert tb > 0.8 * ta, (ta, tb)
+    # (a rate check would be a timing test -- one was here and failed once on a busy machine; the structure is what the build flag guarantees,
+    # so the libraries are asked whether the flag reached the compiler)
+    assert a.lib.orc_reference_shaped() == 0 and b.lib.orc_reference_shaped() == 1
